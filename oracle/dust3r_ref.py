@@ -1,0 +1,205 @@
+"""ORACLE (test infrastructure only) -- CPU fp32 restatement of the reference's forward path.
+
+Restates, in plain PyTorch, what these reference files compute (citations are into
+/root/reference/):
+  dust3r/model.py:128-211          _encode_image / _encode_image_pairs / _encode_symmetrized /
+                                   _decoder / _downstream_head / forward
+  dust3r/model.py:91-98            load_state_dict duplicating dec_blocks -> dec_blocks2
+  dust3r/heads/dpt_head.py:34-115  DPTOutputAdapter_fix.forward, create_dpt_head
+  dust3r/heads/linear_head.py:30-41 LinearPts3d.forward
+  dust3r/heads/postprocess.py:10-58 postprocess / reg_dense_depth / reg_dense_conf
+  dust3r/utils/misc.py:32-51       is_symmetrized / interleave
+  dust3r/inference.py:32-72        loss_of_one_batch (criterion=None) / inference
+  dust3r/utils/device.py:47-76     collate_with_cat
+on top of the restated croco modules in oracle/croco_ref (PARITY UNPINNED for those:
+the croco submodule is absent from the reference snapshot).
+
+Pinning: tests/test_oracle_pins.py runs this restatement against the UNMODIFIED reference
+files (imported through oracle/ref_import.py, build container only) on seeded weights and
+inputs, and against tests/golden/forward_*.pt produced by oracle/make_golden.py from the
+reference itself. State-dict key names equal the reference's, so either side loads the
+other's weights.
+"""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(_HERE, 'croco_ref'), os.path.dirname(_HERE)):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+from models.croco import CroCoNet  # noqa: E402
+from models.dpt_block import DPTOutputAdapter  # noqa: E402
+
+inf = float('inf')
+
+
+# --------------------------------------------------------------------------- heads
+def postprocess_ref(out, depth_mode=('exp', -inf, inf), conf_mode=('exp', 1, inf)):
+    """postprocess.py:10-58. out (B,C,H,W) -> pts3d (B,H,W,3) [, conf (B,H,W)]."""
+    fmap = out.permute(0, 2, 3, 1)
+    xyz = fmap[..., 0:3]
+    mode = depth_mode[0]
+    if mode == 'linear':
+        pts = xyz
+    else:
+        d = xyz.norm(dim=-1, keepdim=True)
+        unit = xyz / d.clip(min=1e-8)
+        pts = unit * (torch.expm1(d) if mode == 'exp' else d.square())
+    res = dict(pts3d=pts)
+    if conf_mode is not None:
+        cmode, vmin, vmax = conf_mode
+        x = fmap[..., 3]
+        if cmode == 'exp':
+            res['conf'] = vmin + x.exp().clip(max=vmax - vmin)
+        else:
+            res['conf'] = (vmax - vmin) * torch.sigmoid(x) + vmin
+    return res
+
+
+class DPTHeadRef(nn.Module):
+    """PixelwiseTaskWithDPT + DPTOutputAdapter_fix (dpt_head.py:20-93)."""
+
+    def __init__(self, enc_dim, dec_dim, dec_depth, has_conf, depth_mode, conf_mode):
+        super().__init__()
+        assert dec_depth > 9
+        self.depth_mode, self.conf_mode = depth_mode, conf_mode
+        self.dpt = DPTOutputAdapter(num_channels=3 + has_conf, feature_dim=256, last_dim=128,
+                                    hooks=[0, dec_depth * 2 // 4, dec_depth * 3 // 4, dec_depth],
+                                    head_type='regression')
+        self.dpt.init(dim_tokens_enc=[enc_dim, dec_dim, dec_dim, dec_dim])
+        for n in (1, 2, 3, 4):                       # dpt_head.py:26-32: drop the aliased duplicates
+            delattr(self.dpt, f'act_{n}_postprocess')
+
+    def dpt_features(self, tokens, image_size):
+        d = self.dpt
+        H, W = image_size
+        nh, nw = H // (d.stride_level * d.P_H), W // (d.stride_level * d.P_W)
+        layers = [tokens[h] for h in d.hooks]
+        layers = [t.reshape(t.shape[0], nh, nw, t.shape[-1]).permute(0, 3, 1, 2) for t in layers]
+        layers = [d.act_postprocess[i](x) for i, x in enumerate(layers)]
+        layers = [d.scratch.layer_rn[i](x) for i, x in enumerate(layers)]
+        p4 = d.scratch.refinenet4(layers[3])[:, :, :layers[2].shape[2], :layers[2].shape[3]]
+        p3 = d.scratch.refinenet3(p4, layers[2])
+        p2 = d.scratch.refinenet2(p3, layers[1])
+        p1 = d.scratch.refinenet1(p2, layers[0])
+        return d.head(p1)
+
+    def forward(self, tokens, image_size):
+        return postprocess_ref(self.dpt_features(tokens, image_size), self.depth_mode, self.conf_mode)
+
+
+class LinearHeadRef(nn.Module):
+    """LinearPts3d (linear_head.py:12-41)."""
+
+    def __init__(self, dec_dim, patch_size, has_conf, depth_mode, conf_mode):
+        super().__init__()
+        self.patch_size = patch_size
+        self.depth_mode, self.conf_mode = depth_mode, conf_mode
+        self.proj = nn.Linear(dec_dim, (3 + has_conf) * patch_size ** 2)
+
+    def forward(self, tokens, image_size):
+        H, W = image_size
+        t = tokens[-1]
+        B = t.shape[0]
+        feat = self.proj(t).transpose(-1, -2).reshape(B, -1, H // self.patch_size, W // self.patch_size)
+        return postprocess_ref(F.pixel_shuffle(feat, self.patch_size), self.depth_mode, self.conf_mode)
+
+
+# --------------------------------------------------------------------------- model
+def _is_symmetrized(v1, v2):
+    x, y = v1['instance'], v2['instance']
+    if len(x) == len(y) == 1:
+        return False
+    return all(x[i] == y[i + 1] and x[i + 1] == y[i] for i in range(0, len(x), 2))
+
+
+def _interleave(a, b):
+    return (torch.stack((a, b), dim=1).flatten(0, 1), torch.stack((b, a), dim=1).flatten(0, 1))
+
+
+class DUSt3RRef(CroCoNet):
+    """Restated AsymmetricCroCo3DStereo (inference behaviour only; landscape_only=False)."""
+
+    def __init__(self, output_mode='pts3d', head_type='linear', depth_mode=('exp', -inf, inf),
+                 conf_mode=('exp', 1, inf), img_size=224, patch_size=16, **croco_kwargs):
+        super().__init__(img_size=img_size, patch_size=patch_size, **croco_kwargs)
+        import copy
+        self.patch_size = patch_size
+        self.dec_blocks2 = copy.deepcopy(self.dec_blocks)                          # model.py:72
+        has_conf = bool(conf_mode)
+        mk = (lambda: DPTHeadRef(self.enc_embed_dim, self.dec_embed_dim, self.dec_depth, has_conf, depth_mode,
+                                 conf_mode)) if head_type == 'dpt' else \
+             (lambda: LinearHeadRef(self.dec_embed_dim, patch_size, has_conf, depth_mode, conf_mode))
+        self.downstream_head1 = mk()
+        self.downstream_head2 = mk()
+        self.head_type = head_type
+
+    def _set_prediction_head(self, *a, **k):                                       # model.py:109-111
+        return
+
+    def load_state_dict(self, ckpt, **kw):                                         # model.py:91-98
+        ckpt = dict(ckpt)
+        if not any(k.startswith('dec_blocks2') for k in ckpt):
+            for k, v in list(ckpt.items()):
+                if k.startswith('dec_blocks'):
+                    ckpt[k.replace('dec_blocks', 'dec_blocks2')] = v
+        return super().load_state_dict(ckpt, **kw)
+
+    def encode(self, img):                                                         # model.py:128-140
+        x, pos = self.patch_embed(img)
+        for blk in self.enc_blocks:
+            x = blk(x, pos)
+        return self.enc_norm(x), pos
+
+    def decode(self, f1, pos1, f2, pos2):                                          # model.py:172-191
+        outs = [(f1, f2)]
+        f1, f2 = self.decoder_embed(f1), self.decoder_embed(f2)
+        for blk1, blk2 in zip(self.dec_blocks, self.dec_blocks2):
+            n1, _ = blk1(f1, f2, pos1, pos2)
+            n2, _ = blk2(f2, f1, pos2, pos1)
+            f1, f2 = n1, n2
+            outs.append((f1, f2))
+        outs[-1] = (self.dec_norm(outs[-1][0]), self.dec_norm(outs[-1][1]))
+        return [o[0] for o in outs], [o[1] for o in outs]
+
+    def forward(self, view1, view2):                                               # model.py:199-211
+        img1, img2 = view1['img'], view2['img']
+        B = img1.shape[0]
+        shape1 = view1.get('true_shape', torch.tensor(img1.shape[-2:])[None].repeat(B, 1))
+        shape2 = view2.get('true_shape', torch.tensor(img2.shape[-2:])[None].repeat(B, 1))
+        sym = _is_symmetrized(view1, view2)
+        if sym:
+            img1, img2 = img1[::2], img2[::2]
+        if img1.shape[-2:] == img2.shape[-2:]:
+            f, pos = self.encode(torch.cat((img1, img2), dim=0))
+            (f1, f2), (pos1, pos2) = f.chunk(2, dim=0), pos.chunk(2, dim=0)
+        else:
+            (f1, pos1), (f2, pos2) = self.encode(img1), self.encode(img2)
+        if sym:
+            f1, f2 = _interleave(f1, f2)
+            pos1, pos2 = _interleave(pos1, pos2)
+        dec1, dec2 = self.decode(f1, pos1, f2, pos2)
+        assert torch.as_tensor(shape1)[0:1].allclose(torch.as_tensor(shape1)), 'true_shape must be all identical'
+        hw1 = tuple(int(v) for v in torch.as_tensor(shape1)[0].tolist())
+        hw2 = tuple(int(v) for v in torch.as_tensor(shape2)[0].tolist())
+        res1 = self.downstream_head1([t.float() for t in dec1], hw1)
+        res2 = self.downstream_head2([t.float() for t in dec2], hw2)
+        res2['pts3d_in_other_view'] = res2.pop('pts3d')
+        return res1, res2
+
+
+from dust3r_amd.synthetic import MODEL_CONFIGS, OUT_GAIN, synthetic_state_dict, synthetic_views  # noqa: E402,F401
+
+
+def build_ref_model(config='DUSt3R_ViTLarge_BaseDecoder_512_dpt', seed=0, out_gain=None):
+    if out_gain is None:
+        out_gain = OUT_GAIN.get(config, 1.0) if isinstance(config, str) else 1.0
+    cfg = MODEL_CONFIGS[config] if isinstance(config, str) else config
+    model = DUSt3RRef(**cfg).eval()
+    model.load_state_dict(synthetic_state_dict(model.state_dict(), seed, out_gain))
+    return model
