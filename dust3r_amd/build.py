@@ -1,0 +1,57 @@
+"""Builds dust3r_amd/csrc/libdust3r_hip.so for gfx950 with hipcc (in-tree, so the library travels
+with the repository snapshot). Cross-compiles without a GPU."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+SOURCES = ['gemm.hip', 'attention.hip', 'elementwise.hip', 'aligner.hip', 'engine.hip', 'capi.hip']
+HEADERS = ['common.hpp', 'kernels.hpp', 'aligner_math.hpp', os.path.join('..', '..', 'include', 'dust3r_hip.h')]
+LIB = os.path.join(CSRC, 'libdust3r_hip.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError('hipcc not found')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = _hipcc()
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed:\n{r.stdout}\n{r.stderr}')
+        return r
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

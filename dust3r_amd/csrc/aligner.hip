@@ -1,0 +1,624 @@
+// dust3r_amd -- fused global-aligner iteration (gfx950, HBM-bound).
+//
+// Replaces the reference's hot loop #5: `global_alignment_iter` = PointCloudOptimizer.forward
+// (~25 elementwise/bmm kernels over (E, A, 3) tensors) + autograd backward + torch Adam
+// (reference dust3r/cloud_opt/base_opt.py:326-366, optimizer.py:188-201). One iteration here is
+// three launches with no host synchronisation:
+//   1. aligner_main_kernel   one pass over every (edge side, pixel): residuals, loss, dL/dX,
+//                            per-pixel log-depth gradient + its Adam step, and per-wave partial
+//                            sums of dL/dM_e (3x4) and of the per-image pose/focal terms.
+//                            Image-major: a thread owns 4 pixels of image i and walks the
+//                            edges incident to i, so each pred/weight byte is read exactly once
+//                            (32 B per edge-pixel, the algorithmic minimum of SURVEY.md 8(d))
+//                            and the depth gradient needs no atomics.
+//   2. aligner_reduce_kernel fixed-order fp64 reduction of the partials (deterministic).
+//   3. aligner_small_kernel  chain rule to (quaternion, log-translation, log-scale, log-focal),
+//                            Adam on those few thousand parameters, loss bookkeeping, and the
+//                            derived matrices (M_e, R_i, T_i, F_i) for the next iteration.
+#include "aligner_math.hpp"
+#include "kernels.hpp"
+
+namespace d3r {
+
+static constexpr int PPT = 4;            // pixels per thread
+static constexpr int CHUNK = 256 * PPT;  // pixels per workgroup
+static constexpr int PW = 16;            // floats per partial record
+
+struct AlignerView {
+    int n, E, maxA, nslot;  // nslot = waves per image = nchunk * 4
+    const int* img_w;       // [n]
+    const int* img_area;    // [n]
+    const int* adj_off;     // [n+1]
+    const int* adj_es;      // [2E] entries e*2+side, grouped by projecting image
+    const float* pred[2];   // [E][maxA][3]
+    const float* wgt[2];    // [E][maxA]
+    float* depth;           // [n][maxA] log-depth
+    float* depth_m;
+    float* depth_v;
+    float* depth_grad;      // optional export (tests)
+    const float* d_edge;    // derived [E][12]  M_e
+    const float* d_img;     // derived [n][16]  R(9) T(3) F ppx ppy -
+    float* part_edge;       // [2E][nslot][16]: gm(12) loss(1)
+    float* part_img;        // [n][nslot][16]:  G = sum g (x) cam (9), sum g (3), sum g*exp(d) (3)
+    float inv_area[2];
+    int l2, update, use_dpp;
+    AdamCoef adam;
+};
+
+// ---- wave reduction: result valid in lane 63 -------------------------------------------------------
+D3R_DEV float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1,3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));  // row_bcast31 -> rows 2,3
+    return v;
+}
+D3R_DEV float wave_sum_shfl(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
+    const int nchunk = a.nslot >> 2;
+    const int img = blockIdx.x / nchunk, chunk = blockIdx.x - img * nchunk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p0 = chunk * CHUNK + threadIdx.x * PPT;
+    const int area = a.img_area[img], W = a.img_w[img];
+    const bool active = p0 < a.maxA;  // maxA % 4 == 0: the 4 pixels are in or out together
+
+    const float* di = a.d_img + img * 16;
+    float R[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = di[k];
+    const float T0 = di[9], T1 = di[10], T2 = di[11], F = di[12], ppx = di[13], ppy = di[14];
+    const float invF = 1.0f / F;
+
+    float X[PPT][3], cam[PPT][3], g[PPT][3], ed[PPT];
+    float4 dlog = make_float4(0, 0, 0, 0);
+    if (active) dlog = *reinterpret_cast<const float4*>(a.depth + (size_t)img * a.maxA + p0);
+    const float dl[4] = {dlog.x, dlog.y, dlog.z, dlog.w};
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = p0 + k;
+        // padded pixels (p >= area) use grid (0,0) like the reference's zero padded _grid (optimizer.py:47-48)
+        const int v = p < area ? p / W : 0, u = p < area ? p - v * W : 0;
+        ed[k] = expf(dl[k]);
+        cam[k][0] = ed[k] * ((float)u - ppx) * invF;
+        cam[k][1] = ed[k] * ((float)v - ppy) * invF;
+        cam[k][2] = ed[k];
+        X[k][0] = R[0] * cam[k][0] + R[1] * cam[k][1] + R[2] * cam[k][2] + T0;
+        X[k][1] = R[3] * cam[k][0] + R[4] * cam[k][1] + R[5] * cam[k][2] + T1;
+        X[k][2] = R[6] * cam[k][0] + R[7] * cam[k][1] + R[8] * cam[k][2] + T2;
+        g[k][0] = g[k][1] = g[k][2] = 0.f;
+    }
+
+    const int slot = chunk * 4 + wave;
+    const int a0 = a.adj_off[img], a1 = a.adj_off[img + 1];
+    for (int ai = a0; ai < a1; ++ai) {
+        const int es = a.adj_es[ai];
+        const int e = es >> 1, side = es & 1;
+        const float* Mp = a.d_edge + e * 12;
+        float M[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) M[k] = Mp[k];
+        float gm[12], loss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) gm[k] = 0.f;
+        if (active) {
+            const float4* pp = reinterpret_cast<const float4*>(a.pred[side] + ((size_t)e * a.maxA + p0) * 3);
+            const float4 q0 = pp[0], q1 = pp[1], q2 = pp[2];
+            const float4 ww = *reinterpret_cast<const float4*>(a.wgt[side] + (size_t)e * a.maxA + p0);
+            const float pr[PPT][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, {q1.z, q1.w, q2.x}, {q2.y, q2.z, q2.w}};
+            const float wv[PPT] = {ww.x * a.inv_area[side], ww.y * a.inv_area[side], ww.z * a.inv_area[side], ww.w * a.inv_area[side]};
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) residual_accumulate(X[k], M, pr[k], wv[k], a.l2 != 0, loss, g[k], gm);
+        }
+        float red[13];
+        if (a.use_dpp) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) red[k] = wave_sum_dpp(gm[k]);
+            red[12] = wave_sum_dpp(loss);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) red[k] = wave_sum_shfl(gm[k]);
+            red[12] = wave_sum_shfl(loss);
+        }
+        if (lane == 63) {
+            float4* dst = reinterpret_cast<float4*>(a.part_edge + ((size_t)es * a.nslot + slot) * PW);
+            dst[0] = make_float4(red[0], red[1], red[2], red[3]);
+            dst[1] = make_float4(red[4], red[5], red[6], red[7]);
+            dst[2] = make_float4(red[8], red[9], red[10], red[11]);
+            dst[3] = make_float4(red[12], 0.f, 0.f, 0.f);
+        }
+    }
+
+    // ---- per-pixel log-depth gradient (+ Adam) and per-image partial sums ------------------------
+    float pi[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) pi[k] = 0.f;
+    float gd[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        // dX/dd = R cam = X - T
+        gd[k] = g[k][0] * (X[k][0] - T0) + g[k][1] * (X[k][1] - T1) + g[k][2] * (X[k][2] - T2);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pi[r * 3 + c] += g[k][r] * cam[k][c];
+            pi[9 + r] += g[k][r];
+            pi[12 + r] += g[k][r] * ed[k];
+        }
+    }
+    if (active) {
+        const size_t off = (size_t)img * a.maxA + p0;
+        if (a.depth_grad) *reinterpret_cast<float4*>(a.depth_grad + off) = make_float4(gd[0], gd[1], gd[2], gd[3]);
+        if (a.update) {
+            float4 m4 = *reinterpret_cast<const float4*>(a.depth_m + off);
+            float4 v4 = *reinterpret_cast<const float4*>(a.depth_v + off);
+            float4 o;
+            o.x = adam_update(dl[0], gd[0], m4.x, v4.x, a.adam);
+            o.y = adam_update(dl[1], gd[1], m4.y, v4.y, a.adam);
+            o.z = adam_update(dl[2], gd[2], m4.z, v4.z, a.adam);
+            o.w = adam_update(dl[3], gd[3], m4.w, v4.w, a.adam);
+            *reinterpret_cast<float4*>(a.depth + off) = o;
+            *reinterpret_cast<float4*>(a.depth_m + off) = m4;
+            *reinterpret_cast<float4*>(a.depth_v + off) = v4;
+        }
+    }
+    float red[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) red[k] = a.use_dpp ? wave_sum_dpp(pi[k]) : wave_sum_shfl(pi[k]);
+    if (lane == 63) {
+        float4* dst = reinterpret_cast<float4*>(a.part_img + ((size_t)img * a.nslot + slot) * PW);
+        dst[0] = make_float4(red[0], red[1], red[2], red[3]);
+        dst[1] = make_float4(red[4], red[5], red[6], red[7]);
+        dst[2] = make_float4(red[8], red[9], red[10], red[11]);
+        dst[3] = make_float4(red[12], red[13], red[14], 0.f);
+    }
+}
+
+// ---- fixed-order fp64 reduction of [entries][nslot][16] partial records --------------------------------
+__global__ __launch_bounds__(256) void aligner_reduce_kernel(const float* __restrict__ part, double* __restrict__ out, int nslot) {
+    __shared__ double sh[16][17];
+    const int entry = blockIdx.x;
+    const int val = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const float* base = part + (size_t)entry * nslot * PW;
+    double acc = 0.0;
+    for (int s = sl; s < nslot; s += 16) acc += (double)base[(size_t)s * PW + val];
+    sh[sl][val] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][threadIdx.x];
+        out[(size_t)entry * PW + threadIdx.x] = t;
+    }
+}
+
+struct SmallView {
+    int n, E;
+    float* pw_poses;     // [E][8]
+    const float* pw_adaptors;  // [E][2]
+    float* im_poses;     // [n][7]
+    float* im_focals;    // [n]
+    const float* im_pp;  // [n][2]
+    const int* img_w; const int* img_h;
+    float *pw_m, *pw_v, *imp_m, *imp_v, *foc_m, *foc_v;
+    const double* red_edge;  // [2E][16]
+    const double* red_img;   // [n][16]
+    float* d_edge;           // [E][12]
+    float* d_img;            // [n][16]
+    double* scratch;         // [E] gs*s~ ; [1] sum
+    float* loss_hist; int iter;
+    float* g_pw; float* g_imp; float* g_foc;  // optional gradient export (tests)
+    float base_scale, pw_break, focal_break;
+    int norm_pw_scale, opt_poses, opt_focals, update;
+    AdamCoef adam;
+};
+
+D3R_DEV float pw_scale_factor(const SmallView& s, double mean_p7) {
+    return s.norm_pw_scale ? expf(logf(s.base_scale) - (float)mean_p7) : 1.0f;
+}
+
+// single workgroup; E and n are a few hundred at most per call site (E <= 600)
+__global__ __launch_bounds__(256) void aligner_small_kernel(SmallView s) {
+    __shared__ double sh_sum;
+    __shared__ double sh_mean;
+    const int tid = threadIdx.x;
+    if (s.update || s.g_pw) {
+        // mean of P7 BEFORE the update defines the s~ the gradients were taken at
+        if (tid == 0) {
+            double m = 0.0;
+            for (int e = 0; e < s.E; ++e) m += (double)s.pw_poses[e * 8 + 7];
+            sh_mean = m / (double)s.E;
+        }
+        __syncthreads();
+        const float nf = pw_scale_factor(s, sh_mean);
+        // pass 1: dL/ds~_e * s~_e
+        for (int e = tid; e < s.E; e += 256) {
+            const float* P = s.pw_poses + e * 8;
+            float R[9];
+            quat_to_rotmat(P, R);
+            const float st = expf(P[7]) * nf;
+            float adapt[3];
+            {
+                const float a0 = s.pw_adaptors[e * 2], a1 = s.pw_adaptors[e * 2 + 1];
+                const float mean = s.norm_pw_scale ? (2.f * a0 + a1) / 3.f : 0.f;
+                adapt[0] = adapt[1] = expf((a0 - mean) / s.pw_break);
+                adapt[2] = expf((a1 - mean) / s.pw_break);
+            }
+            double GM[12], gP[7], gs;
+            for (int k = 0; k < 12; ++k) GM[k] = s.red_edge[(size_t)(2 * e) * PW + k] + s.red_edge[(size_t)(2 * e + 1) * PW + k];
+            edge_chain(P, R, st, adapt, GM, gP, gs);
+            s.scratch[e] = gs * (double)st;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int e = 0; e < s.E; ++e) t += s.scratch[e];
+            sh_sum = t;
+            if (s.loss_hist) {
+                double l = 0.0;
+                for (int k = 0; k < 2 * s.E; ++k) l += s.red_edge[(size_t)k * PW + 12];
+                s.loss_hist[s.iter] = (float)l;
+            }
+        }
+        __syncthreads();
+        // pass 2: gradients + Adam on pairwise poses
+        for (int e = tid; e < s.E; e += 256) {
+            float* P = s.pw_poses + e * 8;
+            float R[9];
+            quat_to_rotmat(P, R);
+            const float st = expf(P[7]) * nf;
+            float adapt[3];
+            {
+                const float a0 = s.pw_adaptors[e * 2], a1 = s.pw_adaptors[e * 2 + 1];
+                const float mean = s.norm_pw_scale ? (2.f * a0 + a1) / 3.f : 0.f;
+                adapt[0] = adapt[1] = expf((a0 - mean) / s.pw_break);
+                adapt[2] = expf((a1 - mean) / s.pw_break);
+            }
+            double GM[12], gP[8], gs;
+            for (int k = 0; k < 12; ++k) GM[k] = s.red_edge[(size_t)(2 * e) * PW + k] + s.red_edge[(size_t)(2 * e + 1) * PW + k];
+            edge_chain(P, R, st, adapt, GM, gP, gs);
+            gP[7] = s.scratch[e] - (s.norm_pw_scale ? sh_sum / (double)s.E : 0.0);
+            if (s.g_pw)
+                for (int k = 0; k < 8; ++k) s.g_pw[e * 8 + k] = (float)gP[k];
+            if (s.update)
+                for (int k = 0; k < 8; ++k) P[k] = adam_update(P[k], (float)gP[k], s.pw_m[e * 8 + k], s.pw_v[e * 8 + k], s.adam);
+        }
+        // image poses / focals
+        for (int i = tid; i < s.n; i += 256) {
+            float* P = s.im_poses + i * 7;
+            float R[9];
+            quat_to_rotmat(P, R);
+            double G[9], GT[3], gP[7], gf;
+            for (int k = 0; k < 9; ++k) G[k] = s.red_img[(size_t)i * PW + k];
+            for (int k = 0; k < 3; ++k) GT[k] = s.red_img[(size_t)i * PW + 9 + k];
+            image_chain(P, R, s.focal_break, G, GT, gP, gf);
+            if (s.g_imp)
+                for (int k = 0; k < 7; ++k) s.g_imp[i * 7 + k] = (float)gP[k];
+            if (s.g_foc) s.g_foc[i] = (float)gf;
+            if (s.update && s.opt_poses)
+                for (int k = 0; k < 7; ++k) P[k] = adam_update(P[k], (float)gP[k], s.imp_m[i * 7 + k], s.imp_v[i * 7 + k], s.adam);
+            if (s.update && s.opt_focals) s.im_focals[i] = adam_update(s.im_focals[i], (float)gf, s.foc_m[i], s.foc_v[i], s.adam);
+        }
+        __syncthreads();
+    }
+    // ---- derived quantities for the next main pass ---------------------------------------------------
+    if (tid == 0) {
+        double m = 0.0;
+        for (int e = 0; e < s.E; ++e) m += (double)s.pw_poses[e * 8 + 7];
+        sh_mean = m / (double)s.E;
+    }
+    __syncthreads();
+    const float nf = pw_scale_factor(s, sh_mean);
+    for (int e = tid; e < s.E; e += 256) {
+        const float* P = s.pw_poses + e * 8;
+        float R[9];
+        quat_to_rotmat(P, R);
+        const float st = expf(P[7]) * nf;
+        const float a0 = s.pw_adaptors[e * 2], a1 = s.pw_adaptors[e * 2 + 1];
+        const float mean = s.norm_pw_scale ? (2.f * a0 + a1) / 3.f : 0.f;
+        const float ad[3] = {expf((a0 - mean) / s.pw_break), expf((a0 - mean) / s.pw_break), expf((a1 - mean) / s.pw_break)};
+        float* M = s.d_edge + e * 12;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) M[r * 4 + c] = st * R[r * 3 + c] * ad[c];
+            M[r * 4 + 3] = st * signed_expm1f(P[4 + r]);
+        }
+    }
+    for (int i = tid; i < s.n; i += 256) {
+        const float* P = s.im_poses + i * 7;
+        float* D = s.d_img + i * 16;
+        quat_to_rotmat(P, D);
+        D[9] = signed_expm1f(P[4]);
+        D[10] = signed_expm1f(P[5]);
+        D[11] = signed_expm1f(P[6]);
+        D[12] = expf(s.im_focals[i] / s.focal_break);
+        D[13] = 0.5f * (float)s.img_w[i] + 10.f * s.im_pp[i * 2];
+        D[14] = 0.5f * (float)s.img_h[i] + 10.f * s.im_pp[i * 2 + 1];
+        D[15] = 0.f;
+    }
+}
+
+}  // namespace d3r
+
+// =====================================================================================================
+// C-ABI (include/dust3r_hip.h)
+// =====================================================================================================
+#include <vector>
+#include <new>
+#include "../../include/dust3r_hip.h"
+
+using namespace d3r;
+
+struct d3r_aligner {
+    int n = 0, E = 0, maxA = 0, nslot = 0;
+    std::vector<int> h_w, h_h, h_area;
+    int *d_w = nullptr, *d_h = nullptr, *d_area = nullptr, *d_adj_off = nullptr, *d_adj_es = nullptr;
+    const float *pred[2] = {nullptr, nullptr}, *wgt[2] = {nullptr, nullptr};
+    float *pw_poses = nullptr, *pw_adaptors = nullptr, *im_poses = nullptr, *im_depth = nullptr, *im_focals = nullptr, *im_pp = nullptr;
+    float* state = nullptr;  // one arena: Adam moments, derived matrices, partials
+    float *depth_m, *depth_v, *pw_m, *pw_v, *imp_m, *imp_v, *foc_m, *foc_v, *d_edge, *d_img, *part_edge, *part_img, *loss_hist, *g_scratch;
+    double *red_edge, *red_img, *scratch;
+    size_t state_bytes = 0;
+    float base_scale = 0.5f, pw_break = 20.f, focal_break = 20.f, inv_area[2] = {0, 0};
+    int l2 = 0, norm_pw_scale = 1, opt_poses = 1, opt_focals = 1, use_dpp = 1;
+    long step = 0;
+    int loss_cap = 0;
+};
+
+#define HIPCHK(x)                                  \
+    do {                                           \
+        hipError_t e_ = (x);                       \
+        if (e_ != hipSuccess) return (int)e_ + 1000; \
+    } while (0)
+
+extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, const int* ei, const int* ej, const int* img_h,
+                                  const int* img_w, int max_area, const float* pred_i, const float* pred_j, const float* w_i,
+                                  const float* w_j, float* pw_poses, float* pw_adaptors, float* im_poses, float* im_depth,
+                                  float* im_focals, float* im_pp, float base_scale, float pw_break, float focal_break, int dist_l2,
+                                  int norm_pw_scale, int opt_poses, int opt_focals, int max_iters) {
+    if (!out || n_imgs <= 0 || n_edges <= 0 || max_area <= 0 || max_area % 4 != 0) return D3R_ERR_INVALID;
+    d3r_aligner* a = new (std::nothrow) d3r_aligner();
+    if (!a) return D3R_ERR_ALLOC;
+    a->n = n_imgs; a->E = n_edges; a->maxA = max_area;
+    a->nslot = cdiv(max_area, CHUNK) * 4;
+    a->h_w.assign(img_w, img_w + n_imgs);
+    a->h_h.assign(img_h, img_h + n_imgs);
+    a->h_area.resize(n_imgs);
+    double ta[2] = {0, 0};
+    for (int i = 0; i < n_imgs; ++i) {
+        a->h_area[i] = img_h[i] * img_w[i];
+        if (a->h_area[i] > max_area || a->h_area[i] % 4 != 0) { delete a; return D3R_ERR_INVALID; }
+    }
+    // adjacency (CSR by projecting image): side 0 entries project onto ei, side 1 onto ej
+    std::vector<int> off(n_imgs + 1, 0), es(2 * (size_t)n_edges);
+    for (int e = 0; e < n_edges; ++e) {
+        if (ei[e] < 0 || ei[e] >= n_imgs || ej[e] < 0 || ej[e] >= n_imgs) { delete a; return D3R_ERR_INVALID; }
+        off[ei[e] + 1]++; off[ej[e] + 1]++;
+        ta[0] += a->h_area[ei[e]]; ta[1] += a->h_area[ej[e]];
+    }
+    for (int i = 0; i < n_imgs; ++i) off[i + 1] += off[i];
+    {
+        std::vector<int> cur(off.begin(), off.end() - 1);
+        for (int e = 0; e < n_edges; ++e) { es[cur[ei[e]]++] = 2 * e; es[cur[ej[e]]++] = 2 * e + 1; }
+    }
+    a->inv_area[0] = (float)(1.0 / ta[0]);
+    a->inv_area[1] = (float)(1.0 / ta[1]);
+    a->pred[0] = pred_i; a->pred[1] = pred_j; a->wgt[0] = w_i; a->wgt[1] = w_j;
+    a->pw_poses = pw_poses; a->pw_adaptors = pw_adaptors; a->im_poses = im_poses; a->im_depth = im_depth;
+    a->im_focals = im_focals; a->im_pp = im_pp;
+    a->base_scale = base_scale; a->pw_break = pw_break; a->focal_break = focal_break;
+    a->l2 = dist_l2; a->norm_pw_scale = norm_pw_scale; a->opt_poses = opt_poses; a->opt_focals = opt_focals;
+    a->loss_cap = max_iters > 0 ? max_iters : 1;
+
+    const size_t nA = (size_t)n_imgs * max_area;
+    size_t fl = 0;
+    auto take = [&](size_t cnt) { size_t o = fl; fl += (cnt + 3) & ~(size_t)3; return o; };
+    const size_t o_dm = take(nA), o_dv = take(nA), o_pwm = take((size_t)n_edges * 8), o_pwv = take((size_t)n_edges * 8),
+                 o_im = take((size_t)n_imgs * 7), o_iv = take((size_t)n_imgs * 7), o_fm = take(n_imgs), o_fv = take(n_imgs),
+                 o_de = take((size_t)n_edges * 12), o_di = take((size_t)n_imgs * 16),
+                 o_pe = take((size_t)2 * n_edges * a->nslot * PW), o_pi = take((size_t)n_imgs * a->nslot * PW),
+                 o_lh = take(a->loss_cap), o_gs = take((size_t)n_edges * 8);
+    const size_t dbl = ((size_t)2 * n_edges * PW + (size_t)n_imgs * PW + n_edges + 8);
+    a->state_bytes = fl * sizeof(float) + dbl * sizeof(double) + 64;
+    if (hipMalloc((void**)&a->state, a->state_bytes) != hipSuccess) { delete a; return D3R_ERR_ALLOC; }
+    (void)hipMemset(a->state, 0, a->state_bytes);
+    float* b = a->state;
+    a->depth_m = b + o_dm; a->depth_v = b + o_dv; a->pw_m = b + o_pwm; a->pw_v = b + o_pwv; a->imp_m = b + o_im;
+    a->imp_v = b + o_iv; a->foc_m = b + o_fm; a->foc_v = b + o_fv; a->d_edge = b + o_de; a->d_img = b + o_di;
+    a->part_edge = b + o_pe; a->part_img = b + o_pi; a->loss_hist = b + o_lh; a->g_scratch = b + o_gs;
+    double* db = reinterpret_cast<double*>(reinterpret_cast<char*>(b) + ((fl * sizeof(float) + 63) & ~(size_t)63));
+    a->red_edge = db; a->red_img = db + (size_t)2 * n_edges * PW; a->scratch = a->red_img + (size_t)n_imgs * PW;
+
+    const size_t ib = (3 * (size_t)n_imgs + (n_imgs + 1) + 2 * (size_t)n_edges) * sizeof(int);
+    if (hipMalloc((void**)&a->d_w, ib) != hipSuccess) { (void)hipFree(a->state); delete a; return D3R_ERR_ALLOC; }
+    a->d_h = a->d_w + n_imgs; a->d_area = a->d_h + n_imgs; a->d_adj_off = a->d_area + n_imgs; a->d_adj_es = a->d_adj_off + n_imgs + 1;
+    (void)hipMemcpy(a->d_w, a->h_w.data(), n_imgs * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(a->d_h, a->h_h.data(), n_imgs * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(a->d_area, a->h_area.data(), n_imgs * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(a->d_adj_off, off.data(), (n_imgs + 1) * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(a->d_adj_es, es.data(), 2 * (size_t)n_edges * sizeof(int), hipMemcpyHostToDevice);
+    *out = a;
+    return D3R_OK;
+}
+
+extern "C" int d3r_aligner_destroy(d3r_aligner* a) {
+    if (!a) return D3R_OK;
+    (void)hipFree(a->state);
+    (void)hipFree(a->d_w);
+    delete a;
+    return D3R_OK;
+}
+
+static AdamCoef adam_coef(double lr, long step) {
+    const double b1 = 0.9, b2 = 0.9;  // base_opt.py:337 betas=(0.9, 0.9)
+    AdamCoef c;
+    c.b1 = (float)b1; c.b2 = (float)b2; c.eps = 1e-8f;
+    c.step_size = (float)(lr / (1.0 - pow(b1, (double)step)));
+    c.bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)step));
+    return c;
+}
+
+static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, float* g_pw, float* g_imp, float* g_depth, float* g_foc,
+                        bool refresh_derived_first, hipStream_t st) {
+    SmallView s;
+    s.n = a->n; s.E = a->E; s.pw_poses = a->pw_poses; s.pw_adaptors = a->pw_adaptors; s.im_poses = a->im_poses;
+    s.im_focals = a->im_focals; s.im_pp = a->im_pp; s.img_w = a->d_w; s.img_h = a->d_h;
+    s.pw_m = a->pw_m; s.pw_v = a->pw_v; s.imp_m = a->imp_m; s.imp_v = a->imp_v; s.foc_m = a->foc_m; s.foc_v = a->foc_v;
+    s.red_edge = a->red_edge; s.red_img = a->red_img; s.d_edge = a->d_edge; s.d_img = a->d_img; s.scratch = a->scratch;
+    s.loss_hist = a->loss_hist; s.iter = hist_idx; s.g_pw = nullptr; s.g_imp = nullptr; s.g_foc = nullptr;
+    s.base_scale = a->base_scale; s.pw_break = a->pw_break; s.focal_break = a->focal_break;
+    s.norm_pw_scale = a->norm_pw_scale; s.opt_poses = a->opt_poses; s.opt_focals = a->opt_focals;
+    s.update = 0; s.adam = adam_coef(lr, a->step + 1);
+    if (refresh_derived_first) {
+        SmallView s0 = s;
+        s0.loss_hist = nullptr;
+        hipLaunchKernelGGL(aligner_small_kernel, dim3(1), dim3(256), 0, st, s0);
+    }
+    AlignerView v;
+    v.n = a->n; v.E = a->E; v.maxA = a->maxA; v.nslot = a->nslot; v.img_w = a->d_w; v.img_area = a->d_area;
+    v.adj_off = a->d_adj_off; v.adj_es = a->d_adj_es; v.pred[0] = a->pred[0]; v.pred[1] = a->pred[1];
+    v.wgt[0] = a->wgt[0]; v.wgt[1] = a->wgt[1]; v.depth = a->im_depth; v.depth_m = a->depth_m; v.depth_v = a->depth_v;
+    v.depth_grad = g_depth; v.d_edge = a->d_edge; v.d_img = a->d_img; v.part_edge = a->part_edge; v.part_img = a->part_img;
+    v.inv_area[0] = a->inv_area[0]; v.inv_area[1] = a->inv_area[1]; v.l2 = a->l2; v.update = update ? 1 : 0;
+    v.use_dpp = a->use_dpp; v.adam = s.adam;
+    hipLaunchKernelGGL(aligner_main_kernel, dim3(a->n * (a->nslot / 4)), dim3(256), 0, st, v);
+    hipLaunchKernelGGL(aligner_reduce_kernel, dim3(2 * a->E), dim3(256), 0, st, a->part_edge, a->red_edge, a->nslot);
+    hipLaunchKernelGGL(aligner_reduce_kernel, dim3(a->n), dim3(256), 0, st, a->part_img, a->red_img, a->nslot);
+    s.update = update ? 1 : 0;
+    s.g_pw = g_pw; s.g_imp = g_imp; s.g_foc = g_foc;
+    hipLaunchKernelGGL(aligner_small_kernel, dim3(1), dim3(256), 0, st, s);
+    if (update) a->step++;
+    return hipGetLastError() == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
+}
+
+extern "C" int d3r_aligner_set_option(d3r_aligner* a, int option, int value) {
+    if (!a) return D3R_ERR_INVALID;
+    switch (option) {
+        case D3R_ALIGNER_OPT_DPP_REDUCE: a->use_dpp = value; return D3R_OK;
+        case D3R_ALIGNER_OPT_RESET_ADAM:
+            (void)hipMemset(a->depth_m, 0, (size_t)((char*)a->d_edge - (char*)a->depth_m));
+            a->step = 0;
+            return D3R_OK;
+    }
+    return D3R_ERR_INVALID;
+}
+
+// niter iterations of global_alignment_iter; lr follows the reference schedule evaluated at
+// t = (iter0 + k) / niter_total (base_opt.py:352-366, commons.py:83-90). losses (device or null).
+extern "C" int d3r_aligner_run(d3r_aligner* a, int niter, int iter0, int niter_total, float lr_base, float lr_min, int schedule,
+                               float* losses_out_device, void* stream) {
+    if (!a || niter <= 0 || niter > a->loss_cap || niter_total <= 0) return D3R_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    for (int k = 0; k < niter; ++k) {
+        const double t = (double)(iter0 + k) / (double)niter_total;
+        const double lr = schedule == D3R_SCHEDULE_COSINE ? (double)lr_min + ((double)lr_base - (double)lr_min) * (1.0 + cos(t * M_PI)) / 2.0
+                                                          : (double)lr_base + ((double)lr_min - (double)lr_base) * t;
+        const int rc = aligner_pass(a, true, lr, k, nullptr, nullptr, nullptr, nullptr, k == 0, st);
+        if (rc != D3R_OK) return rc;
+    }
+    if (losses_out_device) HIPCHK(hipMemcpyAsync(losses_out_device, a->loss_hist, niter * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return D3R_OK;
+}
+
+// one forward/backward WITHOUT a step: loss (device float[1]) and gradients (device, any may be null)
+extern "C" int d3r_aligner_loss_grad(d3r_aligner* a, float* loss_device, float* g_pw_poses, float* g_im_poses, float* g_im_depth,
+                                     float* g_im_focals, void* stream) {
+    if (!a) return D3R_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    float* gpw = g_pw_poses ? g_pw_poses : a->g_scratch;  // forces the gradient branch of the small kernel
+    const int rc = aligner_pass(a, false, 0.0, 0, gpw, g_im_poses, g_im_depth, g_im_focals, true, st);
+    if (rc != D3R_OK) return rc;
+    if (loss_device) HIPCHK(hipMemcpyAsync(loss_device, a->loss_hist, sizeof(float), hipMemcpyDeviceToDevice, st));
+    return D3R_OK;
+}
+
+// ---- host-only self test of the analytic gradients (no GPU): used by the CPU test-suite to check
+// aligner_math.hpp against autograd before any kernel runs. NOT a compute path of the product.
+extern "C" int d3r_selftest_aligner_math_host(int n_imgs, int n_edges, const int* ei, const int* ej, int H, int W,
+                                              const float* pred_i, const float* pred_j, const float* w_i, const float* w_j,
+                                              const float* pw_poses, const float* im_poses, const float* im_depth,
+                                              const float* im_focals, float base_scale, float focal_break, double* loss_out,
+                                              double* g_pw, double* g_imp, double* g_depth, double* g_foc) {
+    const int A = H * W;
+    const double inv_area = 1.0 / ((double)n_edges * A);
+    double mean7 = 0.0;
+    for (int e = 0; e < n_edges; ++e) mean7 += pw_poses[e * 8 + 7];
+    mean7 /= n_edges;
+    const float nf = expf(logf(base_scale) - (float)mean7);
+    std::vector<double> GM((size_t)n_edges * 12, 0.0), GI((size_t)n_imgs * 9, 0.0), GT((size_t)n_imgs * 3, 0.0);
+    std::vector<float> gx((size_t)n_imgs * A * 3, 0.f);
+    std::vector<float> Rimg((size_t)n_imgs * 9);
+    double loss = 0.0;
+    for (int i = 0; i < n_imgs; ++i) quat_to_rotmat(im_poses + i * 7, &Rimg[i * 9]);
+    auto point = [&](int i, int p, float X[3], float cam[3]) {
+        const float* R = &Rimg[i * 9];
+        const float F = expf(im_focals[i] / focal_break), ed = expf(im_depth[(size_t)i * A + p]);
+        const int v = p / W, u = p - v * W;
+        cam[0] = ed * ((float)u - 0.5f * W) / F; cam[1] = ed * ((float)v - 0.5f * H) / F; cam[2] = ed;
+        for (int r = 0; r < 3; ++r)
+            X[r] = R[r * 3] * cam[0] + R[r * 3 + 1] * cam[1] + R[r * 3 + 2] * cam[2] + signed_expm1f(im_poses[i * 7 + 4 + r]);
+    };
+    for (int e = 0; e < n_edges; ++e) {
+        const float* P = pw_poses + e * 8;
+        float R[9], M[12];
+        quat_to_rotmat(P, R);
+        const float st = expf(P[7]) * nf;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) M[r * 4 + c] = st * R[r * 3 + c];
+            M[r * 4 + 3] = st * signed_expm1f(P[4 + r]);
+        }
+        for (int side = 0; side < 2; ++side) {
+            const int img = side ? ej[e] : ei[e];
+            const float* pred = side ? pred_j : pred_i;
+            const float* wg = side ? w_j : w_i;
+            for (int p = 0; p < A; ++p) {
+                float X[3], cam[3], g[3] = {0, 0, 0}, gm[12] = {0}, l = 0.f;
+                point(img, p, X, cam);
+                residual_accumulate(X, M, pred + ((size_t)e * A + p) * 3, (float)(wg[(size_t)e * A + p] * inv_area), false, l, g, gm);
+                loss += l;
+                for (int k = 0; k < 12; ++k) GM[(size_t)e * 12 + k] += gm[k];
+                for (int r = 0; r < 3; ++r) gx[((size_t)img * A + p) * 3 + r] += g[r];
+            }
+        }
+    }
+    for (int i = 0; i < n_imgs; ++i)
+        for (int p = 0; p < A; ++p) {
+            float X[3], cam[3];
+            point(i, p, X, cam);
+            const float* g = &gx[((size_t)i * A + p) * 3];
+            double gd = 0.0;
+            for (int r = 0; r < 3; ++r) {
+                gd += (double)g[r] * (X[r] - signed_expm1f(im_poses[i * 7 + 4 + r]));
+                for (int c = 0; c < 3; ++c) GI[(size_t)i * 9 + r * 3 + c] += (double)g[r] * cam[c];
+                GT[(size_t)i * 3 + r] += g[r];
+            }
+            g_depth[(size_t)i * A + p] = gd;
+        }
+    std::vector<double> gss(n_edges);
+    double gsum = 0.0;
+    for (int e = 0; e < n_edges; ++e) {
+        const float* P = pw_poses + e * 8;
+        float R[9];
+        quat_to_rotmat(P, R);
+        const float st = expf(P[7]) * nf, adapt[3] = {1.f, 1.f, 1.f};
+        double gP[7], gs;
+        edge_chain(P, R, st, adapt, &GM[(size_t)e * 12], gP, gs);
+        for (int k = 0; k < 7; ++k) g_pw[e * 8 + k] = gP[k];
+        gss[e] = gs * st;
+        gsum += gss[e];
+    }
+    for (int e = 0; e < n_edges; ++e) g_pw[e * 8 + 7] = gss[e] - gsum / n_edges;
+    for (int i = 0; i < n_imgs; ++i) {
+        double gP[7], gf;
+        image_chain(im_poses + i * 7, &Rimg[i * 9], focal_break, &GI[(size_t)i * 9], &GT[(size_t)i * 3], gP, gf);
+        for (int k = 0; k < 7; ++k) g_imp[i * 7 + k] = gP[k];
+        g_foc[i] = gf;
+    }
+    *loss_out = loss;
+    return D3R_OK;
+}

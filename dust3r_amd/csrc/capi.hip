@@ -1,0 +1,55 @@
+// dust3r_amd -- C-ABI wrappers of the building-block kernels (include/dust3r_hip.h).
+#include "../../include/dust3r_hip.h"
+#include "kernels.hpp"
+
+using namespace d3r;
+
+static inline int rc_of(hipError_t e) { return e == hipSuccess ? D3R_OK : 1000 + (int)e; }
+static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
+
+extern "C" int d3r_rope2d(void* tokens, const int64_t* positions, int B, int N, int H, int D, float base, float F0, int dtype, void* stream) {
+    if (!tokens || !positions) return D3R_ERR_INVALID;
+    return rc_of(launch_rope2d(dtype, tokens, positions, B, N, H, D, base, F0, (hipStream_t)stream));
+}
+
+extern "C" int d3r_layernorm(const float* x, const float* gamma, const float* beta, void* out, int rows, int C, float eps, int dtype, void* stream) {
+    if (!x || !gamma || !beta || !out) return D3R_ERR_INVALID;
+    return rc_of(launch_layernorm(dtype, x, gamma, beta, out, rows, C, eps, (hipStream_t)stream));
+}
+
+extern "C" int d3r_linear(const void* act, const void* wgt, const float* bias, void* out, const float* residual, int M, int N, int K, int epilogue,
+                          int dtype, void* stream) {
+    if (!act || !wgt || !out || N % 4 != 0) return D3R_ERR_INVALID;
+    GemmParams p;
+    p.act = act; p.lda = K; p.wgt = wgt; p.bias = bias; p.M = M; p.K = K; p.n_pad = rup(N, 128); p.n_store = N;
+    p.epi = epilogue == 1 ? EPI_F32 : (epilogue == 2 ? EPI_GELU : EPI_T);
+    p.out = out; p.ldo = N; p.res1 = epilogue == 1 ? residual : nullptr; p.ldr = N;
+    return rc_of(launch_gemm(dtype, p, (hipStream_t)stream));
+}
+
+extern "C" int d3r_conv2d_nhwc(const void* in, const void* wgt, const float* bias, void* out, const void* res1, const void* res2, void* out_relu_copy,
+                               int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int pad, int relu, const void* zero_page, int dtype,
+                               void* stream) {
+    if (!in || !wgt || !out || !zero_page || Cout % 4 != 0) return D3R_ERR_INVALID;
+    GemmParams p;
+    p.amode = AMODE_CONV; p.act = in; p.wgt = wgt; p.bias = bias;
+    p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.cstride = Cin; p.ksize = ksize; p.stride = stride; p.pad = pad;
+    p.Hout = (Hin + 2 * pad - ksize) / stride + 1; p.Wout = (Win + 2 * pad - ksize) / stride + 1;
+    p.M = B * p.Hout * p.Wout; p.K = ksize * ksize * Cin; p.n_pad = rup(Cout, 128); p.n_store = Cout; p.zero_page = zero_page;
+    p.epi = EPI_T; p.flags = relu ? GF_RELU : 0; p.out = out; p.ldo = Cout; p.res1 = res1; p.res2 = res2; p.ldr = Cout;
+    p.out2 = out_relu_copy; p.ldo2 = Cout;
+    return rc_of(launch_gemm(dtype, p, (hipStream_t)stream));
+}
+
+extern "C" int d3r_attention(const void* q, const void* k, const void* vt, void* out, int B, int H, int Nq, int Nk, int ldv, float scale, int dtype,
+                             void* stream) {
+    if (!q || !k || !vt || !out) return D3R_ERR_INVALID;
+    AttnParams a;
+    a.q = q; a.k = k; a.vt = vt; a.out = out; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldv = ldv; a.scale = scale;
+    return rc_of(launch_attention(dtype, a, (hipStream_t)stream));
+}
+
+extern "C" int d3r_upsample2x_nhwc(const void* in, void* out, int B, int Hi, int Wi, int C, int Ho, int Wo, int dtype, void* stream) {
+    if (!in || !out) return D3R_ERR_INVALID;
+    return rc_of(launch_upsample2x(dtype, in, out, nullptr, B, Hi, Wi, C, C, Ho, Wo, (hipStream_t)stream));
+}

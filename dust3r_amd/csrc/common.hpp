@@ -1,0 +1,122 @@
+// dust3r_amd -- common device helpers for the gfx950 (MI355X / CDNA4) kernels.
+//
+// Every matrix kernel is written once against `Traits<DT>`; DT selects the MFMA family:
+//   D3R_BF16 / D3R_F16 : v_mfma_f32_{16x16x32,32x32x16}_{bf16,f16}   (2.5 PFLOP/s dense peak)
+//   D3R_F32            : v_mfma_f32_{16x16x4,32x32x2}_f32            (exact f32, 157 TFLOP/s)
+// The f32 instantiation is the "reference-exact" precision mode (the reference runs fp32,
+// dust3r/inference.py:44); it shares tiles, LDS images and epilogues with the 16-bit modes
+// because all of them move operands as 16-byte chunks (8 x 16-bit or 4 x f32) and the MFMA
+// contraction index may be permuted freely as long as both operands use the same map.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define D3R_BF16 0
+#define D3R_F16 1
+#define D3R_F32 2
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define D3R_DEV __device__ __forceinline__
+
+template <int DT> struct Traits;
+
+template <> struct Traits<D3R_BF16> {
+    static constexpr int EB = 2;   // bytes per element
+    static constexpr int CH = 8;   // elements per 16-byte chunk
+    D3R_DEV static void mma16(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+    D3R_DEV static void mma32(f32x16_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+    D3R_DEV static uint32_t pack2(float lo, float hi) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+        v2 t = {(__bf16)lo, (__bf16)hi};
+        return __builtin_bit_cast(uint32_t, t);
+    }
+    D3R_DEV static float unpack_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+    D3R_DEV static float unpack_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+};
+
+template <> struct Traits<D3R_F16> {
+    static constexpr int EB = 2;
+    static constexpr int CH = 8;
+    D3R_DEV static void mma16(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+    }
+    D3R_DEV static void mma32(f32x16_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+    }
+    D3R_DEV static uint32_t pack2(float lo, float hi) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+        v2 t = {(_Float16)lo, (_Float16)hi};
+        return __builtin_bit_cast(uint32_t, t);
+    }
+    D3R_DEV static float unpack_lo(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xFFFFu)); }
+    D3R_DEV static float unpack_hi(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16)); }
+};
+
+template <> struct Traits<D3R_F32> {
+    static constexpr int EB = 4;
+    static constexpr int CH = 4;
+    // one 16-byte chunk = 4 consecutive k; MFMA #j consumes element j of every lane's chunk, so
+    // k-slot (lane>>4) of MFMA j is global k = 4*(lane>>4)+j on BOTH operands (consistent permutation).
+    D3R_DEV static void mma16(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+    }
+    D3R_DEV static void mma32(f32x16_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+    }
+};
+
+// ---- typed 4-element (row-contiguous) loads / stores used by every epilogue -----------------
+template <int DT> D3R_DEV void store4(void* base, size_t elem_off, float a, float b, float c, float d) {
+    if constexpr (DT == D3R_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem_off) = make_float4(a, b, c, d);
+    } else {
+        uint2 v;
+        v.x = Traits<DT>::pack2(a, b);
+        v.y = Traits<DT>::pack2(c, d);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + elem_off) = v;
+    }
+}
+template <int DT> D3R_DEV float4 load4(const void* base, size_t elem_off) {
+    if constexpr (DT == D3R_F32) {
+        return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
+    } else {
+        uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem_off);
+        return make_float4(Traits<DT>::unpack_lo(v.x), Traits<DT>::unpack_hi(v.x), Traits<DT>::unpack_lo(v.y),
+                           Traits<DT>::unpack_hi(v.y));
+    }
+}
+template <int DT> D3R_DEV void store1(void* base, size_t elem_off, float a) {
+    if constexpr (DT == D3R_F32) reinterpret_cast<float*>(base)[elem_off] = a;
+    else reinterpret_cast<uint16_t*>(base)[elem_off] = (uint16_t)(Traits<DT>::pack2(a, 0.f) & 0xFFFFu);
+}
+template <int DT> D3R_DEV float load1(const void* base, size_t elem_off) {
+    if constexpr (DT == D3R_F32) return reinterpret_cast<const float*>(base)[elem_off];
+    else return Traits<DT>::unpack_lo((uint32_t)reinterpret_cast<const uint16_t*>(base)[elem_off]);
+}
+
+D3R_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// XCD-aware bijective block remap (8 XCDs, block b runs on XCD b % 8): gives each XCD a
+// contiguous range of logical tile ids so neighbouring tiles share operand panels in one L2.
+D3R_DEV int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t dt_bytes(int dt) { return dt == D3R_F32 ? 4 : 2; }

@@ -1,0 +1,310 @@
+// dust3r_amd -- bandwidth-bound kernels of the forward path (gfx950): LayerNorm, dtype
+// conversion, patch gather, the standalone 2-D RoPE op, bilinear x2 upsampling and the
+// post-processing epilogues. All of them move 8-16 bytes per lane per access.
+#include "kernels.hpp"
+
+namespace d3r {
+
+// ------------------------------------------------------------------------------ LayerNorm
+// croco blocks use nn.LayerNorm(eps=1e-6) on the fp32 residual stream (oracle/croco_ref/models/
+// croco.py); one wave per row, row kept in registers, two-pass mean / variance like ATen.
+template <int DT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, void* __restrict__ out, int rows,
+                                                        int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
+    const int nch = C >> 2;
+    constexpr int MAXV = 8;  // C <= 2048
+    float4 v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            v[i] = xr[c];
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+            const float4 b = reinterpret_cast<const float4*>(beta)[c];
+            store4<DT>(out, (size_t)row * C + 4 * c, (v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                       (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+        }
+    }
+}
+
+hipError_t launch_layernorm(int dt, const float* x, const float* gamma, const float* beta, void* out, int rows, int C,
+                            float eps, hipStream_t s) {
+    if (C % 4 != 0 || C > 2048 || rows <= 0) return hipErrorInvalidValue;
+    const dim3 grid(cdiv(rows, 4)), block(256);
+    switch (dt) {
+        case D3R_BF16: hipLaunchKernelGGL(layernorm_kernel<D3R_BF16>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
+        case D3R_F16: hipLaunchKernelGGL(layernorm_kernel<D3R_F16>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
+        case D3R_F32: hipLaunchKernelGGL(layernorm_kernel<D3R_F32>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ convert
+template <int DT> __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ x, void* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        store4<DT>(out, 4 * i, v.x, v.y, v.z, v.w);
+    }
+}
+hipError_t launch_convert(int dt, const float* x, void* out, size_t n, hipStream_t s) {
+    if (n % 4 != 0) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    switch (dt) {
+        case D3R_BF16: hipLaunchKernelGGL(convert_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, x, out, n4); break;
+        case D3R_F16: hipLaunchKernelGGL(convert_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, x, out, n4); break;
+        case D3R_F32: hipLaunchKernelGGL(convert_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, x, out, n4); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ patchify
+// PatchEmbedDust3R (dust3r/patch_embed.py:19-29): conv k=s=ps is a GEMM over rows
+// m = (b, ty, tx), k = (c, py, px) -- the order of proj.weight.view(D, -1).
+template <int DT>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, void* __restrict__ out, int B, int H, int W,
+                                                       int ps) {
+    const int tw = W / ps, th = H / ps, q = ps / 4;
+    const size_t total = (size_t)B * 3 * H * (W / 4);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        size_t r = i;
+        const int x4 = (int)(r % (W / 4)); r /= (W / 4);
+        const int y = (int)(r % H); r /= H;
+        const int c = (int)(r % 3);
+        const int b = (int)(r / 3);
+        const float4 v = *reinterpret_cast<const float4*>(img + (((size_t)b * 3 + c) * H + y) * W + 4 * x4);
+        const int ty = y / ps, py = y - ty * ps, tx = x4 / q, px = (x4 - tx * q) * 4;
+        const size_t m = ((size_t)b * th + ty) * tw + tx;
+        store4<DT>(out, m * (size_t)(3 * ps * ps) + (size_t)c * ps * ps + py * ps + px, v.x, v.y, v.z, v.w);
+    }
+}
+hipError_t launch_patchify(int dt, const float* img, void* out, int B, int H, int W, int ps, hipStream_t s) {
+    if (ps % 4 != 0 || H % ps != 0 || W % ps != 0) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * 3 * H * (W / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    switch (dt) {
+        case D3R_BF16: hipLaunchKernelGGL(patchify_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, img, out, B, H, W, ps); break;
+        case D3R_F16: hipLaunchKernelGGL(patchify_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, img, out, B, H, W, ps); break;
+        case D3R_F32: hipLaunchKernelGGL(patchify_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, img, out, B, H, W, ps); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ RoPE
+// Standalone op with the signature of the reference's only native extension, croco's
+// curope `rope_2d(tokens[B,N,H,D], positions[B,N,2] int64, base, F0)` (in place): first D/2
+// dims rotate with y, second with x; inside a half, element i pairs with i + D/4, angle =
+// pos * F0 / base^(i/(D/4)). The engine itself fuses RoPE into the projection epilogue
+// (gemm.hip) from the cos/sin table below; this kernel is the drop-in for the op.
+template <int DT>
+__global__ __launch_bounds__(256) void rope2d_kernel(void* __restrict__ tokens, const int64_t* __restrict__ pos, int BN, int H,
+                                                     int D, float base, float F0) {
+    const int Q = D >> 2;
+    const size_t total = (size_t)BN * H * 2 * Q;  // one thread per (token, head, half, i)
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        size_t r = idx;
+        const int i = (int)(r % Q); r /= Q;
+        const int half = (int)(r & 1); r >>= 1;
+        const int h = (int)(r % H);
+        const size_t bn = r / H;
+        const float inv_freq = F0 / powf(base, (float)i / (float)Q);
+        const float ang = (float)pos[bn * 2 + half] * inv_freq;
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        const size_t e = (bn * H + h) * (size_t)D + half * 2 * Q + i;
+        const float u = load1<DT>(tokens, e), v = load1<DT>(tokens, e + Q);
+        store1<DT>(tokens, e, u * cs - v * sn);
+        store1<DT>(tokens, e + Q, v * cs + u * sn);
+    }
+}
+hipError_t launch_rope2d(int dt, void* tokens, const int64_t* pos, int B, int N, int H, int D, float base, float F0,
+                         hipStream_t s) {
+    if (D % 4 != 0 || B <= 0 || N <= 0 || H <= 0) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * N * H * (D / 2);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    switch (dt) {
+        case D3R_BF16: hipLaunchKernelGGL(rope2d_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, tokens, pos, B * N, H, D, base, F0); break;
+        case D3R_F16: hipLaunchKernelGGL(rope2d_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, tokens, pos, B * N, H, D, base, F0); break;
+        case D3R_F32: hipLaunchKernelGGL(rope2d_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, tokens, pos, B * N, H, D, base, F0); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+__global__ void rope_table_kernel(float* table, int max_pos, float base, float F0) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // (pos, i) with i in [0,16)
+    if (idx >= max_pos * 16) return;
+    const int pos = idx >> 4, i = idx & 15;
+    const float inv_freq = (float)((double)F0 / pow((double)base, (double)i / 16.0));
+    const float ang = (float)pos * inv_freq;  // fp32 product, as the reference's torch fallback forms it
+    table[2 * idx] = (float)cos((double)ang);
+    table[2 * idx + 1] = (float)sin((double)ang);
+}
+hipError_t launch_rope_table(float* table, int max_pos, float base, float F0, hipStream_t s) {
+    hipLaunchKernelGGL(rope_table_kernel, dim3(cdiv(max_pos * 16, 256)), dim3(256), 0, s, table, max_pos, base, F0);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ bilinear x2
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) on NHWC, cropped to (Ho, Wo)
+// (dpt_head.py:57 crops refinenet4's output to layer 3's size). ATen's source-index formula.
+template <int DT>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const void* __restrict__ in, void* __restrict__ out, void* __restrict__ out_relu,
+                                                         int B, int Hi, int Wi, int C, int cstride, int Ho, int Wo) {
+    const int c4n = C >> 2;
+    const size_t total = (size_t)B * Ho * Wo * c4n;
+    const float sh = Hi > 1 ? (float)(Hi - 1) / (float)(2 * Hi - 1) : 0.f;
+    const float sw = Wi > 1 ? (float)(Wi - 1) / (float)(2 * Wi - 1) : 0.f;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        size_t r = idx;
+        const int c4 = (int)(r % c4n); r /= c4n;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float fy = sh * (float)oy, fx = sw * (float)ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const size_t rb = (size_t)b * Hi;
+        const float4 v00 = load4<DT>(in, ((rb + y0) * Wi + x0) * (size_t)cstride + 4 * c4);
+        const float4 v01 = load4<DT>(in, ((rb + y0) * Wi + x1) * (size_t)cstride + 4 * c4);
+        const float4 v10 = load4<DT>(in, ((rb + y1) * Wi + x0) * (size_t)cstride + 4 * c4);
+        const float4 v11 = load4<DT>(in, ((rb + y1) * Wi + x1) * (size_t)cstride + 4 * c4);
+        const float o0 = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+        const float o1 = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+        const float o2 = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+        const float o3 = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+        const size_t oo = (((size_t)b * Ho + oy) * Wo + ox) * (size_t)cstride + 4 * c4;
+        store4<DT>(out, oo, o0, o1, o2, o3);
+        if (out_relu) store4<DT>(out_relu, oo, fmaxf(o0, 0.f), fmaxf(o1, 0.f), fmaxf(o2, 0.f), fmaxf(o3, 0.f));
+    }
+}
+hipError_t launch_upsample2x(int dt, const void* in, void* out, void* out_relu, int B, int Hi, int Wi, int C, int cstride,
+                             int Ho, int Wo, hipStream_t s) {
+    if (C % 4 != 0 || Ho > 2 * Hi || Wo > 2 * Wi) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    switch (dt) {
+        case D3R_BF16: hipLaunchKernelGGL(upsample2x_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo); break;
+        case D3R_F16: hipLaunchKernelGGL(upsample2x_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo); break;
+        case D3R_F32: hipLaunchKernelGGL(upsample2x_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ head epilogues
+// postprocess (dust3r/heads/postprocess.py:10-58) with depth_mode ('exp', -inf, inf) and
+// conf_mode ('exp', 1, inf): pts = xyz / max(|xyz|, 1e-8) * expm1(|xyz|); conf = 1 + exp(x).
+D3R_DEV void postprocess_store(float x, float y, float z, float cl, float* pts, float* conf, size_t pix) {
+    const float d = sqrtf(x * x + y * y + z * z);
+    const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+    pts[3 * pix + 0] = x * sc;
+    pts[3 * pix + 1] = y * sc;
+    pts[3 * pix + 2] = z * sc;
+    conf[pix] = 1.0f + expf(cl);
+}
+
+// DPT head tail: Conv2d(last_dim, 4, 1) on the ReLU'd features + postprocess (dpt_head.py:63,
+// croco dpt_block head[3:5]). 16 lanes per pixel, 8 channels per lane per step.
+template <int DT>
+__global__ __launch_bounds__(256) void head_final_kernel(const void* __restrict__ feat, int C, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ pts, float* __restrict__ conf,
+                                                         size_t npix) {
+    const int sub = threadIdx.x & 15;
+    for (size_t pix = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (size_t)gridDim.x * 16) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int c = sub * 8; c < C; c += 128) {
+            const float4 f0 = load4<DT>(feat, pix * (size_t)C + c), f1 = load4<DT>(feat, pix * (size_t)C + c + 4);
+            const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a0 += fv[e] * w[0 * C + c + e];
+                a1 += fv[e] * w[1 * C + c + e];
+                a2 += fv[e] * w[2 * C + c + e];
+                a3 += fv[e] * w[3 * C + c + e];
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            a0 += __shfl_xor(a0, o);
+            a1 += __shfl_xor(a1, o);
+            a2 += __shfl_xor(a2, o);
+            a3 += __shfl_xor(a3, o);
+        }
+        if (sub == 0) postprocess_store(a0 + bias[0], a1 + bias[1], a2 + bias[2], a3 + bias[3], pts, conf, pix);
+    }
+}
+hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, const float* b, float* pts, float* conf,
+                             size_t npix, hipStream_t s) {
+    if (C % 8 != 0) return hipErrorInvalidValue;
+    const int grid = (int)((npix + 15) / 16 < 65536 ? (npix + 15) / 16 : 65536);
+    switch (dt) {
+        case D3R_BF16: hipLaunchKernelGGL(head_final_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix); break;
+        case D3R_F16: hipLaunchKernelGGL(head_final_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix); break;
+        case D3R_F32: hipLaunchKernelGGL(head_final_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// LinearPts3d tail (dust3r/heads/linear_head.py:36-41): pixel_shuffle(ps) of the token-major
+// projection (channel = c*ps*ps + py*ps + px) followed by postprocess.
+__global__ __launch_bounds__(256) void linear_head_post_kernel(const float* __restrict__ feat, float* __restrict__ pts,
+                                                               float* __restrict__ conf, int B, int th, int tw, int ps) {
+    const int H = th * ps, W = tw * ps, pp = ps * ps;
+    const size_t total = (size_t)B * H * W;
+    for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (size_t)gridDim.x * 256) {
+        size_t r = pix;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        const int ty = y / ps, py = y - ty * ps, tx = x / ps, px = x - tx * ps;
+        const float* f = feat + (((size_t)b * th + ty) * tw + tx) * (size_t)(4 * pp) + py * ps + px;
+        postprocess_store(f[0], f[pp], f[2 * pp], f[3 * pp], pts, conf, pix);
+    }
+}
+hipError_t launch_linear_head_post(const float* feat, float* pts, float* conf, int B, int th, int tw, int ps, hipStream_t s) {
+    const size_t total = (size_t)B * th * tw * ps * ps;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(linear_head_post_kernel, dim3(grid), dim3(256), 0, s, feat, pts, conf, B, th, tw, ps);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s); }
+
+}  // namespace d3r

@@ -1,0 +1,677 @@
+// dust3r_amd -- model engine: weight packing + forward orchestration for
+// AsymmetricCroCo3DStereo.forward (reference dust3r/model.py:199-211).
+//
+// The engine owns its device memory (weights packed once at load time into the layouts the
+// kernels want; one workspace arena grown on demand) and enqueues the whole forward -- ~600
+// kernel launches -- from C++ on the caller's stream, so the Python host makes ONE ctypes call
+// per batch. Data layout in HBM:
+//   residual streams  fp32  [tokens][C]           (LayerNorm, residual adds stay fp32)
+//   GEMM operands     dtype [tokens][C]           (bf16 / f16 / f32 per d3r_model_config.dtype)
+//   q, k              dtype [B][H][N][64]  (RoPE applied), v^T dtype [B][H][64][ldv]
+//   DPT feature maps  dtype NHWC, channel stride padded to the next K-tile multiple
+//   outputs           fp32  pts3d [B][H][W][3], conf [B][H][W]   (the reference's output layout)
+#include <math.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/dust3r_hip.h"
+#include "kernels.hpp"
+
+using namespace d3r;
+
+namespace {
+
+inline int rup(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---- host-side dtype conversion for weight packing ---------------------------------------------------
+inline uint16_t f2bf(float f) {  // round to nearest even
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline uint16_t f2h(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+struct HostPack {  // a [rows][cols] matrix in the engine dtype, zero initialised
+    int dt;
+    size_t rows, cols;
+    std::vector<uint8_t> bytes;
+    HostPack(int dt_, size_t r, size_t c) : dt(dt_), rows(r), cols(c), bytes(r * c * dt_bytes(dt_), 0) {}
+    inline void set(size_t r, size_t c, float v) {
+        const size_t i = r * cols + c;
+        if (dt == D3R_F32) reinterpret_cast<float*>(bytes.data())[i] = v;
+        else reinterpret_cast<uint16_t*>(bytes.data())[i] = dt == D3R_BF16 ? f2bf(v) : f2h(v);
+    }
+};
+
+enum PackKind { PK_VEC, PK_MAT, PK_CONV, PK_CONVT, PK_CONVT_BIAS, PK_IGNORE };
+
+struct Slot {
+    PackKind kind = PK_IGNORE;
+    void* dst = nullptr;      // device destination (matrix in dtype or fp32 vector)
+    int rows = 0, cols = 0;   // expected logical (N, K) / vector length in rows
+    int row_off = 0;          // first destination row (concatenated matrices / biases)
+    int dst_cols = 0;         // destination row length (K, possibly padded)
+    int cin = 0, cin_pad = 0, ksize = 1, cout_pad = 0;
+    bool loaded = false, explicit_loaded = false;
+    std::string mirror;       // dec_blocks.* -> dec_blocks2.* duplication
+};
+
+struct Lin { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, n_pad = 0; };
+struct LNp { float* g = nullptr; float* b = nullptr; };
+struct EncBlk { LNp n1, n2; Lin qkv, proj, fc1, fc2; };
+struct DecBlk { LNp n1, n2, n3, ny; Lin qkv, proj, cq, ckv, cproj, fc1, fc2; };
+struct ConvW { void* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0, cin_pad = 0, k = 1, n_pad = 0, K = 0; };
+struct Refine { ConvW r1c1, r1c2, r2c1, r2c2; Lin outc; };
+struct DptHead {
+    Lin act1x1[4];
+    Lin convt[2];      // ConvTranspose k=4 / k=2 as GEMM; N = k*k*cout_pad
+    int convt_k[2] = {4, 2}, convt_coutp[2] = {0, 0};
+    ConvW act3conv;    // Conv2d(768,768,3,s2,p1)
+    ConvW layer_rn[4];
+    Refine rn[4];      // rn[0] = refinenet1 ... rn[3] = refinenet4
+    ConvW head0, head2;
+    float* head4_w = nullptr; float* head4_b = nullptr;
+    int cstride[4] = {0, 0, 0, 0};  // channel stride of the 4 reassembled maps
+};
+
+}  // namespace
+
+struct d3r_model {
+    d3r_model_config cfg;
+    int dt = 0, ktile = 64;
+    std::unordered_map<std::string, Slot> slots;
+    std::vector<void*> allocs;
+    size_t weight_bytes = 0;
+    Lin patch;
+    std::vector<EncBlk> enc;
+    LNp enc_norm, dec_norm;
+    Lin dec_embed;
+    std::vector<DecBlk> dec[2];
+    DptHead dpt[2];
+    Lin lin_head[2];
+    float* rope_table = nullptr;
+    void* zero_page = nullptr;
+    void* ws = nullptr; size_t ws_bytes = 0;
+    // last forward (debug hook)
+    const void* last_encn = nullptr; size_t last_encn_elems = 0;
+
+    void* dalloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+        (void)hipMemset(p, 0, bytes ? bytes : 16);
+        allocs.push_back(p);
+        weight_bytes += bytes;
+        return p;
+    }
+};
+
+namespace {
+
+// ---- slot registration ---------------------------------------------------------------------------------
+bool reg_vec(d3r_model* m, const std::string& key, float** dst, int n, int n_alloc = 0) {
+    if (!*dst) {
+        *dst = (float*)m->dalloc((size_t)(n_alloc ? n_alloc : n) * sizeof(float));
+        if (!*dst) return false;
+    }
+    Slot s; s.kind = PK_VEC; s.dst = *dst; s.rows = n;
+    m->slots[key] = s;
+    return true;
+}
+bool reg_vec_at(d3r_model* m, const std::string& key, float* base, int off, int n) {
+    Slot s; s.kind = PK_VEC; s.dst = base + off; s.rows = n;
+    m->slots[key] = s;
+    return true;
+}
+bool alloc_lin(d3r_model* m, Lin& L, int N, int K, bool bias = true) {
+    L.N = N; L.K = K; L.n_pad = rup(N, 128);
+    L.w = m->dalloc((size_t)L.n_pad * K * dt_bytes(m->dt));
+    L.b = bias ? (float*)m->dalloc((size_t)L.n_pad * sizeof(float)) : nullptr;
+    return L.w && (!bias || L.b);
+}
+void reg_mat(d3r_model* m, const std::string& key, const Lin& L, int rows, int row_off) {
+    Slot s; s.kind = PK_MAT; s.dst = L.w; s.rows = rows; s.cols = L.K; s.row_off = row_off; s.dst_cols = L.K;
+    m->slots[key] = s;
+}
+bool reg_linear(d3r_model* m, const std::string& prefix, Lin& L, int N, int K) {
+    if (!alloc_lin(m, L, N, K)) return false;
+    reg_mat(m, prefix + ".weight", L, N, 0);
+    reg_vec_at(m, prefix + ".bias", L.b, 0, N);
+    return true;
+}
+bool reg_ln(d3r_model* m, const std::string& prefix, LNp& p, int C) {
+    return reg_vec(m, prefix + ".weight", &p.g, C) && reg_vec(m, prefix + ".bias", &p.b, C);
+}
+bool reg_conv(d3r_model* m, const std::string& prefix, ConvW& c, int Cout, int Cin, int k, bool bias) {
+    c.Cout = Cout; c.Cin = Cin; c.k = k; c.cin_pad = rup(Cin, m->ktile); c.n_pad = rup(Cout, 128); c.K = k * k * c.cin_pad;
+    c.w = m->dalloc((size_t)c.n_pad * c.K * dt_bytes(m->dt));
+    if (!c.w) return false;
+    Slot s; s.kind = PK_CONV; s.dst = c.w; s.rows = Cout; s.cin = Cin; s.cin_pad = c.cin_pad; s.ksize = k; s.dst_cols = c.K;
+    m->slots[prefix + ".weight"] = s;
+    if (bias) {
+        c.b = (float*)m->dalloc((size_t)c.n_pad * sizeof(float));
+        if (!c.b) return false;
+        reg_vec_at(m, prefix + ".bias", c.b, 0, Cout);
+    }
+    return true;
+}
+bool reg_convt(d3r_model* m, const std::string& prefix, Lin& L, int Cin, int Cout, int k, int cin_pad, int cout_pad) {
+    L.N = k * k * cout_pad; L.K = cin_pad; L.n_pad = rup(L.N, 128);
+    L.w = m->dalloc((size_t)L.n_pad * L.K * dt_bytes(m->dt));
+    L.b = (float*)m->dalloc((size_t)L.n_pad * sizeof(float));
+    if (!L.w || !L.b) return false;
+    Slot s; s.kind = PK_CONVT; s.dst = L.w; s.rows = Cin; s.cols = Cout; s.ksize = k; s.cin_pad = cin_pad; s.cout_pad = cout_pad; s.dst_cols = L.K;
+    m->slots[prefix + ".weight"] = s;
+    Slot b; b.kind = PK_CONVT_BIAS; b.dst = L.b; b.rows = Cout; b.ksize = k; b.cout_pad = cout_pad;
+    m->slots[prefix + ".bias"] = b;
+    return true;
+}
+void reg_ignore(d3r_model* m, const std::string& key) { Slot s; s.kind = PK_IGNORE; s.loaded = true; m->slots[key] = s; }
+
+bool build_slots(d3r_model* m) {
+    const d3r_model_config& c = m->cfg;
+    const int Ce = c.enc_embed_dim, Cd = c.dec_embed_dim, ps = c.patch_size;
+    if (!reg_linear(m, "patch_embed.proj", m->patch, Ce, 3 * ps * ps)) return false;
+    reg_ignore(m, "mask_token");
+    m->enc.resize(c.enc_depth);
+    for (int l = 0; l < c.enc_depth; ++l) {
+        const std::string p = "enc_blocks." + std::to_string(l);
+        EncBlk& b = m->enc[l];
+        if (!reg_ln(m, p + ".norm1", b.n1, Ce) || !reg_ln(m, p + ".norm2", b.n2, Ce) || !reg_linear(m, p + ".attn.qkv", b.qkv, 3 * Ce, Ce) ||
+            !reg_linear(m, p + ".attn.proj", b.proj, Ce, Ce) || !reg_linear(m, p + ".mlp.fc1", b.fc1, 4 * Ce, Ce) ||
+            !reg_linear(m, p + ".mlp.fc2", b.fc2, Ce, 4 * Ce))
+            return false;
+    }
+    if (!reg_ln(m, "enc_norm", m->enc_norm, Ce) || !reg_ln(m, "dec_norm", m->dec_norm, Cd) || !reg_linear(m, "decoder_embed", m->dec_embed, Cd, Ce))
+        return false;
+    for (int side = 0; side < 2; ++side) {
+        m->dec[side].resize(c.dec_depth);
+        for (int l = 0; l < c.dec_depth; ++l) {
+            const std::string p = std::string(side ? "dec_blocks2." : "dec_blocks.") + std::to_string(l);
+            DecBlk& b = m->dec[side][l];
+            if (!reg_ln(m, p + ".norm1", b.n1, Cd) || !reg_ln(m, p + ".norm2", b.n2, Cd) || !reg_ln(m, p + ".norm3", b.n3, Cd) ||
+                !reg_ln(m, p + ".norm_y", b.ny, Cd) || !reg_linear(m, p + ".attn.qkv", b.qkv, 3 * Cd, Cd) ||
+                !reg_linear(m, p + ".attn.proj", b.proj, Cd, Cd) || !reg_linear(m, p + ".cross_attn.projq", b.cq, Cd, Cd) ||
+                !reg_linear(m, p + ".cross_attn.proj", b.cproj, Cd, Cd) || !reg_linear(m, p + ".mlp.fc1", b.fc1, 4 * Cd, Cd) ||
+                !reg_linear(m, p + ".mlp.fc2", b.fc2, Cd, 4 * Cd))
+                return false;
+            // projk and projv share their input: packed as one (2 Cd, Cd) matrix
+            if (!alloc_lin(m, b.ckv, 2 * Cd, Cd)) return false;
+            reg_mat(m, p + ".cross_attn.projk.weight", b.ckv, Cd, 0);
+            reg_mat(m, p + ".cross_attn.projv.weight", b.ckv, Cd, Cd);
+            reg_vec_at(m, p + ".cross_attn.projk.bias", b.ckv.b, 0, Cd);
+            reg_vec_at(m, p + ".cross_attn.projv.bias", b.ckv.b, Cd, Cd);
+        }
+    }
+    // dec_blocks.* duplicates into dec_blocks2.* until an explicit dec_blocks2 key arrives (model.py:91-98)
+    {
+        std::vector<std::string> keys;
+        for (auto& kv : m->slots)
+            if (kv.first.rfind("dec_blocks.", 0) == 0) keys.push_back(kv.first);
+        for (auto& k : keys) m->slots[k].mirror = "dec_blocks2." + k.substr(strlen("dec_blocks."));
+    }
+    for (int hd = 0; hd < 2; ++hd) {
+        const std::string hp = "downstream_head" + std::to_string(hd + 1);
+        if (c.head_type == 0) {
+            if (!reg_linear(m, hp + ".proj", m->lin_head[hd], 4 * ps * ps, Cd)) return false;
+            continue;
+        }
+        DptHead& D = m->dpt[hd];
+        const std::string dp = hp + ".dpt";
+        const int ld[4] = {96, 192, 384, 768};
+        const int din[4] = {Ce, Cd, Cd, Cd};
+        for (int i = 0; i < 4; ++i) {
+            D.cstride[i] = rup(ld[i], m->ktile);
+            if (!alloc_lin(m, D.act1x1[i], ld[i], din[i])) return false;
+            reg_mat(m, dp + ".act_postprocess." + std::to_string(i) + ".0.weight", D.act1x1[i], ld[i], 0);
+            reg_vec_at(m, dp + ".act_postprocess." + std::to_string(i) + ".0.bias", D.act1x1[i].b, 0, ld[i]);
+        }
+        D.convt_coutp[0] = D.cstride[0]; D.convt_coutp[1] = D.cstride[1];
+        if (!reg_convt(m, dp + ".act_postprocess.0.1", D.convt[0], ld[0], ld[0], 4, D.cstride[0], D.cstride[0])) return false;
+        if (!reg_convt(m, dp + ".act_postprocess.1.1", D.convt[1], ld[1], ld[1], 2, D.cstride[1], D.cstride[1])) return false;
+        if (!reg_conv(m, dp + ".act_postprocess.3.1", D.act3conv, ld[3], ld[3], 3, true)) return false;
+        for (int i = 0; i < 4; ++i) {
+            if (!reg_conv(m, dp + ".scratch.layer_rn." + std::to_string(i), D.layer_rn[i], 256, ld[i], 3, false)) return false;
+            reg_ignore(m, dp + ".scratch.layer" + std::to_string(i + 1) + "_rn.weight");  // alias of layer_rn.i
+            const std::string rp = dp + ".scratch.refinenet" + std::to_string(i + 1);
+            Refine& R = D.rn[i];
+            if (!reg_conv(m, rp + ".resConfUnit1.conv1", R.r1c1, 256, 256, 3, true) || !reg_conv(m, rp + ".resConfUnit1.conv2", R.r1c2, 256, 256, 3, true) ||
+                !reg_conv(m, rp + ".resConfUnit2.conv1", R.r2c1, 256, 256, 3, true) || !reg_conv(m, rp + ".resConfUnit2.conv2", R.r2c2, 256, 256, 3, true))
+                return false;
+            if (!alloc_lin(m, R.outc, 256, 256)) return false;
+            reg_mat(m, rp + ".out_conv.weight", R.outc, 256, 0);
+            reg_vec_at(m, rp + ".out_conv.bias", R.outc.b, 0, 256);
+        }
+        // refinenet4.resConfUnit1 exists in the checkpoint but is never evaluated (single input): still required keys
+        if (!reg_conv(m, dp + ".head.0", D.head0, 128, 256, 3, true) || !reg_conv(m, dp + ".head.2", D.head2, 128, 128, 3, true)) return false;
+        if (!reg_vec(m, dp + ".head.4.weight", &D.head4_w, 4 * 128) || !reg_vec(m, dp + ".head.4.bias", &D.head4_b, 4)) return false;
+    }
+    return true;
+}
+
+int pack_slot(d3r_model* m, Slot& s, const float* data, int ndim, const int64_t* shape) {
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    const size_t eb = dt_bytes(m->dt);
+    switch (s.kind) {
+        case PK_IGNORE: return D3R_OK;
+        case PK_VEC:
+            if (numel != (size_t)s.rows) return D3R_ERR_SHAPE;
+            return hipMemcpy(s.dst, data, numel * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
+        case PK_MAT: {
+            if (ndim < 2 || shape[0] != s.rows || numel != (size_t)s.rows * s.cols) return D3R_ERR_SHAPE;
+            HostPack hp(m->dt, s.rows, s.dst_cols);
+            for (int r = 0; r < s.rows; ++r)
+                for (int c = 0; c < s.cols; ++c) hp.set(r, c, data[(size_t)r * s.cols + c]);
+            char* d = (char*)s.dst + (size_t)s.row_off * s.dst_cols * eb;
+            return hipMemcpy(d, hp.bytes.data(), hp.bytes.size(), hipMemcpyHostToDevice) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
+        }
+        case PK_CONV: {
+            const int k = s.ksize;
+            if (ndim != 4 || shape[0] != s.rows || shape[1] != s.cin || shape[2] != k || shape[3] != k) return D3R_ERR_SHAPE;
+            HostPack hp(m->dt, s.rows, s.dst_cols);
+            for (int co = 0; co < s.rows; ++co)
+                for (int ci = 0; ci < s.cin; ++ci)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx)
+                            hp.set(co, (size_t)(ky * k + kx) * s.cin_pad + ci, data[(((size_t)co * s.cin + ci) * k + ky) * k + kx]);
+            return hipMemcpy(s.dst, hp.bytes.data(), hp.bytes.size(), hipMemcpyHostToDevice) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
+        }
+        case PK_CONVT: {
+            const int k = s.ksize, Cin = s.rows, Cout = s.cols;
+            if (ndim != 4 || shape[0] != Cin || shape[1] != Cout || shape[2] != k || shape[3] != k) return D3R_ERR_SHAPE;
+            HostPack hp(m->dt, (size_t)k * k * s.cout_pad, s.dst_cols);
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int co = 0; co < Cout; ++co)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx)
+                            hp.set((size_t)(ky * k + kx) * s.cout_pad + co, ci, data[(((size_t)ci * Cout + co) * k + ky) * k + kx]);
+            return hipMemcpy(s.dst, hp.bytes.data(), hp.bytes.size(), hipMemcpyHostToDevice) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
+        }
+        case PK_CONVT_BIAS: {
+            if (numel != (size_t)s.rows) return D3R_ERR_SHAPE;
+            std::vector<float> b((size_t)s.ksize * s.ksize * s.cout_pad, 0.f);
+            for (int t = 0; t < s.ksize * s.ksize; ++t)
+                for (int co = 0; co < s.rows; ++co) b[(size_t)t * s.cout_pad + co] = data[co];
+            return hipMemcpy(s.dst, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
+        }
+    }
+    return D3R_ERR_INVALID;
+}
+
+// ---- launch helpers ------------------------------------------------------------------------------------------
+struct Ctx {
+    d3r_model* m;
+    hipStream_t st;
+    int rc = D3R_OK;
+    void chk(hipError_t e) { if (e != hipSuccess && rc == D3R_OK) rc = 1000 + (int)e; }
+};
+
+void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi, void* out, int ldo, const void* res1 = nullptr,
+                 void* out2 = nullptr, int ldo2 = 0, int n_store = -1, int flags = 0) {
+    GemmParams p;
+    p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad;
+    p.n_store = n_store >= 0 ? n_store : L.N;
+    p.epi = epi; p.out = out; p.ldo = ldo; p.res1 = res1; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo2; p.flags = flags;
+    c.chk(launch_gemm(c.m->dt, p, c.st));
+}
+
+void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_c, int nreg, const int* kinds, void* const* dsts, int heads,
+                int ntok, int tok_w, int ldv) {
+    GemmParams p;
+    p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_store = L.N;
+    p.epi = EPI_HEADS; p.head_c = head_c;
+    for (int i = 0; i < nreg; ++i) { p.head_kind[i] = kinds[i]; p.head_dst[i] = dsts[i]; }
+    p.heads = heads; p.ntok = ntok; p.tok_w = tok_w; p.ldv = ldv; p.rope_table = c.m->rope_table;
+    c.chk(launch_gemm(c.m->dt, p, c.st));
+}
+
+void conv(Ctx& c, const void* in, int B, int Hin, int Win, int cstride, const ConvW& w, int stride, int pad, void* out, int ldo,
+          int flags, const void* res1 = nullptr, const void* res2 = nullptr, void* out2 = nullptr, int n_store = -1) {
+    GemmParams p;
+    p.amode = AMODE_CONV; p.act = in; p.wgt = w.w; p.bias = w.b;
+    p.Hin = Hin; p.Win = Win; p.Cin = w.cin_pad; p.cstride = cstride; p.ksize = w.k; p.stride = stride; p.pad = pad;
+    p.Hout = (Hin + 2 * pad - w.k) / stride + 1; p.Wout = (Win + 2 * pad - w.k) / stride + 1;
+    p.M = B * p.Hout * p.Wout; p.K = w.K; p.n_pad = w.n_pad; p.n_store = n_store >= 0 ? n_store : w.Cout;
+    p.zero_page = c.m->zero_page;
+    p.epi = EPI_T; p.flags = flags; p.out = out; p.ldo = ldo; p.res1 = res1; p.res2 = res2; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo;
+    c.chk(launch_gemm(c.m->dt, p, c.st));
+}
+
+struct Arena {
+    char* base; size_t off = 0, cap;
+    Arena(void* b, size_t c) : base((char*)b), cap(c) {}
+    void* take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+}  // namespace
+
+// =========================================================================================================
+extern "C" const char* d3r_version(void) { return "dust3r_amd 0.1 (gfx950)"; }
+
+extern "C" int d3r_device_check(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return D3R_ERR_STATE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return D3R_ERR_STATE;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? D3R_OK : D3R_ERR_STATE;
+}
+
+extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
+    if (!out || !cfg) return D3R_ERR_INVALID;
+    if (cfg->dtype < 0 || cfg->dtype > 2 || cfg->patch_size % 4 != 0) return D3R_ERR_INVALID;
+    if (cfg->enc_embed_dim != cfg->enc_num_heads * 64 || cfg->dec_embed_dim != cfg->dec_num_heads * 64) return D3R_ERR_INVALID;  // head dim 64
+    d3r_model* m = new (std::nothrow) d3r_model();
+    if (!m) return D3R_ERR_ALLOC;
+    m->cfg = *cfg; m->dt = cfg->dtype; m->ktile = 128 / (int)dt_bytes(cfg->dtype);
+    if (cfg->enc_embed_dim % m->ktile || cfg->dec_embed_dim % m->ktile || (3 * cfg->patch_size * cfg->patch_size) % m->ktile ||
+        (cfg->head_type == 1 && cfg->dec_depth <= 9)) { delete m; return D3R_ERR_INVALID; }
+    if (!build_slots(m)) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
+    m->rope_table = (float*)m->dalloc(512 * 16 * 2 * sizeof(float));
+    m->zero_page = m->dalloc(4096);
+    if (!m->rope_table || !m->zero_page) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
+    if (launch_rope_table(m->rope_table, 512, cfg->rope_freq, 1.0f, nullptr) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_LAUNCH; }
+    (void)hipDeviceSynchronize();
+    *out = m;
+    return D3R_OK;
+}
+
+extern "C" int d3r_model_destroy(d3r_model* m) {
+    if (!m) return D3R_OK;
+    for (void* p : m->allocs) (void)hipFree(p);
+    if (m->ws) (void)hipFree(m->ws);
+    delete m;
+    return D3R_OK;
+}
+
+extern "C" int d3r_model_load_tensor(d3r_model* m, const char* key, const float* data, int ndim, const int64_t* shape) {
+    if (!m || !key || !data) return D3R_ERR_INVALID;
+    auto it = m->slots.find(key);
+    if (it == m->slots.end()) {
+        const std::string k(key);
+        if (k.find("pos_embed") != std::string::npos || k.rfind("prediction_head", 0) == 0) return D3R_OK;
+        return D3R_ERR_UNKNOWN_KEY;
+    }
+    Slot& s = it->second;
+    int rc = pack_slot(m, s, data, ndim, shape);
+    if (rc != D3R_OK) return rc;
+    s.loaded = true;
+    if (std::string(key).rfind("dec_blocks2.", 0) == 0) s.explicit_loaded = true;
+    if (!s.mirror.empty()) {
+        Slot& t = m->slots[s.mirror];
+        if (!t.explicit_loaded) {
+            rc = pack_slot(m, t, data, ndim, shape);
+            if (rc != D3R_OK) return rc;
+            t.loaded = true;
+        }
+    }
+    return D3R_OK;
+}
+
+extern "C" int d3r_model_missing(const d3r_model* m) {
+    if (!m) return -1;
+    int n = 0;
+    for (auto& kv : m->slots)
+        if (!kv.second.loaded) ++n;
+    return n;
+}
+
+extern "C" size_t d3r_model_device_bytes(const d3r_model* m) { return m ? m->weight_bytes + m->ws_bytes : 0; }
+
+extern "C" int d3r_model_debug_read(d3r_model* m, int what, float* out, size_t max_elems, void* stream) {
+    if (!m || what != 0 || !m->last_encn) return D3R_ERR_INVALID;
+    const size_t n = m->last_encn_elems < max_elems ? m->last_encn_elems : max_elems;
+    if (m->dt == D3R_F32) return hipMemcpyAsync(out, m->last_encn, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
+    return D3R_ERR_INVALID;  // 16-bit modes: read through the Python side (torch view of the raw buffer is not exposed)
+}
+
+// ---- the forward ---------------------------------------------------------------------------------------------
+namespace {
+
+void self_attention(Ctx& c, const void* xn, const Lin& qkv, int M, int C, int heads, int nimg, int ntok, int tok_w, int ldv, void* q, void* k,
+                    void* vt, void* ao) {
+    const int kinds[3] = {HEAD_ROPE, HEAD_ROPE, HEAD_VT};
+    void* dsts[3] = {q, k, vt};
+    gemm_heads(c, xn, C, qkv, M, C, 3, kinds, dsts, heads, ntok, tok_w, ldv);
+    AttnParams a;
+    a.q = q; a.k = k; a.vt = vt; a.out = ao; a.B = nimg; a.H = heads; a.Nq = ntok; a.Nk = ntok; a.ldv = ldv; a.scale = 0.125f;
+    c.chk(launch_attention(c.m->dt, a, c.st));
+}
+
+void run_dpt(Ctx& c, const DptHead& D, Arena ar, const void* const hooks[4], const int hook_c[4], int B, int th, int tw, float* pts, float* conf) {
+    d3r_model* m = c.m;
+    const size_t eb = dt_bytes(m->dt);
+    const int N = th * tw;
+    const int th2 = (th - 1) / 2 + 1, tw2 = (tw - 1) / 2 + 1;
+    const int Hl[4] = {4 * th, 2 * th, th, th2}, Wl[4] = {4 * tw, 2 * tw, tw, tw2};
+    // reassemble: 1x1 conv (+ ConvTranspose / strided conv)
+    void* cmap[4];
+    for (int i = 0; i < 4; ++i) cmap[i] = ar.take((size_t)B * Hl[i] * Wl[i] * D.cstride[i] * eb);
+    void* t1 = ar.take((size_t)B * N * 768 * eb);
+    for (int i = 0; i < 4; ++i) {
+        const Lin& L = D.act1x1[i];
+        const bool direct = (i == 2);
+        gemm_linear(c, hooks[i], hook_c[i], L, B * N, EPI_T, direct ? cmap[2] : t1, D.cstride[i], nullptr, nullptr, 0, D.cstride[i]);
+        if (i < 2) {
+            GemmParams p;
+            p.act = t1; p.lda = D.cstride[i]; p.wgt = D.convt[i].w; p.bias = D.convt[i].b; p.M = B * N; p.K = D.convt[i].K;
+            p.n_pad = D.convt[i].n_pad; p.n_store = D.convt[i].N; p.epi = EPI_CONVT; p.ksize = D.convt_k[i]; p.ct_cout = D.convt_coutp[i];
+            p.Hin = th; p.Win = tw; p.out = cmap[i]; p.ldo = D.cstride[i];
+            c.chk(launch_gemm(m->dt, p, c.st));
+        } else if (i == 3) {
+            conv(c, t1, B, th, tw, D.cstride[3], D.act3conv, 2, 1, cmap[3], D.cstride[3], 0);
+        }
+    }
+    // layer_rn: 3x3 -> 256 (no bias), plus ReLU copy for the residual units' pre-activation
+    void *r[4], *rr[4];
+    for (int i = 0; i < 4; ++i) {
+        const size_t bytes = (size_t)B * Hl[i] * Wl[i] * 256 * eb;
+        r[i] = ar.take(bytes); rr[i] = ar.take(bytes);
+        conv(c, cmap[i], B, Hl[i], Wl[i], D.cstride[i], D.layer_rn[i], 1, 1, r[i], 256, 0, nullptr, nullptr, rr[i]);
+    }
+    const size_t big = (size_t)B * Hl[0] * Wl[0] * 256 * eb;
+    void *tA = ar.take(big), *tB = ar.take(big), *tC = ar.take(big);
+    void* path = nullptr;  // output of the previous refinenet (already upsampled)
+    for (int lvl = 3; lvl >= 0; --lvl) {
+        const Refine& R = D.rn[lvl];
+        const int H = Hl[lvl], W = Wl[lvl];
+        const void* skip;      // input of resConfUnit2 (un-activated) ...
+        const void* skip_relu; // ... and its ReLU
+        if (lvl == 3) {
+            skip = r[3]; skip_relu = rr[3];
+        } else {
+            conv(c, rr[lvl], B, H, W, 256, R.r1c1, 1, 1, tA, 256, GF_RELU);
+            conv(c, tA, B, H, W, 256, R.r1c2, 1, 1, tB, 256, 0, m->cfg.dpt_skip_relu_inplace ? rr[lvl] : r[lvl], path, tC);
+            skip = tB; skip_relu = tC;
+        }
+        conv(c, skip_relu, B, H, W, 256, R.r2c1, 1, 1, tA, 256, GF_RELU);
+        void* o = (lvl == 3) ? tB : tC;
+        conv(c, tA, B, H, W, 256, R.r2c2, 1, 1, o, 256, 0, m->cfg.dpt_skip_relu_inplace ? skip_relu : skip);
+        // out_conv (1x1) commutes with the bilinear upsampling (both linear, weights sum to 1): run it at low resolution
+        gemm_linear(c, o, 256, R.outc, B * H * W, EPI_T, tA, 256);
+        const int Ho = lvl == 3 ? Hl[2] : 2 * H, Wo = lvl == 3 ? Wl[2] : 2 * W;  // dpt_head.py:57 crops refinenet4 to layer 3's size
+        void* np = ar.take((size_t)B * Ho * Wo * 256 * eb);
+        c.chk(launch_upsample2x(m->dt, tA, np, nullptr, B, H, W, 256, 256, Ho, Wo, c.st));
+        path = np;
+    }
+    // head: 3x3 256->128, x2, 3x3 128->128 + ReLU, 1x1 128->4 + postprocess
+    const int H8 = 8 * th, W8 = 8 * tw;
+    void* h0 = ar.take((size_t)B * H8 * W8 * 128 * eb);
+    conv(c, path, B, H8, W8, 256, D.head0, 1, 1, h0, 128, 0);
+    void* h1 = ar.take((size_t)B * 4 * H8 * W8 * 128 * eb);
+    c.chk(launch_upsample2x(m->dt, h0, h1, nullptr, B, H8, W8, 128, 128, 2 * H8, 2 * W8, c.st));
+    void* h2 = ar.take((size_t)B * 4 * H8 * W8 * 128 * eb);
+    conv(c, h1, B, 2 * H8, 2 * W8, 128, D.head2, 1, 1, h2, 128, GF_RELU);
+    c.chk(launch_head_final(m->dt, h2, 128, D.head4_w, D.head4_b, pts, conf, (size_t)B * 4 * H8 * W8, c.st));
+    if (ar.base && ar.off > ar.cap) c.rc = D3R_ERR_ALLOC;
+}
+
+// returns bytes needed when ws == nullptr (dry run), else runs
+size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1,
+                    float* pts2, float* conf2, hipStream_t st, int* rc_out) {
+    const d3r_model_config& cf = m->cfg;
+    const int ps = cf.patch_size, th = H / ps, tw = W / ps, N = th * tw;
+    const int Ce = cf.enc_embed_dim, Cd = cf.dec_embed_dim, He = cf.enc_num_heads, Hd = cf.dec_num_heads;
+    const int M2 = 2 * B * N, M1 = B * N, ldv = rup(N, 64);
+    const size_t eb = dt_bytes(m->dt);
+    const bool dry = ws == nullptr;
+    Arena ar(ws, ws_cap);
+    Ctx c{m, st};
+
+    float* x = (float*)ar.take((size_t)M2 * Ce * 4);
+    void* xn = ar.take((size_t)M2 * Ce * eb);
+    void* q = ar.take((size_t)M2 * Ce * eb);
+    void* k = ar.take((size_t)M2 * Ce * eb);
+    void* vt = ar.take((size_t)2 * B * He * 64 * ldv * eb);
+    void* ao = ar.take((size_t)M2 * Ce * eb);
+    void* hb = ar.take((size_t)M2 * 4 * Ce * eb);   // MLP hidden; also holds the gathered patches
+    void* encn = ar.take((size_t)M2 * Ce * eb);
+    float* f[2] = {(float*)ar.take((size_t)M2 * Cd * 4), (float*)ar.take((size_t)M2 * Cd * 4)};
+    void* yn = ar.take((size_t)M1 * Cd * eb);
+    void* hook[2][3];
+    for (int s = 0; s < 2; ++s)
+        for (int j = 0; j < 3; ++j) hook[s][j] = ar.take((size_t)M1 * Cd * eb);
+    float* lin_out = cf.head_type == 0 ? (float*)ar.take((size_t)M1 * 4 * ps * ps * 4) : nullptr;
+    const size_t common_end = ar.off;
+
+    if (!dry) {
+        if (ldv != N) c.chk(hipMemsetAsync(vt, 0, (size_t)2 * B * He * 64 * ldv * eb, st));
+        // ---- encoder: both image batches in one pass (model.py:142-151) ----------------------------------
+        const size_t pk = 3 * (size_t)ps * ps;
+        c.chk(launch_patchify(m->dt, img1, hb, B, H, W, ps, st));
+        c.chk(launch_patchify(m->dt, img2, (char*)hb + (size_t)M1 * pk * eb, B, H, W, ps, st));
+        gemm_linear(c, hb, (int)pk, m->patch, M2, EPI_F32, x, Ce);
+        for (int l = 0; l < cf.enc_depth; ++l) {
+            const EncBlk& b = m->enc[l];
+            c.chk(launch_layernorm(m->dt, x, b.n1.g, b.n1.b, xn, M2, Ce, 1e-6f, st));
+            self_attention(c, xn, b.qkv, M2, Ce, He, 2 * B, N, tw, ldv, q, k, vt, ao);
+            gemm_linear(c, ao, Ce, b.proj, M2, EPI_F32, x, Ce, x);
+            c.chk(launch_layernorm(m->dt, x, b.n2.g, b.n2.b, xn, M2, Ce, 1e-6f, st));
+            gemm_linear(c, xn, Ce, b.fc1, M2, EPI_GELU, hb, 4 * Ce);
+            gemm_linear(c, hb, 4 * Ce, b.fc2, M2, EPI_F32, x, Ce, x);
+        }
+        c.chk(launch_layernorm(m->dt, x, m->enc_norm.g, m->enc_norm.b, encn, M2, Ce, 1e-6f, st));
+        m->last_encn = encn; m->last_encn_elems = (size_t)M2 * Ce;
+        // ---- decoder (model.py:172-191): side s reads the PREVIOUS layer's (f_s, f_other) ---------------------
+        gemm_linear(c, encn, Ce, m->dec_embed, M2, EPI_F32, f[0], Cd);
+        int cur = 0;
+        const int hk6 = cf.dec_depth * 2 / 4, hk9 = cf.dec_depth * 3 / 4;
+        for (int l = 0; l < cf.dec_depth; ++l) {
+            for (int s = 0; s < 2; ++s) {
+                const DecBlk& b = m->dec[s][l];
+                const float* xo = f[cur] + (size_t)s * M1 * Cd;         // own stream (old)
+                const float* yo = f[cur] + (size_t)(1 - s) * M1 * Cd;   // other view (old)
+                float* xw = f[cur ^ 1] + (size_t)s * M1 * Cd;           // own stream (new)
+                c.chk(launch_layernorm(m->dt, xo, b.n1.g, b.n1.b, xn, M1, Cd, 1e-6f, st));
+                self_attention(c, xn, b.qkv, M1, Cd, Hd, B, N, tw, ldv, q, k, vt, ao);
+                gemm_linear(c, ao, Cd, b.proj, M1, EPI_F32, xw, Cd, xo);
+                // cross attention: q from norm2(x), k/v from norm_y(y)
+                c.chk(launch_layernorm(m->dt, yo, b.ny.g, b.ny.b, yn, M1, Cd, 1e-6f, st));
+                c.chk(launch_layernorm(m->dt, xw, b.n2.g, b.n2.b, xn, M1, Cd, 1e-6f, st));
+                {
+                    const int kq[1] = {HEAD_ROPE};
+                    void* dq[1] = {q};
+                    gemm_heads(c, xn, Cd, b.cq, M1, Cd, 1, kq, dq, Hd, N, tw, ldv);
+                    const int kkv[2] = {HEAD_ROPE, HEAD_VT};
+                    void* dkv[2] = {k, vt};
+                    gemm_heads(c, yn, Cd, b.ckv, M1, Cd, 2, kkv, dkv, Hd, N, tw, ldv);
+                    AttnParams a;
+                    a.q = q; a.k = k; a.vt = vt; a.out = ao; a.B = B; a.H = Hd; a.Nq = N; a.Nk = N; a.ldv = ldv; a.scale = 0.125f;
+                    c.chk(launch_attention(m->dt, a, st));
+                }
+                gemm_linear(c, ao, Cd, b.cproj, M1, EPI_F32, xw, Cd, xw);
+                c.chk(launch_layernorm(m->dt, xw, b.n3.g, b.n3.b, xn, M1, Cd, 1e-6f, st));
+                gemm_linear(c, xn, Cd, b.fc1, M1, EPI_GELU, hb, 4 * Cd);
+                const int layer_no = l + 1;
+                void* hcopy = (cf.head_type == 1 && (layer_no == hk6 || layer_no == hk9)) ? hook[s][layer_no == hk6 ? 0 : 1] : nullptr;
+                gemm_linear(c, hb, 4 * Cd, b.fc2, M1, EPI_F32, xw, Cd, xw, hcopy, Cd);
+            }
+            cur ^= 1;
+        }
+        for (int s = 0; s < 2; ++s)
+            c.chk(launch_layernorm(m->dt, f[cur] + (size_t)s * M1 * Cd, m->dec_norm.g, m->dec_norm.b, hook[s][2], M1, Cd, 1e-6f, st));
+    }
+    // ---- heads -----------------------------------------------------------------------------------------------
+    size_t peak = common_end;
+    float* pts[2] = {pts1, pts2};
+    float* cnf[2] = {conf1, conf2};
+    if (cf.head_type == 0) {
+        if (!dry)
+            for (int s = 0; s < 2; ++s) {
+                gemm_linear(c, hook[s][2], Cd, m->lin_head[s], M1, EPI_F32, lin_out, 4 * ps * ps);
+                c.chk(launch_linear_head_post(lin_out, pts[s], cnf[s], B, th, tw, ps, st));
+            }
+    } else {
+        const int chunk = B < 4 ? B : 4;
+        for (int s = 0; s < 2; ++s)
+            for (int b0 = 0; b0 < B; b0 += chunk) {
+                const int bc = (B - b0) < chunk ? (B - b0) : chunk;
+                Arena sub(dry ? nullptr : (char*)ws + common_end, ws_cap > common_end ? ws_cap - common_end : 0);
+                const void* hooks[4] = {(const char*)encn + ((size_t)s * M1 + (size_t)b0 * N) * Ce * eb, (const char*)hook[s][0] + (size_t)b0 * N * Cd * eb,
+                                        (const char*)hook[s][1] + (size_t)b0 * N * Cd * eb, (const char*)hook[s][2] + (size_t)b0 * N * Cd * eb};
+                const int hc[4] = {Ce, Cd, Cd, Cd};
+                if (dry) {
+                    // size only: replay the allocation pattern
+                    Ctx dc{m, st};
+                    struct Probe { };
+                    (void)dc;
+                    const size_t ebb = eb;
+                    const int th2 = (th - 1) / 2 + 1, tw2 = (tw - 1) / 2 + 1;
+                    const int Hl[4] = {4 * th, 2 * th, th, th2}, Wl[4] = {4 * tw, 2 * tw, tw, tw2};
+                    const DptHead& D = m->dpt[s];
+                    for (int i = 0; i < 4; ++i) sub.take((size_t)bc * Hl[i] * Wl[i] * D.cstride[i] * ebb);
+                    sub.take((size_t)bc * N * 768 * ebb);
+                    for (int i = 0; i < 4; ++i) { sub.take((size_t)bc * Hl[i] * Wl[i] * 256 * ebb); sub.take((size_t)bc * Hl[i] * Wl[i] * 256 * ebb); }
+                    for (int i = 0; i < 3; ++i) sub.take((size_t)bc * Hl[0] * Wl[0] * 256 * ebb);
+                    for (int lvl = 3; lvl >= 0; --lvl) {
+                        const int Ho = lvl == 3 ? Hl[2] : 2 * Hl[lvl], Wo = lvl == 3 ? Wl[2] : 2 * Wl[lvl];
+                        sub.take((size_t)bc * Ho * Wo * 256 * ebb);
+                    }
+                    sub.take((size_t)bc * 64 * N * 128 * ebb);
+                    sub.take((size_t)bc * 256 * N * 128 * ebb);
+                    sub.take((size_t)bc * 256 * N * 128 * ebb);
+                    if (common_end + sub.off > peak) peak = common_end + sub.off;
+                } else {
+                    run_dpt(c, m->dpt[s], sub, hooks, hc, bc, th, tw, pts[s] + (size_t)b0 * H * W * 3, cnf[s] + (size_t)b0 * H * W);
+                }
+            }
+    }
+    if (rc_out) *rc_out = c.rc;
+    return peak + 256;
+}
+
+}  // namespace
+
+extern "C" int d3r_model_forward(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1,
+                                 float* pts2, float* conf2, void* stream) {
+    if (!m || !img1 || !img2 || B <= 0 || !pts1 || !conf1 || !pts2 || !conf2) return D3R_ERR_INVALID;
+    const int ps = m->cfg.patch_size;
+    if (H % ps || W % ps || H <= 0 || W <= 0 || H / ps > 511 || W / ps > 511) return D3R_ERR_SHAPE;
+    if (d3r_model_missing(m) != 0) return D3R_ERR_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = forward_impl(m, nullptr, 0, img1, img2, B, H, W, pts1, conf1, pts2, conf2, st, nullptr);
+    if (need > m->ws_bytes) {
+        (void)hipStreamSynchronize(st);
+        if (m->ws) (void)hipFree(m->ws);
+        m->ws = nullptr; m->ws_bytes = 0;
+        if (hipMalloc(&m->ws, need) != hipSuccess) return D3R_ERR_ALLOC;
+        m->ws_bytes = need;
+    }
+    int rc = D3R_OK;
+    forward_impl(m, m->ws, m->ws_bytes, img1, img2, B, H, W, pts1, conf1, pts2, conf2, st, &rc);
+    return rc;
+}

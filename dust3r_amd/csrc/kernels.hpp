@@ -1,0 +1,77 @@
+// dust3r_amd -- internal kernel launch interface (C++ side, below the C-ABI of include/dust3r_hip.h).
+#pragma once
+#include "common.hpp"
+
+namespace d3r {
+
+// ------------------------------------------------------------------------------ GEMM / conv
+enum { AMODE_LINEAR = 0, AMODE_CONV = 1 };
+enum { EPI_T = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_HEADS = 3, EPI_CONVT = 4 };
+enum { HEAD_ROPE = 1, HEAD_VT = 2, HEAD_PLAIN = 3 };
+enum { GF_RELU = 1 };
+
+struct GemmParams {
+    const void* act = nullptr;   // [M][lda] (linear) or NHWC image batch (conv), element type DT
+    const void* wgt = nullptr;   // [n_pad][K], element type DT, rows >= N zero filled
+    const float* bias = nullptr; // [n_pad] or null
+    int M = 0, K = 0, n_pad = 0; // K in elements, multiple of 128/sizeof(DT)
+    int n_store = 0;             // columns written (multiple of 4, <= n_pad)
+    int lda = 0;
+    int amode = AMODE_LINEAR;
+    // implicit-GEMM conv geometry (NHWC, K index = (ky, kx, cin))
+    int Hin = 0, Win = 0, Cin = 0, cstride = 0, Hout = 0, Wout = 0, ksize = 1, stride = 1, pad = 0;
+    const void* zero_page = nullptr;
+    // epilogue
+    int epi = EPI_T;
+    int flags = 0;
+    void* out = nullptr; int ldo = 0;
+    const void* res1 = nullptr; const void* res2 = nullptr; int ldr = 0;
+    void* out2 = nullptr; int ldo2 = 0;
+    int ct_cout = 0;             // EPI_CONVT: (padded) output channels per tap
+    // EPI_HEADS: column n belongs to region n / head_c; head (n % head_c) / 64
+    int head_c = 1 << 30;
+    int head_kind[3] = {0, 0, 0};
+    void* head_dst[3] = {nullptr, nullptr, nullptr};
+    int heads = 0, ntok = 1, tok_w = 1, ldv = 0;
+    const float* rope_table = nullptr;  // [max_pos][16] (cos, sin) pairs
+};
+
+hipError_t launch_gemm(int dt, const GemmParams& p, hipStream_t s);
+
+// ------------------------------------------------------------------------------ attention
+struct AttnParams {
+    const void* q = nullptr;   // [B][H][Nq][64]
+    const void* k = nullptr;   // [B][H][Nk][64]
+    const void* vt = nullptr;  // [B][H][64][ldv]   (ldv >= round_up(Nk, 64), pad zero filled)
+    void* out = nullptr;       // [B][Nq][H*64]
+    int B = 0, H = 0, Nq = 0, Nk = 0, ldv = 0;
+    float scale = 0.125f;
+};
+hipError_t launch_attention(int dt, const AttnParams& p, hipStream_t s);
+
+// ------------------------------------------------------------------------------ elementwise
+// LayerNorm over the last dim of an fp32 [rows][C] tensor -> DT [rows][C]
+hipError_t launch_layernorm(int dt, const float* x, const float* gamma, const float* beta, void* out, int rows, int C,
+                            float eps, hipStream_t s);
+// fp32 -> DT copy (rows x C, contiguous)
+hipError_t launch_convert(int dt, const float* x, void* out, size_t n, hipStream_t s);
+// NCHW fp32 image -> [B*th*tw][3*ps*ps] patch rows of DT (k = (c, py, px))
+hipError_t launch_patchify(int dt, const float* img, void* out, int B, int H, int W, int ps, hipStream_t s);
+// standalone in-place 2-D RoPE on tokens[B][N][H][D] (fp32 / bf16 / f16): the reference's native op
+hipError_t launch_rope2d(int dt, void* tokens, const int64_t* pos, int B, int N, int H, int D, float base, float F0,
+                         hipStream_t s);
+hipError_t launch_rope_table(float* table, int max_pos, float base, float F0, hipStream_t s);
+// bilinear x2, align_corners=True, NHWC DT -> NHWC DT (optionally also relu copy), output cropped to (Ho, Wo)
+hipError_t launch_upsample2x(int dt, const void* in, void* out, void* out_relu, int B, int Hi, int Wi, int C, int cstride,
+                             int Ho, int Wo, hipStream_t s);
+// final DPT stage: relu'd NHWC DT [pix][C] x W[4][C] + b -> postprocess -> pts3d [pix][3], conf [pix]
+hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, const float* b, float* pts, float* conf,
+                             size_t npix, hipStream_t s);
+// linear head: proj output fp32 [B*th*tw][(3+1)*ps*ps] -> pixel_shuffle -> postprocess
+hipError_t launch_linear_head_post(const float* feat, float* pts, float* conf, int B, int th, int tw, int ps, hipStream_t s);
+hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+
+// ------------------------------------------------------------------------------ aligner
+struct AlignerDev;  // defined in aligner.hip
+
+}  // namespace d3r

@@ -1,0 +1,162 @@
+/* dust3r_hip.h -- C ABI of libdust3r_hip.so: the MI355X (gfx950) engine behind the DUSt3R
+ * inference-and-alignment hot path.
+ *
+ * Boundary. The reference (naver/dust3r) exposes this path as a PYTHON API; its only native
+ * interface is croco's `curope` extension. The Python host package `dust3r_amd/` mirrors the
+ * reference API (same names / arguments / outputs) and binds these entry points with ctypes;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add. Every function cites
+ * the reference interface it replaces (paths relative to the reference repository root).
+ *
+ * Conventions: plain pointers and sizes, no framework types. Unless a parameter says "host",
+ * pointers are DEVICE pointers owned by the caller (borrowed for the duration of the call, or
+ * until destroy for handles that document it). `stream` is a hipStream_t passed as void*
+ * (NULL = default stream); calls enqueue work and return without synchronising unless noted.
+ * Return value: D3R_OK (0) or a negative D3R_ERR_* code / 1000 + hipError_t.
+ * Threading: a handle must not be used from two threads at once; distinct handles are independent.
+ */
+#ifndef DUST3R_HIP_H
+#define DUST3R_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3R_OK 0
+#define D3R_ERR_INVALID (-1)
+#define D3R_ERR_ALLOC (-2)
+#define D3R_ERR_LAUNCH (-3)
+#define D3R_ERR_UNKNOWN_KEY (-4)
+#define D3R_ERR_SHAPE (-5)
+#define D3R_ERR_STATE (-6)
+
+/* arithmetic type of the matrix kernels (accumulation is always fp32) */
+#define D3R_DTYPE_BF16 0 /* v_mfma_*_bf16: the throughput mode named by BASELINE.json */
+#define D3R_DTYPE_F16 1  /* v_mfma_*_f16: same rate, 3 more mantissa bits */
+#define D3R_DTYPE_F32 2  /* v_mfma_f32_*_f32: exact fp32 like the reference (dust3r/inference.py:44), 1/16 rate */
+
+const char* d3r_version(void);
+/* 0 when a gfx950 device is visible to the HIP runtime, else an error code (used to fail loudly) */
+int d3r_device_check(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2-D rotary embedding -- drop-in for the reference's only native op:
+ *   croco/models/curope: rope_2d(Tensor tokens[B,N,H,D], Tensor positions[B,N,2] int64, float base, float F0)
+ *   (pybind module `curope`, wrapped by cuRoPE2D; called from
+ *   croco Attention/CrossAttention.forward which dust3r/model.py:136-137,180-186 drives).
+ * In place on `tokens` (contiguous, D % 4 == 0); dtype is one of D3R_DTYPE_*.
+ */
+int d3r_rope2d(void* tokens, const int64_t* positions, int B, int N, int H, int D, float base, float F0, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Building-block kernels (exported so the parity tests can pin each one against PyTorch fp32).
+ */
+/* LayerNorm(eps) over the last dim: x fp32 [rows][C] -> out dtype [rows][C]   (croco norm_layer, eps=1e-6) */
+int d3r_layernorm(const float* x, const float* gamma, const float* beta, void* out, int rows, int C, float eps, int dtype, void* stream);
+
+/* out = epilogue(act[M][K] . wgt[N][K]^T + bias): nn.Linear of croco Mlp/Attention (dust3r/model.py:136-137,176-186).
+ * act, wgt in `dtype`; wgt must hold n_pad = round_up(N,128) rows (extra rows zero); K % (128/sizeof(dtype)) == 0.
+ * epilogue: 0 store dtype | 1 fp32 out (+ optional fp32 residual, may alias out) | 2 GELU(erf) store dtype */
+int d3r_linear(const void* act, const void* wgt, const float* bias, void* out, const float* residual, int M, int N, int K,
+               int epilogue, int dtype, void* stream);
+
+/* 2-D convolution, NHWC, as implicit GEMM: in [B][Hin][Win][Cin] dtype, wgt [round_up(Cout,128)][k*k*Cin] dtype with
+ * K index (ky, kx, cin); out [B][Hout][Wout][Cout] dtype = [relu](conv + bias + res1 + res2)   (DPT head convs,
+ * dust3r/heads/dpt_head.py:34-65). zero_page: >= 256 bytes of zeros. */
+int d3r_conv2d_nhwc(const void* in, const void* wgt, const float* bias, void* out, const void* res1, const void* res2,
+                    void* out_relu_copy, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int pad, int relu,
+                    const void* zero_page, int dtype, void* stream);
+
+/* softmax(q k^T * scale) v: q [B][H][Nq][64], k [B][H][Nk][64], vt [B][H][64][ldv] (ldv % 64 == 0, pad zero),
+ * out [B][Nq][H*64]; all `dtype`   (croco Attention / CrossAttention core) */
+int d3r_attention(const void* q, const void* k, const void* vt, void* out, int B, int H, int Nq, int Nk, int ldv, float scale,
+                  int dtype, void* stream);
+
+/* F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) on NHWC, output cropped to (Ho, Wo) */
+int d3r_upsample2x_nhwc(const void* in, void* out, int B, int Hi, int Wi, int C, int Ho, int Wo, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model engine -- replaces AsymmetricCroCo3DStereo.forward (dust3r/model.py:199-211) including
+ * _encode_image_pairs (:142-151), _decoder (:172-191), the DPT / linear heads
+ * (dust3r/heads/dpt_head.py:34-115, linear_head.py:30-41) and postprocess (heads/postprocess.py:10-58).
+ */
+typedef struct d3r_model d3r_model;
+
+typedef struct d3r_model_config {
+    int enc_embed_dim, enc_depth, enc_num_heads; /* 1024 / 24 / 16 (README.md:318) */
+    int dec_embed_dim, dec_depth, dec_num_heads; /* 768 / 12 / 12 */
+    int patch_size;                              /* 16 */
+    int head_type;                               /* 0 = linear (LinearPts3d), 1 = dpt */
+    int dtype;                                   /* D3R_DTYPE_* */
+    float rope_freq;                             /* 100 for pos_embed='RoPE100' */
+    int dpt_skip_relu_inplace;                   /* 0: skip adds un-activated x (nn.ReLU(False)); see SURVEY.md A.5 */
+} d3r_model_config;
+
+int d3r_model_create(d3r_model** out, const d3r_model_config* cfg);
+int d3r_model_destroy(d3r_model* m);
+/* Load one tensor of the reference checkpoint's state dict by its key, e.g.
+ * "enc_blocks.3.attn.qkv.weight". data: HOST fp32, contiguous, PyTorch layout. Keys the engine does not use
+ * (mask_token, aliased scratch.layerN_rn, ...) return D3R_OK and are ignored; unknown keys -> D3R_ERR_UNKNOWN_KEY.
+ * dec_blocks.* also fills dec_blocks2.* until a dec_blocks2 key arrives (dust3r/model.py:91-98). */
+int d3r_model_load_tensor(d3r_model* m, const char* key, const float* data_host, int ndim, const int64_t* shape);
+/* number of tensors still missing (0 = ready) */
+int d3r_model_missing(const d3r_model* m);
+/* forward on B pairs of equal-size images (H, W multiples of patch_size):
+ * img1, img2: fp32 [B][3][H][W] in [-1,1]; outputs fp32: pts1 [B][H][W][3], conf1 [B][H][W],
+ * pts2 (= pred2['pts3d_in_other_view']) and conf2. Workspace is owned by the model and grown on demand. */
+int d3r_model_forward(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1, float* pts2,
+                      float* conf2, void* stream);
+/* bytes of device memory currently held (weights + workspace) */
+size_t d3r_model_device_bytes(const d3r_model* m);
+/* debug/parity hook: copy an internal activation of the last forward to `out_f32` (device fp32).
+ * what: 0 = encoder output after enc_norm [2B*N][enc_dim] (img1 batch then img2 batch) */
+int d3r_model_debug_read(d3r_model* m, int what, float* out_f32, size_t max_elems, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Global aligner -- replaces the hot loop of cloud_opt.PointCloudOptimizer:
+ *   forward            dust3r/cloud_opt/optimizer.py:188-201 (+ base_opt.py:143-195, commons.py:62-80)
+ *   loss.backward()    autograd
+ *   Adam step + lr     dust3r/cloud_opt/base_opt.py:326-366 (betas (0.9, 0.9), cosine/linear schedule)
+ * Parameter tensors use the reference's own parameterisation and names (state_dict(trainable=True)):
+ *   pw_poses [E][8] = quat XYZW, signed-log translation, log scale;  pw_adaptors [E][2] (frozen);
+ *   im_poses [n][7];  im_depthmaps [n][max_area] log-depth;  im_focals [n] = focal_break*log(f);  im_pp [n][2] (frozen)
+ * They live in caller-owned device memory and are updated IN PLACE; the handle borrows them and the
+ * pred/weight tensors until destroy. pred_* [E][max_area][3], w_* [E][max_area] = conf_trf(conf)
+ * (zero in padding), fp32. ei/ej/img_h/img_w are HOST arrays.
+ */
+typedef struct d3r_aligner d3r_aligner;
+#define D3R_SCHEDULE_COSINE 0
+#define D3R_SCHEDULE_LINEAR 1
+#define D3R_ALIGNER_OPT_DPP_REDUCE 1 /* 1 (default): DPP wave reduction; 0: __shfl_xor butterfly */
+#define D3R_ALIGNER_OPT_RESET_ADAM 2
+
+int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, const int* ei, const int* ej, const int* img_h, const int* img_w,
+                       int max_area, const float* pred_i, const float* pred_j, const float* w_i, const float* w_j, float* pw_poses,
+                       float* pw_adaptors, float* im_poses, float* im_depthmaps, float* im_focals, float* im_pp, float base_scale,
+                       float pw_break, float focal_break, int dist_l2, int norm_pw_scale, int opt_im_poses, int opt_im_focals,
+                       int max_iters_per_run);
+int d3r_aligner_destroy(d3r_aligner* a);
+int d3r_aligner_set_option(d3r_aligner* a, int option, int value);
+/* `niter` iterations of global_alignment_iter; iteration k uses lr = schedule((iter0 + k) / niter_total).
+ * losses_out (device fp32 [niter], may be NULL) receives the loss evaluated BEFORE each step, as float(loss) does
+ * at base_opt.py:366 -- but without the reference's per-iteration host synchronisation. */
+int d3r_aligner_run(d3r_aligner* a, int niter, int iter0, int niter_total, float lr_base, float lr_min, int schedule,
+                    float* losses_out, void* stream);
+/* one forward/backward without a step (parity tests): loss[1] and the gradients w.r.t. each parameter tensor */
+int d3r_aligner_loss_grad(d3r_aligner* a, float* loss, float* g_pw_poses, float* g_im_poses, float* g_im_depthmaps,
+                          float* g_im_focals, void* stream);
+
+/* Host-only self test of the analytic gradient formulas shared with the kernels (no GPU touched; all pointers HOST).
+ * Not a compute path: the product never calls it. */
+int d3r_selftest_aligner_math_host(int n_imgs, int n_edges, const int* ei, const int* ej, int H, int W, const float* pred_i,
+                                   const float* pred_j, const float* w_i, const float* w_j, const float* pw_poses,
+                                   const float* im_poses, const float* im_depthmaps, const float* im_focals, float base_scale,
+                                   float focal_break, double* loss, double* g_pw_poses, double* g_im_poses, double* g_im_depthmaps,
+                                   double* g_im_focals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUST3R_HIP_H */
