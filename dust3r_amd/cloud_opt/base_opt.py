@@ -1,0 +1,373 @@
+"""Global alignment -- host-side mirror of the reference `dust3r/cloud_opt/base_opt.py`
+(`BasePCOptimizer`, `global_alignment_loop`, `clean_pointcloud`).
+
+Same constructor keywords, attributes (`edges, imshapes, imsizes, im_conf, pred_i, pred_j, conf_i,
+conf_j, pw_poses, pw_adaptors, min_conf_thr, conf_trf, is_symmetrized, n_imgs, n_edges,
+str_edges`), getters and `compute_global_alignment(init, niter_PnP, lr, niter, schedule, lr_min)`.
+What differs is WHERE the optimisation runs: the reference builds an autograd graph of ~25 kernels
+per iteration and steps torch.optim.Adam (base_opt.py:326-366); here `global_alignment_loop` hands
+the parameter tensors to the fused HIP aligner (csrc/aligner.hip, C ABI `d3r_aligner_*`), which
+updates them in place. There is no CPU execution path for the loop.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+import tqdm
+
+from .. import _lib
+from .._lib import check, current_stream, lib, ptr
+from ..utils.geometry import geotrf, inv
+from ..utils.rigid import quat_translation_to_homogeneous, rotmat_to_unitquat
+from . import init_im_poses as init_fun
+from .commons import (cosine_schedule, edge_str, get_conf_trf, get_imshapes, linear_schedule, signed_expm1,
+                      signed_log1p)
+
+
+def _ravel_hw(tensor, fill=0):
+    """(H, W, ...) -> (H*W, ...) zero padded to `fill` rows (reference optimizer.py:231-237)."""
+    tensor = tensor.reshape((tensor.shape[0] * tensor.shape[1],) + tuple(tensor.shape[2:]))
+    if len(tensor) < fill:
+        tensor = torch.cat((tensor, tensor.new_zeros((fill - len(tensor),) + tuple(tensor.shape[1:]))))
+    return tensor
+
+
+class _EdgeView:
+    """dict-like access `view['i_j'] -> (H, W, ...)` into a stacked (E, max_area, ...) tensor."""
+
+    def __init__(self, owner, attr, side):
+        self._o, self._attr, self._side = owner, attr, side
+
+    def _index(self, key):
+        return self._o._edge_index[key]
+
+    def __getitem__(self, key):
+        e = self._index(key)
+        i, j = self._o.edges[e]
+        h, w = self._o.imshapes[i if self._side == 0 else j]
+        t = getattr(self._o, self._attr)[e]
+        return t[:h * w].view((h, w) + tuple(t.shape[1:]))
+
+    def __contains__(self, key):
+        return key in self._o._edge_index
+
+    def keys(self):
+        return self._o._edge_index.keys()
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def __len__(self):
+        return len(self._o._edge_index)
+
+
+class BasePCOptimizer(nn.Module):
+    """Optimize a global scene given pairwise observations. Nodes: images; edges: (pred1, pred2)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self._init_from_views(*args, **kwargs)
+
+    def _init_from_views(self, view1, view2, pred1, pred2, dist='l1', conf='log', min_conf_thr=3, base_scale=0.5,
+                         allow_pw_adaptors=False, pw_break=20, rand_pose=torch.randn, iterationsCount=None, verbose=True):
+        if allow_pw_adaptors:
+            raise NotImplementedError('allow_pw_adaptors=True is not supported by the fused aligner (frozen in every reference recipe)')
+        if dist not in ('l1', 'l2'):
+            raise KeyError(dist)
+        if not isinstance(view1['idx'], list):
+            view1['idx'] = view1['idx'].tolist()
+        if not isinstance(view2['idx'], list):
+            view2['idx'] = view2['idx'].tolist()
+        self.edges = [(int(i), int(j)) for i, j in zip(view1['idx'], view2['idx'])]
+        self.is_symmetrized = set(self.edges) == {(j, i) for i, j in self.edges}
+        self.dist_name = dist
+        self.verbose = verbose
+        self.n_imgs = self._check_edges()
+        self._edge_index = {edge_str(i, j): e for e, (i, j) in enumerate(self.edges)}
+
+        pred1_pts, pred2_pts = pred1['pts3d'], pred2['pts3d_in_other_view']
+        pred1_conf, pred2_conf = pred1['conf'], pred2['conf']
+        self.imshapes = get_imshapes(self.edges, pred1_pts, pred2_pts)
+        im_areas = [h * w for h, w in self.imshapes]
+        self.max_area = max(im_areas)
+        assert all(a % 4 == 0 for a in im_areas), 'image areas must be multiples of 4'
+
+        def stack(seq):
+            if isinstance(seq, torch.Tensor) and seq.shape[1] * seq.shape[2] == self.max_area:
+                return seq.detach().float().reshape((seq.shape[0], self.max_area) + tuple(seq.shape[3:])).contiguous()
+            return torch.stack([_ravel_hw(torch.as_tensor(p).detach().float(), self.max_area) for p in seq]).contiguous()
+
+        self.register_buffer('_stacked_pred_i', stack(pred1_pts))
+        self.register_buffer('_stacked_pred_j', stack(pred2_pts))
+        self.register_buffer('_conf_i', stack(pred1_conf))
+        self.register_buffer('_conf_j', stack(pred2_conf))
+        self.pred_i, self.pred_j = _EdgeView(self, '_stacked_pred_i', 0), _EdgeView(self, '_stacked_pred_j', 1)
+        self.conf_i, self.conf_j = _EdgeView(self, '_conf_i', 0), _EdgeView(self, '_conf_j', 1)
+
+        self.min_conf_thr = min_conf_thr
+        self.conf_mode = conf
+        self.conf_trf = get_conf_trf(conf)
+        self.im_conf = self._compute_img_conf()
+
+        # pre-computed pixel weights (zero in the padding, like ParameterStack(fill=max_area))
+        def weights(c, side):
+            w = self.conf_trf(c.clamp_min(1e-30)) if conf == 'log' else self.conf_trf(c)
+            for e, (i, j) in enumerate(self.edges):
+                a = im_areas[i if side == 0 else j]
+                if a < self.max_area:
+                    w[e, a:] = 0
+            return w.contiguous()
+        self.register_buffer('_weight_i', weights(self._conf_i.clone(), 0))
+        self.register_buffer('_weight_j', weights(self._conf_j.clone(), 1))
+
+        self.base_scale = base_scale
+        self.norm_pw_scale = True
+        self.pw_break = pw_break
+        self.POSE_DIM = 7
+        self.pw_poses = nn.Parameter(rand_pose((self.n_edges, 1 + self.POSE_DIM)).float())
+        self.pw_adaptors = nn.Parameter(torch.zeros((self.n_edges, 2)), requires_grad=False)
+        self.has_im_poses = False
+        self.rand_pose = rand_pose
+
+        self.imgs = None
+        if 'img' in view1 and 'img' in view2:
+            from ..utils.image import rgb
+            imgs = [torch.zeros((3,) + hw) for hw in self.imshapes]
+            for v in range(len(self.edges)):
+                imgs[view1['idx'][v]] = view1['img'][v]
+                imgs[view2['idx'][v]] = view2['img'][v]
+            self.imgs = rgb(imgs)
+        self._engine = None
+        self._engine_sig = None
+
+    # ------------------------------------------------------------------ bookkeeping
+    @property
+    def n_edges(self):
+        return len(self.edges)
+
+    @property
+    def str_edges(self):
+        return [edge_str(i, j) for i, j in self.edges]
+
+    @property
+    def imsizes(self):
+        return [(w, h) for h, w in self.imshapes]
+
+    @property
+    def device(self):
+        return self.pw_poses.device
+
+    def _check_edges(self):
+        indices = sorted({i for edge in self.edges for i in edge})
+        assert indices == list(range(len(indices))), 'bad pair indices: missing values '
+        return len(indices)
+
+    @torch.no_grad()
+    def _compute_img_conf(self):
+        im_conf = [torch.zeros(hw, device=self._conf_i.device) for hw in self.imshapes]
+        for e, (i, j) in enumerate(self.edges):
+            im_conf[i] = torch.maximum(im_conf[i], self.conf_i[edge_str(i, j)])
+            im_conf[j] = torch.maximum(im_conf[j], self.conf_j[edge_str(i, j)])
+        return im_conf
+
+    _TRAINABLE_KEYS = ('pw_poses', 'pw_adaptors', 'im_depthmaps', 'im_poses', 'im_focals', 'im_pp')
+
+    def state_dict(self, trainable=True):
+        if trainable:
+            out = {k: getattr(self, k).detach().clone() for k in self._TRAINABLE_KEYS if hasattr(self, k)}
+            out.update({f'im_conf.{i}': c.clone() for i, c in enumerate(self.im_conf)})
+            return out
+        return {k: getattr(self, k) for k in ('_stacked_pred_i', '_stacked_pred_j', '_weight_i', '_weight_j')}
+
+    @torch.no_grad()
+    def load_state_dict(self, data, **kw):
+        for k, v in data.items():
+            if k in self._TRAINABLE_KEYS and hasattr(self, k):
+                getattr(self, k).data.copy_(torch.as_tensor(v).to(getattr(self, k).device).reshape(getattr(self, k).shape))
+            elif k.startswith('im_conf.'):
+                self.im_conf[int(k.split('.')[1])].copy_(torch.as_tensor(v))
+        return self
+
+    def to(self, device, *a, **k):
+        self._destroy_engine()
+        super().to(device, *a, **k)
+        self.im_conf = [c.to(device) for c in self.im_conf]
+        return self
+
+    # ------------------------------------------------------------------ parameter access (cam-to-world)
+    def get_adaptors(self):
+        adapt = self.pw_adaptors
+        adapt = torch.cat((adapt[:, 0:1], adapt), dim=-1)
+        if self.norm_pw_scale:
+            adapt = adapt - adapt.mean(dim=1, keepdim=True)
+        return (adapt / self.pw_break).exp()
+
+    def _get_poses(self, poses):
+        return quat_translation_to_homogeneous(poses[:, :4], signed_expm1(poses[:, 4:7]))
+
+    def _set_pose(self, poses, idx, R, T=None, scale=None, force=False):
+        pose = poses[idx]
+        if not (poses.requires_grad or force):
+            return pose
+        if R is not None and tuple(R.shape) == (4, 4):
+            assert T is None
+            T, R = R[:3, 3], R[:3, :3]
+        with torch.no_grad():
+            if R is not None:
+                poses.data[idx, 0:4] = rotmat_to_unitquat(torch.as_tensor(R).float()).to(poses.device)
+            if T is not None:
+                poses.data[idx, 4:7] = signed_log1p(torch.as_tensor(T).float().to(poses.device) / (scale or 1))
+            if scale is not None:
+                assert poses.shape[-1] in (8, 13)
+                poses.data[idx, -1] = float(np.log(float(scale)))
+        return pose
+
+    def get_pw_norm_scale_factor(self):
+        if self.norm_pw_scale:
+            return (np.log(self.base_scale) - self.pw_poses[:, -1].mean()).exp()
+        return 1
+
+    def get_pw_scale(self):
+        return self.pw_poses[:, -1].exp() * self.get_pw_norm_scale_factor()
+
+    def get_pw_poses(self):
+        RT = self._get_poses(self.pw_poses)
+        scaled = RT.clone()
+        scaled[:, :3] *= self.get_pw_scale().view(-1, 1, 1)
+        return scaled
+
+    def get_masks(self):
+        return [(conf > self.min_conf_thr) for conf in self.im_conf]
+
+    def get_conf(self, mode=None):
+        trf = self.conf_trf if mode is None else get_conf_trf(mode)
+        return [trf(c) for c in self.im_conf]
+
+    def depth_to_pts3d(self):
+        raise NotImplementedError()
+
+    def get_pts3d(self, raw=False):
+        res = self.depth_to_pts3d()
+        if not raw:
+            res = [dm[:h * w].view(h, w, 3) for dm, (h, w) in zip(res, self.imshapes)]
+        return res
+
+    def get_focals(self):
+        raise NotImplementedError()
+
+    def get_im_poses(self):
+        raise NotImplementedError()
+
+    def get_depthmaps(self, raw=False):
+        raise NotImplementedError()
+
+    def get_intrinsics(self):
+        raise NotImplementedError()
+
+    @torch.no_grad()
+    def clean_pointcloud(self, **kw):
+        cams = inv(self.get_im_poses())
+        new_confs = clean_pointcloud(self.im_conf, self.get_intrinsics(), cams, self.get_depthmaps(), self.get_pts3d(), **kw)
+        for i, c in enumerate(new_confs):
+            self.im_conf[i][:] = c
+        return self
+
+    def mask_sky(self):
+        raise NotImplementedError('sky segmentation (cv2) belongs to the visualisation layer, outside this engine')
+
+    def show(self, *a, **k):
+        raise NotImplementedError('trimesh visualisation is outside this engine; export get_pts3d()/get_im_poses() instead')
+
+    # ------------------------------------------------------------------ engine
+    def _engine_signature(self):
+        return None
+
+    def _destroy_engine(self):
+        if getattr(self, '_engine', None) is not None:
+            lib.d3r_aligner_destroy(self._engine)
+            self._engine = None
+
+    def __del__(self):
+        try:
+            self._destroy_engine()
+        except Exception:
+            pass
+
+    def forward(self, ret_details=False):
+        raise NotImplementedError()
+
+    def compute_global_alignment(self, init=None, niter_PnP=10, **kw):
+        if init is None:
+            pass
+        elif init in ('msp', 'mst'):
+            init_fun.init_minimum_spanning_tree(self, niter_PnP=niter_PnP)
+        elif init == 'known_poses':
+            init_fun.init_from_known_poses(self, min_conf_thr=self.min_conf_thr, niter_PnP=niter_PnP)
+        else:
+            raise ValueError(f'bad value for {init=}')
+        return global_alignment_loop(self, **kw)
+
+
+def global_alignment_loop(net, lr=0.01, niter=300, schedule='cosine', lr_min=1e-6):
+    """Mirror of base_opt.py:326-349: Adam(lr, betas=(0.9, 0.9)), lr scheduled per iteration; returns the
+    loss of the last iteration. The iterations run inside the fused HIP aligner."""
+    if schedule not in ('cosine', 'linear'):
+        raise ValueError(f'bad lr {schedule=}')
+    if niter <= 0:
+        return float('inf')
+    verbose = net.verbose
+    if verbose:
+        print('Global alignement - optimizing for:')
+        print(net.trainable_names())
+    eng = net._ensure_engine()
+    check(lib.d3r_aligner_set_option(eng, 2, 0), 'reset adam')          # a fresh optimiser per call, as in the reference
+    sched = 0 if schedule == 'cosine' else 1
+    chunk = min(niter, 50 if verbose else 1024)
+    losses = torch.empty(chunk, dtype=torch.float32, device=net.device)
+    loss = float('inf')
+    bar = tqdm.tqdm(total=niter) if verbose else None
+    done = 0
+    while done < niter:
+        k = min(chunk, niter - done)
+        check(lib.d3r_aligner_run(eng, k, done, niter, float(lr), float(lr_min), sched, ptr(losses), current_stream()), 'aligner_run')
+        done += k
+        if verbose or done >= niter:
+            loss = float(losses[k - 1])                                    # the only host synchronisation
+        if bar is not None:
+            t = (done - 1) / niter
+            cur = cosine_schedule(t, lr, lr_min) if schedule == 'cosine' else linear_schedule(t, lr, lr_min)
+            bar.set_postfix_str(f'lr={cur:g} loss={loss:g}')
+            bar.update(k)
+    if bar is not None:
+        bar.close()
+    return loss
+
+
+@torch.no_grad()
+def clean_pointcloud(im_confs, K, cams, depthmaps, all_pts3d, tol=0.001, bad_conf=0, dbg=()):
+    """Mirror of base_opt.py:369-405: a point of image i that projects IN FRONT of image j's depthmap
+    while being less confident than the pixel it lands on gets its confidence clipped to `bad_conf`."""
+    assert len(im_confs) == len(cams) == len(K) == len(depthmaps) == len(all_pts3d)
+    assert 0 <= tol < 1
+    res = [c.clone() for c in im_confs]
+    all_pts3d = [p.view(*c.shape, 3) for p, c in zip(all_pts3d, im_confs)]
+    depthmaps = [d.view(*c.shape) for d, c in zip(depthmaps, im_confs)]
+    for i, pts3d in enumerate(all_pts3d):
+        for j in range(len(all_pts3d)):
+            if i == j:
+                continue
+            proj = geotrf(cams[j], pts3d)
+            proj_depth = proj[:, :, 2]
+            u, v = geotrf(K[j], proj, norm=1, ncol=2).round().long().unbind(-1)
+            H, W = im_confs[j].shape
+            msk_i = (proj_depth > 0) & (0 <= u) & (u < W) & (0 <= v) & (v < H)
+            msk_j = v[msk_i], u[msk_i]
+            bad_points = (proj_depth[msk_i] < (1 - tol) * depthmaps[j][msk_j]) & (res[i][msk_i] < res[j][msk_j])
+            bad_msk_i = msk_i.clone()
+            bad_msk_i[msk_i] = bad_points
+            res[i][bad_msk_i] = res[i][bad_msk_i].clip_(max=bad_conf)
+    return res

@@ -1,0 +1,296 @@
+"""Host-side mirror of the reference's `dust3r/model.py`: `AsymmetricCroCo3DStereo`, `load_model`.
+
+Same constructor keywords, `from_pretrained`, `load_state_dict` (with the dec_blocks ->
+dec_blocks2 duplication of model.py:91-98), `patch_size`, and `forward(view1, view2) -> (res1,
+res2)` with `res1 = {pts3d (B,H,W,3), conf (B,H,W)}`, `res2 = {pts3d_in_other_view, conf}` in fp32
+(model.py:199-211). The arithmetic runs in the HIP engine (csrc/engine.hip) behind the C ABI
+`d3r_model_*`; this class only owns the fp32 master weights (under the reference checkpoint's key
+names) and the view-dict plumbing. There is no CPU execution path.
+
+Differences, by design:
+  * inference only (no autograd through the engine); `landscape_only=False` semantics, which is what
+    the reference's own `load_model` forces for inference (model.py:31-36);
+  * `precision` ('bf16' | 'fp16' | 'fp32') selects the MFMA family of every contraction
+    (fp32 = the reference's own arithmetic type, exact-fp32 MFMA at 1/16 of the bf16 rate);
+  * a symmetrised batch (misc.py:32-40) is evaluated in full instead of encoding half of it: the
+    outputs are the same because every kernel is batch-position independent.
+"""
+import ast
+import ctypes as C
+import os
+import re
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ModelConfig, check, current_stream, lib, ptr
+
+inf = float('inf')
+
+
+def expected_state(cfg):
+    """OrderedDict key -> shape of the reference checkpoint for this configuration."""
+    Ce, Cd, ps = cfg['enc_embed_dim'], cfg['dec_embed_dim'], cfg['patch_size']
+    s = OrderedDict()
+
+    def lin(p, n, k):
+        s[p + '.weight'] = (n, k)
+        s[p + '.bias'] = (n,)
+
+    def ln(p, c):
+        s[p + '.weight'] = (c,)
+        s[p + '.bias'] = (c,)
+
+    s['mask_token'] = (1, 1, Cd)
+    s['patch_embed.proj.weight'] = (Ce, 3, ps, ps)
+    s['patch_embed.proj.bias'] = (Ce,)
+    for l in range(cfg['enc_depth']):
+        p = f'enc_blocks.{l}'
+        ln(p + '.norm1', Ce), lin(p + '.attn.qkv', 3 * Ce, Ce), lin(p + '.attn.proj', Ce, Ce)
+        ln(p + '.norm2', Ce), lin(p + '.mlp.fc1', 4 * Ce, Ce), lin(p + '.mlp.fc2', Ce, 4 * Ce)
+    ln('enc_norm', Ce)
+    lin('decoder_embed', Cd, Ce)
+    for name in ('dec_blocks', 'dec_blocks2'):
+        for l in range(cfg['dec_depth']):
+            p = f'{name}.{l}'
+            ln(p + '.norm1', Cd), lin(p + '.attn.qkv', 3 * Cd, Cd), lin(p + '.attn.proj', Cd, Cd)
+            for q in ('projq', 'projk', 'projv', 'proj'):
+                lin(p + '.cross_attn.' + q, Cd, Cd)
+            ln(p + '.norm2', Cd), ln(p + '.norm3', Cd), lin(p + '.mlp.fc1', 4 * Cd, Cd), lin(p + '.mlp.fc2', Cd, 4 * Cd)
+            ln(p + '.norm_y', Cd)
+    ln('dec_norm', Cd)
+    for h in (1, 2):
+        hp = f'downstream_head{h}'
+        if cfg['head_type'] == 'linear':
+            lin(hp + '.proj', 4 * ps * ps, Cd)
+            continue
+        dp = hp + '.dpt'
+        ld, din = (96, 192, 384, 768), (Ce, Cd, Cd, Cd)
+        for i in range(4):
+            s[f'{dp}.scratch.layer{i + 1}_rn.weight'] = (256, ld[i], 3, 3)
+        for i in range(4):
+            s[f'{dp}.scratch.layer_rn.{i}.weight'] = (256, ld[i], 3, 3)
+        for i in range(1, 5):
+            rp = f'{dp}.scratch.refinenet{i}'
+            s[rp + '.out_conv.weight'] = (256, 256, 1, 1)
+            s[rp + '.out_conv.bias'] = (256,)
+            for u in (1, 2):
+                for cv in (1, 2):
+                    s[f'{rp}.resConfUnit{u}.conv{cv}.weight'] = (256, 256, 3, 3)
+                    s[f'{rp}.resConfUnit{u}.conv{cv}.bias'] = (256,)
+        s[dp + '.head.0.weight'], s[dp + '.head.0.bias'] = (128, 256, 3, 3), (128,)
+        s[dp + '.head.2.weight'], s[dp + '.head.2.bias'] = (128, 128, 3, 3), (128,)
+        s[dp + '.head.4.weight'], s[dp + '.head.4.bias'] = (4, 128, 1, 1), (4,)
+        for i in range(4):
+            s[f'{dp}.act_postprocess.{i}.0.weight'] = (ld[i], din[i], 1, 1)
+            s[f'{dp}.act_postprocess.{i}.0.bias'] = (ld[i],)
+        s[f'{dp}.act_postprocess.0.1.weight'], s[f'{dp}.act_postprocess.0.1.bias'] = (96, 96, 4, 4), (96,)
+        s[f'{dp}.act_postprocess.1.1.weight'], s[f'{dp}.act_postprocess.1.1.bias'] = (192, 192, 2, 2), (192,)
+        s[f'{dp}.act_postprocess.3.1.weight'], s[f'{dp}.act_postprocess.3.1.bias'] = (768, 768, 3, 3), (768,)
+    return s
+
+
+class _LoadResult:
+    def __init__(self, missing_keys, unexpected_keys):
+        self.missing_keys, self.unexpected_keys = missing_keys, unexpected_keys
+
+    def __repr__(self):
+        if not self.missing_keys and not self.unexpected_keys:
+            return '<All keys matched successfully>'
+        return f'_IncompatibleKeys(missing_keys={self.missing_keys}, unexpected_keys={self.unexpected_keys})'
+
+
+class AsymmetricCroCo3DStereo(nn.Module):
+    """Two siamese encoders, two decoders, two pointmap heads -- executed by libdust3r_hip."""
+
+    def __init__(self, output_mode='pts3d', head_type='linear', depth_mode=('exp', -inf, inf), conf_mode=('exp', 1, inf),
+                 freeze='none', landscape_only=True, patch_embed_cls='PatchEmbedDust3R',
+                 img_size=224, patch_size=16, mask_ratio=0.9, enc_embed_dim=768, enc_depth=12, enc_num_heads=12,
+                 dec_embed_dim=512, dec_depth=8, dec_num_heads=16, mlp_ratio=4, norm_im2_in_dec=True, pos_embed='cosine',
+                 precision=None, **unused):
+        super().__init__()
+        assert output_mode == 'pts3d', f'unexpected {output_mode=}'
+        assert head_type in ('linear', 'dpt'), f'unexpected {head_type=}'
+        assert tuple(depth_mode) == ('exp', -inf, inf) and tuple(conf_mode) == ('exp', 1, inf), \
+            'the engine implements depth_mode=("exp",-inf,inf), conf_mode=("exp",1,inf) (the released checkpoints)'
+        assert pos_embed.startswith('RoPE'), 'DUSt3R checkpoints use RoPE positional embedding'
+        assert mlp_ratio == 4 and norm_im2_in_dec, 'unsupported CroCo variant'
+        assert enc_embed_dim == 64 * enc_num_heads and dec_embed_dim == 64 * dec_num_heads, 'head dim must be 64'
+        img_size = tuple(img_size) if isinstance(img_size, (tuple, list)) else (img_size, img_size)
+        assert img_size[0] % patch_size == 0 and img_size[1] % patch_size == 0, \
+            f'{img_size=} must be multiple of {patch_size=}'
+        self.output_mode, self.head_type, self.depth_mode, self.conf_mode = output_mode, head_type, depth_mode, conf_mode
+        self.patch_embed_cls, self.landscape_only = patch_embed_cls, landscape_only
+        self.patch_size, self.img_size = patch_size, img_size
+        self.enc_embed_dim, self.enc_depth, self.enc_num_heads = enc_embed_dim, enc_depth, enc_num_heads
+        self.dec_embed_dim, self.dec_depth, self.dec_num_heads = dec_embed_dim, dec_depth, dec_num_heads
+        self.rope_freq = float(pos_embed[len('RoPE'):])
+        self.croco_args = dict(img_size=img_size, patch_size=patch_size, mask_ratio=mask_ratio, enc_embed_dim=enc_embed_dim,
+                               enc_depth=enc_depth, enc_num_heads=enc_num_heads, dec_embed_dim=dec_embed_dim,
+                               dec_depth=dec_depth, dec_num_heads=dec_num_heads, mlp_ratio=mlp_ratio,
+                               norm_im2_in_dec=norm_im2_in_dec, pos_embed=pos_embed)
+        self.precision = precision or os.environ.get('DUST3R_AMD_PRECISION', 'bf16')
+        self.dpt_skip_relu_inplace = bool(int(os.environ.get('DUST3R_AMD_DPT_RELU_INPLACE', '0')))
+        self._cfg = dict(enc_embed_dim=enc_embed_dim, enc_depth=enc_depth, dec_embed_dim=dec_embed_dim, dec_depth=dec_depth,
+                         patch_size=patch_size, head_type=head_type)
+        self._spec = expected_state(self._cfg)
+        self._weights = OrderedDict()        # fp32 CPU master copy, reference key names
+        self._engine = None
+        self._engine_device = None
+        self._device = torch.device('cpu')
+
+    # ------------------------------------------------------------------ weights
+    def state_dict(self, *a, **k):
+        return OrderedDict(self._weights)
+
+    def load_state_dict(self, ckpt, strict=True, **kw):
+        new = dict(ckpt)
+        if not any(k.startswith('dec_blocks2') for k in ckpt):            # model.py:91-98
+            for key, value in ckpt.items():
+                if key.startswith('dec_blocks'):
+                    new[key.replace('dec_blocks', 'dec_blocks2')] = value
+        unexpected = [k for k in new if k not in self._spec]
+        for k, shape in self._spec.items():
+            if k in new:
+                t = torch.as_tensor(new[k]).detach().to('cpu', torch.float32).contiguous()
+                if tuple(t.shape) != tuple(shape):
+                    raise RuntimeError(f'size mismatch for {k}: checkpoint {tuple(t.shape)} vs model {tuple(shape)}')
+                self._weights[k] = t
+        missing = [k for k in self._spec if k not in self._weights]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f'Error(s) in loading state_dict: missing {missing[:5]}..., unexpected {unexpected[:5]}...')
+        if self._engine is not None:
+            self._upload()
+        return _LoadResult(missing, unexpected)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, **kw):
+        if os.path.isfile(pretrained_model_name_or_path):
+            return load_model(pretrained_model_name_or_path, device='cpu')
+        raise Exception(f'tried to load {pretrained_model_name_or_path} from huggingface, but failed '
+                        '(no network access in this build: pass a local checkpoint file)')
+
+    # ------------------------------------------------------------------ device / engine
+    def to(self, device=None, *a, **k):
+        if device is None:
+            return self
+        device = torch.device(device)
+        self._device = device
+        if device.type == 'cuda':
+            self._build_engine(device)
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device('cuda', torch.cuda.current_device() if device is None else device))
+
+    def set_precision(self, precision):
+        if precision != self.precision:
+            self.precision = precision
+            if self._engine is not None:
+                self._destroy_engine()
+                self._build_engine(self._engine_device or self._device)
+        return self
+
+    def _destroy_engine(self):
+        if self._engine is not None:
+            lib.d3r_model_destroy(self._engine)
+            self._engine = None
+
+    def __del__(self):
+        try:
+            self._destroy_engine()
+        except Exception:
+            pass
+
+    def _build_engine(self, device):
+        _lib.require_device()
+        self._destroy_engine()
+        with torch.cuda.device(device):
+            cfg = ModelConfig(self.enc_embed_dim, self.enc_depth, self.enc_num_heads, self.dec_embed_dim, self.dec_depth,
+                              self.dec_num_heads, self.patch_size, 1 if self.head_type == 'dpt' else 0,
+                              _lib.DTYPES[self.precision], self.rope_freq, int(self.dpt_skip_relu_inplace))
+            h = C.c_void_p()
+            check(lib.d3r_model_create(C.byref(h), C.byref(cfg)), 'model_create')
+            self._engine, self._engine_device = h, device
+            self._upload()
+
+    def _upload(self):
+        with torch.cuda.device(self._engine_device):
+            for key, t in self._weights.items():
+                shape = (C.c_int64 * t.ndim)(*t.shape)
+                check(lib.d3r_model_load_tensor(self._engine, key.encode(), C.c_void_p(t.data_ptr()), t.ndim, shape),
+                      f'load_tensor({key})')
+            torch.cuda.synchronize()
+
+    @property
+    def device(self):
+        return self._device
+
+    def device_bytes(self):
+        return int(lib.d3r_model_device_bytes(self._engine)) if self._engine is not None else 0
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, view1, view2):
+        _lib.require_device()
+        if self._engine is None:
+            raise _lib.D3RError('model is not on a GPU: call .to("cuda") first (dust3r_amd has no CPU execution path)')
+        missing = lib.d3r_model_missing(self._engine)
+        if missing:
+            raise _lib.D3RError(f'{missing} weight tensors were never loaded')
+        img1, img2 = view1['img'], view2['img']
+        B = img1.shape[0]
+        shape1 = view1.get('true_shape', torch.tensor(img1.shape[-2:])[None].repeat(B, 1))
+        shape2 = view2.get('true_shape', torch.tensor(img2.shape[-2:])[None].repeat(B, 1))
+        for sh in (shape1, shape2):                                       # misc.py:59-64 (wrapper_no)
+            sh = torch.as_tensor(sh)
+            assert sh[0:1].allclose(sh), 'true_shape must be all identical'
+        if img1.shape != img2.shape:
+            raise NotImplementedError('pairs of two different image sizes are not supported by the engine yet')
+        H, W = img1.shape[-2:]
+        assert H % self.patch_size == 0, f'Input image height ({H}) is not a multiple of patch size ({self.patch_size}).'
+        assert W % self.patch_size == 0, f'Input image width ({W}) is not a multiple of patch size ({self.patch_size}).'
+        dev = self._engine_device
+        with torch.cuda.device(dev):
+            i1 = img1.to(dev, torch.float32).contiguous()
+            i2 = img2.to(dev, torch.float32).contiguous()
+            pts1 = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+            pts2 = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+            conf1 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+            conf2 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+            check(lib.d3r_model_forward(self._engine, ptr(i1), ptr(i2), B, H, W, ptr(pts1), ptr(conf1), ptr(pts2), ptr(conf2),
+                                        current_stream()), 'model_forward')
+        res1 = dict(pts3d=pts1, conf=conf1)
+        res2 = dict(pts3d_in_other_view=pts2, conf=conf2)
+        return res1, res2
+
+
+def parse_model_string(args):
+    """Parse the constructor string stored in a checkpoint (`ckpt['args'].model`), e.g.
+    "AsymmetricCroCo3DStereo(pos_embed='RoPE100', img_size=(512, 512), head_type='dpt', ...)",
+    without `eval` (the reference evals it, model.py:39)."""
+    m = re.match(r'\s*AsymmetricCroCo3DStereo\s*\((.*)\)\s*$', args, re.S)
+    if not m:
+        raise ValueError(f'cannot parse model string: {args!r}')
+    src = m.group(1).replace('-inf', '-1e999').replace('inf', '1e999')
+    call = ast.parse(f'f({src})', mode='eval').body
+    return {kw.arg: ast.literal_eval(kw.value) for kw in call.keywords}
+
+
+def load_model(model_path, device, verbose=True, precision=None):
+    """Mirror of dust3r/model.py:27-43 (`strict=False`, ManyAR patch embed swapped, landscape_only=False)."""
+    if verbose:
+        print('... loading model from', model_path)
+    ckpt = torch.load(model_path, map_location='cpu', weights_only=False)
+    args = ckpt['args'].model if hasattr(ckpt['args'], 'model') else ckpt['args']['model']
+    args = args.replace('ManyAR_PatchEmbed', 'PatchEmbedDust3R')
+    kwargs = parse_model_string(args)
+    kwargs['landscape_only'] = False
+    if verbose:
+        print(f'instantiating : AsymmetricCroCo3DStereo({kwargs})')
+    net = AsymmetricCroCo3DStereo(precision=precision, **kwargs)
+    s = net.load_state_dict(ckpt['model'], strict=False)
+    if verbose:
+        print(s)
+    return net.to(device)

@@ -1,0 +1,105 @@
+"""Thin torch-tensor wrappers over the building-block entry points of libdust3r_hip.so
+(d3r_rope2d / d3r_layernorm / d3r_linear / d3r_conv2d_nhwc / d3r_attention / d3r_upsample2x_nhwc).
+
+`rope_2d` is the drop-in for the reference's only native op, croco's `curope.rope_2d(tokens,
+positions, base, F0)` (in place; see include/dust3r_hip.h). The other wrappers exist so the parity
+tests can pin each kernel against PyTorch; the model engine calls the kernels from C++ directly.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, lib, ptr
+
+
+def _dt(t):
+    return {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16, torch.float32: _lib.DTYPE_F32}[t.dtype]
+
+
+def rope_2d(tokens, positions, base, F0=1.0):
+    """In-place 2-D RoPE on tokens (B, N, H, D) contiguous; positions (B, N, 2) int64 (y, x)."""
+    _lib.require_device()
+    assert tokens.is_cuda and tokens.is_contiguous() and tokens.ndim == 4, 'tokens must be a contiguous CUDA (B,N,H,D) tensor'
+    B, N, H, D = tokens.shape
+    assert D % 4 == 0, 'D must be a multiple of 4'
+    assert positions.shape == (B, N, 2) and positions.dtype == torch.int64 and positions.is_contiguous()
+    check(lib.d3r_rope2d(ptr(tokens), ptr(positions), B, N, H, D, float(base), float(F0), _dt(tokens), current_stream()), 'rope2d')
+    return tokens
+
+
+def layernorm(x, gamma, beta, eps=1e-6, dtype=torch.bfloat16):
+    _lib.require_device()
+    rows, Cc = x.shape
+    out = torch.empty((rows, Cc), dtype=dtype, device=x.device)
+    check(lib.d3r_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out), rows, Cc, eps, _dt(out), current_stream()), 'layernorm')
+    return out
+
+
+def pad_rows(w, mult=128):
+    n = w.shape[0]
+    n_pad = (n + mult - 1) // mult * mult
+    if n_pad == n:
+        return w.contiguous()
+    return torch.cat((w, w.new_zeros((n_pad - n,) + tuple(w.shape[1:]))), dim=0).contiguous()
+
+
+def linear(act, weight, bias=None, epilogue='store', residual=None):
+    """act (M,K), weight (N,K) in the same 16/32-bit dtype -> (M,N). epilogue: 'store' | 'f32' | 'gelu'."""
+    _lib.require_device()
+    M, K = act.shape
+    N = weight.shape[0]
+    wp = pad_rows(weight)
+    bp = None if bias is None else pad_rows(bias.float())
+    epi = {'store': 0, 'f32': 1, 'gelu': 2}[epilogue]
+    out = torch.empty((M, N), dtype=torch.float32 if epi == 1 else act.dtype, device=act.device)
+    check(lib.d3r_linear(ptr(act), ptr(wp), ptr(bp), ptr(out), ptr(residual), M, N, K, epi, _dt(act), current_stream()), 'linear')
+    return out
+
+
+def pack_conv_weight(w):
+    """torch (Cout, Cin, kh, kw) -> (round_up(Cout,128), kh*kw*Cin) with K index (ky, kx, cin)."""
+    return pad_rows(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
+
+
+_zero_pages = {}
+
+
+def _zero_page(device):
+    if device not in _zero_pages:
+        _zero_pages[device] = torch.zeros(4096, dtype=torch.uint8, device=device)
+    return _zero_pages[device]
+
+
+def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, relu=False, res1=None, res2=None, relu_copy=False):
+    """x (B,H,W,Cin) NHWC; weight torch layout (Cout,Cin,k,k); returns (B,Ho,Wo,Cout) [, relu copy]."""
+    _lib.require_device()
+    B, H, W, Cin = x.shape
+    Cout, _, k, _ = weight.shape
+    wp = pack_conv_weight(weight.to(x.dtype))
+    bp = None if bias is None else pad_rows(bias.float())
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    out2 = torch.empty_like(out) if relu_copy else None
+    check(lib.d3r_conv2d_nhwc(ptr(x), ptr(wp), ptr(bp), ptr(out), ptr(res1), ptr(res2), ptr(out2), B, H, W, Cin, Cout, k, stride,
+                              pad, int(relu), ptr(_zero_page(x.device)), _dt(x), current_stream()), 'conv2d_nhwc')
+    return (out, out2) if relu_copy else out
+
+
+def attention(q, k, vt, Nk=None, scale=0.125):
+    """q (B,H,Nq,64), k (B,H,Nk,64), vt (B,H,64,ldv) with ldv % 64 == 0 and zero padding -> (B,Nq,H*64)."""
+    _lib.require_device()
+    B, H, Nq, D = q.shape
+    assert D == 64
+    Nk = k.shape[2] if Nk is None else Nk
+    ldv = vt.shape[3]
+    out = torch.empty((B, Nq, H * 64), dtype=q.dtype, device=q.device)
+    check(lib.d3r_attention(ptr(q), ptr(k), ptr(vt), ptr(out), B, H, Nq, Nk, ldv, scale, _dt(q), current_stream()), 'attention')
+    return out
+
+
+def upsample2x_nhwc(x, out_hw=None):
+    _lib.require_device()
+    B, H, W, Cc = x.shape
+    Ho, Wo = out_hw if out_hw is not None else (2 * H, 2 * W)
+    out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    check(lib.d3r_upsample2x_nhwc(ptr(x), ptr(out), B, H, W, Cc, Ho, Wo, _dt(x), current_stream()), 'upsample2x')
+    return out
