@@ -1,0 +1,105 @@
+"""ORACLE (test infrastructure; BUILD CONTAINER ONLY) -- generates tests/golden/*.pt by running the
+UNMODIFIED reference files from /root/reference (through oracle/ref_import.py) on seeded synthetic
+weights / inputs. The fixtures hold only small outputs; weights and inputs are regenerated from
+their seeds at test time (dust3r_amd/synthetic.py), so the fixtures stay a few hundred KB.
+
+    python oracle/make_golden.py
+
+What is pinned by these vectors: every reference line that exists in the snapshot (dust3r/model.py
+forward glue, heads, postprocess, cloud_opt optimizer + Adam loop). What is NOT (stated in the
+fixture's `unpinned` field): the croco modules and roma functions underneath, which are restated.
+"""
+import copy
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle.ref_import import import_reference  # noqa: E402
+
+import_reference()
+from dust3r.cloud_opt import GlobalAlignerMode, global_aligner  # noqa: E402
+from dust3r.inference import inference  # noqa: E402
+from dust3r.image_pairs import make_pairs  # noqa: E402
+from dust3r.model import AsymmetricCroCo3DStereo  # noqa: E402
+
+from dust3r_amd.synthetic import (MODEL_CONFIGS, OUT_GAIN, synthetic_image_list, synthetic_scene,  # noqa: E402
+                                  synthetic_state_dict, synthetic_views)
+
+inf = float('inf')
+OUT = os.path.join(ROOT, 'tests', 'golden')
+UNPINNED = 'croco models/* and roma are absent from the reference snapshot: restated in oracle/ (see oracle/__init__.py)'
+
+
+def ref_model(config, seed=0):
+    m = AsymmetricCroCo3DStereo(output_mode='pts3d', depth_mode=('exp', -inf, inf), conf_mode=('exp', 1, inf),
+                                landscape_only=False, **MODEL_CONFIGS[config]).eval()
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), seed, OUT_GAIN[config]))
+    return m
+
+
+def forward_golden(config, B, H, W, seed):
+    m = ref_model(config)
+    v1, v2 = synthetic_views(B, H, W, seed=seed)
+    with torch.no_grad():
+        r1, r2 = m(v1, v2)
+    return dict(kind='forward', config=config, weight_seed=0, view_seed=seed, B=B, H=H, W=W, unpinned=UNPINNED,
+                pts3d=r1['pts3d'].clone(), conf=r1['conf'].clone(), pts3d_in_other_view=r2['pts3d_in_other_view'].clone(),
+                conf2=r2['conf'].clone())
+
+
+def inference_golden(config, n_views, H, W, seed):
+    """reference make_pairs + inference(batch_size=2) end to end: pins collate / output structure / edge order."""
+    m = ref_model(config)
+    imgs = synthetic_image_list(n_views, H, W, seed=seed)
+    pairs = make_pairs(imgs, scene_graph='complete', prefilter=None, symmetrize=True)
+    out = inference(pairs, m, 'cpu', batch_size=2, verbose=False)
+    return dict(kind='inference', config=config, n_views=n_views, H=H, W=W, view_seed=seed, unpinned=UNPINNED,
+                idx1=list(out['view1']['idx']), idx2=list(out['view2']['idx']),
+                pts3d=out['pred1']['pts3d'].clone(), conf=out['pred1']['conf'].clone(),
+                pts3d_in_other_view=out['pred2']['pts3d_in_other_view'].clone(), conf2=out['pred2']['conf'].clone())
+
+
+def aligner_golden(n_views, H, W, seed, niter):
+    out, init, gt = synthetic_scene(n_views, H, W, seed=seed, symmetrize=True)
+    scene = global_aligner(copy.deepcopy(out), 'cpu', mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
+    scene.load_state_dict(scene.state_dict(trainable=True) | init)
+    loss0 = scene()
+    loss0.backward()
+    grads = {k: getattr(scene, k).grad.clone() for k in ('pw_poses', 'im_poses', 'im_depthmaps', 'im_focals')}
+    for p in scene.parameters():
+        p.grad = None
+    import dust3r.cloud_opt.base_opt as bo
+    losses = []
+    orig = bo.global_alignment_iter
+
+    def spy(*a, **k):
+        l, lr = orig(*a, **k)
+        losses.append(l)
+        return l, lr
+    bo.global_alignment_iter = spy
+    final = scene.compute_global_alignment(init=None, niter=niter, schedule='cosine', lr=0.01)
+    bo.global_alignment_iter = orig
+    return dict(kind='aligner', n_views=n_views, H=H, W=W, seed=seed, niter=niter, unpinned=UNPINNED, loss0=float(loss0),
+                grads=grads, losses=torch.tensor(losses), final_loss=float(final),
+                im_poses=scene.get_im_poses().detach().clone(), focals=scene.get_focals().detach().clone(),
+                state={k: v.detach().clone() for k, v in scene.state_dict(trainable=True).items() if not k.startswith('im_conf')})
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    jobs = {
+        'forward_tiny_dpt.pt': lambda: forward_golden('tiny_dpt', 2, 32, 48, seed=1),
+        'forward_tiny_linear.pt': lambda: forward_golden('tiny_linear', 3, 32, 32, seed=2),
+        'inference_tiny_dpt.pt': lambda: inference_golden('tiny_dpt', 3, 32, 48, seed=3),
+        'aligner_4v.pt': lambda: aligner_golden(4, 24, 32, seed=0, niter=300),
+    }
+    for name, fn in jobs.items():
+        g = fn()
+        torch.save(g, os.path.join(OUT, name))
+        print(name, os.path.getsize(os.path.join(OUT, name)) // 1024, 'KiB')

@@ -1,0 +1,126 @@
+"""GPU parity of the model engine (C ABI d3r_model_forward through dust3r_amd.model) against the CPU
+fp32 oracle and the golden vectors generated from the reference.
+
+Tolerances (per-pixel relative pointmap error |d| / |ref|):
+  fp32 mode : max  <= 1e-3  -- the north-star bar; the engine's fp32-MFMA path is held to it strictly
+  fp16/bf16 : mean <= 8e-3 / 5e-2 on the tiny configs -- 16-bit operand rounding through the depth,
+              measured and reported (DESIGN.md "precision modes"); the bar there is the rounding floor of the
+              same network evaluated by PyTorch with operands rounded to the same type (tools/precision_probe.py)
+"""
+import os
+
+import pytest
+import torch
+
+from dust3r_amd.synthetic import MODEL_CONFIGS, synthetic_views
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def pix_rel(a, b):
+    e = (a.float().cpu() - b).norm(dim=-1) / b.norm(dim=-1).clamp_min(1e-8)
+    return float(e.max()), float(e.mean())
+
+
+def engine_from_oracle(oracle, config, precision, gpu):
+    from dust3r_amd.model import AsymmetricCroCo3DStereo
+    cfg = MODEL_CONFIGS[config] if isinstance(config, str) else config
+    m = AsymmetricCroCo3DStereo(precision=precision, landscape_only=False, **cfg)
+    m.load_state_dict(oracle.state_dict(), strict=True)
+    return m.to(gpu)
+
+
+def compare(engine, oracle, v1, v2, max_tol, mean_tol, tag=''):
+    with torch.no_grad():
+        r1, r2 = oracle(v1, v2)
+    e1, e2 = engine({k: v for k, v in v1.items()}, {k: v for k, v in v2.items()})
+    torch.cuda.synchronize()
+    assert e1['pts3d'].dtype == torch.float32 and e1['pts3d'].shape == r1['pts3d'].shape and e2['conf'].shape == r2['conf'].shape
+    for name, a, b in (('pts1', e1['pts3d'], r1['pts3d']), ('pts2', e2['pts3d_in_other_view'], r2['pts3d_in_other_view'])):
+        mx, mean = pix_rel(a, b)
+        print(f'[{tag}] {name}: rel err max {mx:.3e} mean {mean:.3e}')
+        assert mx < max_tol and mean < mean_tol, (name, mx, mean)
+    for name, a, b in (('conf1', e1['conf'], r1['conf']), ('conf2', e2['conf'], r2['conf'])):
+        err = float(((a.cpu() - b).abs() / b.abs()).max())
+        print(f'[{tag}] {name}: rel err max {err:.3e}')
+        assert err < max_tol * 3, (name, err)
+
+
+TOLS = {'fp32': (1e-3, 2e-4), 'fp16': (5e-2, 8e-3), 'bf16': (3e-1, 5e-2)}
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16', 'bf16'])
+@pytest.mark.parametrize('config,B,H,W', [('tiny_dpt', 2, 32, 48), ('tiny_dpt', 1, 64, 64), ('tiny_dpt', 1, 48, 80), ('tiny_linear', 3, 32, 32),
+                                          ('tiny_linear', 1, 224, 224)])
+def test_forward_matches_oracle(gpu, precision, config, B, H, W):
+    from oracle.dust3r_ref import build_ref_model
+    oracle = build_ref_model(config)
+    eng = engine_from_oracle(oracle, config, precision, gpu)
+    v1, v2 = synthetic_views(B, H, W, seed=H + W)
+    compare(eng, oracle, v1, v2, *TOLS[precision], tag=f'{config} {precision} {B}x{H}x{W}')
+
+
+@pytest.mark.parametrize('name', ['forward_tiny_dpt.pt', 'forward_tiny_linear.pt'])
+def test_forward_matches_reference_golden(gpu, name):
+    """fp32 engine against vectors produced by the unmodified reference files (oracle/make_golden.py)."""
+    from oracle.dust3r_ref import build_ref_model
+    g = torch.load(os.path.join(GOLD, name), weights_only=False)
+    eng = engine_from_oracle(build_ref_model(g['config'], seed=g['weight_seed']), g['config'], 'fp32', gpu)
+    v1, v2 = synthetic_views(g['B'], g['H'], g['W'], seed=g['view_seed'])
+    e1, e2 = eng(v1, v2)
+    for a, b in ((e1['pts3d'], g['pts3d']), (e2['pts3d_in_other_view'], g['pts3d_in_other_view'])):
+        mx, mean = pix_rel(a, b)
+        assert mx < 1e-3, (mx, mean)
+    assert float(((e1['conf'].cpu() - g['conf']).abs() / g['conf']).max()) < 1e-3
+
+
+def test_forward_batch_position_independence(gpu):
+    """A pair's result must not depend on where it sits in the batch (bit-exact): this is what makes pair
+    sharding across ranks and the symmetrised-batch shortcut output-identical."""
+    from oracle.dust3r_ref import build_ref_model
+    eng = engine_from_oracle(build_ref_model('tiny_dpt'), 'tiny_dpt', 'bf16', gpu)
+    v1, v2 = synthetic_views(4, 32, 48, seed=11)
+    full1, full2 = eng(v1, v2)
+    for b in (0, 3):
+        s1 = dict(img=v1['img'][b:b + 1], true_shape=v1['true_shape'][b:b + 1], idx=[0], instance=['0'])
+        s2 = dict(img=v2['img'][b:b + 1], true_shape=v2['true_shape'][b:b + 1], idx=[1], instance=['1'])
+        o1, o2 = eng(s1, s2)
+        assert torch.equal(o1['pts3d'][0], full1['pts3d'][b]) and torch.equal(o2['conf'][0], full2['conf'][b])
+
+
+def test_inference_api_end_to_end(gpu):
+    """make_pairs -> inference(): same structure / edge order as the reference golden, values from the fp32 engine."""
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.inference import inference
+    from dust3r_amd.synthetic import synthetic_image_list
+    from oracle.dust3r_ref import build_ref_model
+    g = torch.load(os.path.join(GOLD, 'inference_tiny_dpt.pt'), weights_only=False)
+    eng = engine_from_oracle(build_ref_model(g['config']), g['config'], 'fp32', gpu)
+    imgs = synthetic_image_list(g['n_views'], g['H'], g['W'], seed=g['view_seed'])
+    out = inference(make_pairs(imgs, 'complete', None, True), eng, gpu, batch_size=2, verbose=False)
+    assert out['view1']['idx'] == g['idx1'] and out['view2']['idx'] == g['idx2'] and out['loss'] is None
+    assert out['pred1']['pts3d'].device.type == 'cpu' and out['view1']['img'].device.type == 'cpu'
+    mx, _ = pix_rel(out['pred1']['pts3d'], g['pts3d'])
+    mx2, _ = pix_rel(out['pred2']['pts3d_in_other_view'], g['pts3d_in_other_view'])
+    assert mx < 1e-3 and mx2 < 1e-3
+
+
+def test_full_size_fp32_pair_matches_oracle(gpu):
+    """BASELINE config: DUSt3R_ViTLarge_BaseDecoder_512_dpt, one 512x384 pair, fp32 engine vs CPU oracle <= 1e-3."""
+    from oracle.dust3r_ref import build_ref_model
+    cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    oracle = build_ref_model(cfg)
+    eng = engine_from_oracle(oracle, cfg, 'fp32', gpu)
+    v1, v2 = synthetic_views(1, 384, 512, seed=0)
+    compare(eng, oracle, v1, v2, 1e-3, 2e-4, tag='512_dpt fp32 1x384x512')
+    # 16-bit modes on the full network: report (and bound) the error against the same fp32 oracle outputs
+    with torch.no_grad():
+        r1, _ = oracle(v1, v2)
+    for prec, bound in (('fp16', 2e-2), ('bf16', 1e-1)):
+        eng.set_precision(prec)
+        e1, _ = eng(v1, v2)
+        mx, mean = pix_rel(e1['pts3d'], r1['pts3d'])
+        print(f'[512_dpt {prec}] pts1 rel err max {mx:.3e} mean {mean:.3e}')
+        assert mean < bound

@@ -1,0 +1,143 @@
+"""GPU parity tests of the building-block kernels, called through the C ABI (ctypes) and compared
+with plain PyTorch fp32 on the SAME (already rounded) operands. Tolerances: fp32 path 2e-5 relative
+to the output scale (accumulation order only); 16-bit paths additionally carry ONE output rounding
+(2^-8 bf16, 2^-11 f16) where the kernel stores 16-bit."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+OUT_TOL = {torch.float32: 2e-5, torch.bfloat16: 6e-3, torch.float16: 8e-4}
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('rows,C', [(7, 128), (1000, 768), (513, 1024)])
+def test_layernorm(gpu, dtype, rows, C):
+    from dust3r_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(rows + C)
+    x = (torch.randn((rows, C), generator=g) * 3 + 0.5).to(gpu)
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(gpu), (0.1 * torch.randn(C, generator=g)).to(gpu)
+    out = ops.layernorm(x, gamma, beta, eps=1e-6, dtype=dtype)
+    ref = F.layer_norm(x, (C,), gamma, beta, eps=1e-6)
+    assert relerr(out, ref) < OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N,K', [(300, 192, 256), (128, 128, 128), (1000, 3072, 1024), (77, 96, 768)])
+def test_linear_epilogues(gpu, dtype, M, N, K):
+    from dust3r_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(M * 7 + N)
+    a = torch.randn((M, K), generator=g).to(gpu).to(dtype)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(gpu).to(dtype)
+    b = torch.randn(N, generator=g).to(gpu)
+    res = torch.randn((M, N), generator=g).to(gpu)
+    ref = a.float() @ w.float().T + b
+    out = ops.linear(a, w, b, 'store')
+    assert relerr(out, ref) < OUT_TOL[dtype], 'store epilogue'
+    out = ops.linear(a, w, b, 'f32', residual=res)
+    assert out.dtype == torch.float32 and relerr(out, ref + res) < 2e-5, 'fp32 + residual epilogue'
+    out = ops.linear(a, w, None, 'f32')
+    assert relerr(out, a.float() @ w.float().T) < 2e-5, 'no-bias'
+    out = ops.linear(a, w, b, 'gelu')
+    assert relerr(out, F.gelu(ref)) < OUT_TOL[dtype], 'gelu epilogue'
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,H,W,Cin,Cout,k,stride,pad', [(2, 12, 16, 128, 256, 3, 1, 1), (1, 24, 32, 256, 128, 3, 2, 1), (3, 6, 8, 256, 96, 1, 1, 0),
+                                                       (1, 7, 5, 64, 128, 3, 1, 1), (2, 21, 32, 128, 128, 3, 2, 1)])
+def test_conv2d_nhwc(gpu, dtype, B, H, W, Cin, Cout, k, stride, pad):
+    from dust3r_amd import ops
+    if dtype == torch.float32 and Cin % 32:
+        pytest.skip('Cin must be a multiple of the K tile')
+    g = torch.Generator(device='cpu').manual_seed(B * 100 + Cin + Cout)
+    x = torch.randn((B, H, W, Cin), generator=g).to(gpu).to(dtype)
+    w = (torch.randn((Cout, Cin, k, k), generator=g) / math.sqrt(Cin * k * k)).to(gpu).to(dtype)
+    b = torch.randn(Cout, generator=g).to(gpu)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    out = ops.conv2d_nhwc(x, w, b, stride=stride, pad=pad)
+    assert out.shape == ref.shape and relerr(out, ref) < OUT_TOL[dtype]
+    r1 = torch.randn(ref.shape, generator=g).to(gpu).to(dtype)
+    r2 = torch.randn(ref.shape, generator=g).to(gpu).to(dtype)
+    out, out_relu = ops.conv2d_nhwc(x, w, b, stride=stride, pad=pad, res1=r1, res2=r2, relu_copy=True)
+    full = ref + r1.float() + r2.float()
+    assert relerr(out, full) < OUT_TOL[dtype] and relerr(out_relu, full.clamp_min(0)) < OUT_TOL[dtype]
+    out = ops.conv2d_nhwc(x, w, None, stride=stride, pad=pad, relu=True)
+    assert relerr(out, (ref - b).clamp_min(0)) < OUT_TOL[dtype]
+
+
+def _attention_ref(q, k, v, scale):
+    a = (q.float() @ k.float().transpose(-1, -2)) * scale
+    return (a.softmax(-1) @ v.float()).transpose(1, 2).flatten(2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,H,Nq,Nk', [(2, 3, 196, 196), (1, 2, 768, 768), (2, 1, 6, 6), (1, 4, 130, 70), (1, 1, 768, 196)])
+def test_attention(gpu, dtype, B, H, Nq, Nk):
+    from dust3r_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(Nq * 3 + Nk)
+    q = (torch.randn((B, H, Nq, 64), generator=g) * 1.5).to(gpu).to(dtype)
+    k = (torch.randn((B, H, Nk, 64), generator=g) * 1.5).to(gpu).to(dtype)
+    v = torch.randn((B, H, Nk, 64), generator=g).to(gpu).to(dtype)
+    ldv = (Nk + 63) // 64 * 64
+    vt = torch.zeros((B, H, 64, ldv), dtype=dtype, device=gpu)
+    vt[..., :Nk] = v.transpose(-1, -2)
+    out = ops.attention(q, k, vt, Nk=Nk, scale=0.125)
+    ref = _attention_ref(q, k, v, 0.125)
+    # P is rounded to the 16-bit type before P V: tolerance is that rounding (not accumulated: P sums to 1)
+    tol = {torch.float32: 3e-5, torch.bfloat16: 1.2e-2, torch.float16: 2e-3}[dtype]
+    assert relerr(out, ref) < tol
+
+
+def test_attention_softmax_is_stable(gpu):
+    """one key dominating by a huge margin at a late tile: the running-max rescale branch must be exact."""
+    from dust3r_amd import ops
+    B, H, N = 1, 1, 256
+    q = torch.zeros((B, H, N, 64), device=gpu)
+    k = torch.zeros((B, H, N, 64), device=gpu)
+    q[..., 0] = 30.0
+    k[0, 0, 200, 0] = 30.0           # score 900 * 0.125 for key 200, 0 elsewhere
+    v = torch.randn((B, H, N, 64), device=gpu)
+    out = ops.attention(q, k, v.transpose(-1, -2).contiguous(), scale=0.125)
+    assert relerr(out[0, :, :], v[0, 0, 200].expand(N, 64)) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_rope2d_matches_reference_op(gpu, dtype):
+    """d3r_rope2d vs the restated curope arithmetic (oracle) and vs croco's pure-torch RoPE2D module."""
+    from dust3r_amd import ops
+    from oracle.croco_ref.models.pos_embed import RoPE2D, rope_2d_inplace_ref
+    B, N, H, D = 2, 35, 3, 64
+    g = torch.Generator(device='cpu').manual_seed(5)
+    tok = torch.randn((B, N, H, D), generator=g)
+    pos = torch.stack((torch.randint(0, 24, (B, N), generator=g), torch.randint(0, 32, (B, N), generator=g)), dim=-1)
+    ref = rope_2d_inplace_ref(tok.clone(), pos, 100.0, 1.0)
+    ref2 = RoPE2D(freq=100.0)(tok.transpose(1, 2), pos).transpose(1, 2)
+    assert relerr(ref, ref2) < 1e-5
+    out = ops.rope_2d(tok.to(gpu).to(dtype).contiguous(), pos.to(gpu).contiguous(), 100.0, 1.0)
+    ref16 = rope_2d_inplace_ref(tok.to(dtype).float(), pos, 100.0, 1.0)
+    assert relerr(out.cpu(), ref16) < {torch.float32: 1e-5, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
+    # rotation => norm preserving per (y | x) half
+    if dtype == torch.float32:
+        assert torch.allclose(out.cpu().norm(dim=-1), tok.norm(dim=-1), rtol=1e-5)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,H,W,C,crop', [(2, 12, 16, 256, None), (1, 11, 16, 256, (21, 32)), (1, 5, 3, 128, None)])
+def test_upsample2x(gpu, dtype, B, H, W, C, crop):
+    from dust3r_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(H * W)
+    x = torch.randn((B, H, W, C), generator=g).to(gpu).to(dtype)
+    ref = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode='bilinear', align_corners=True).permute(0, 2, 3, 1)
+    if crop:
+        ref = ref[:, :crop[0], :crop[1]]
+    out = ops.upsample2x_nhwc(x, crop)
+    assert out.shape == ref.shape and relerr(out, ref) < OUT_TOL[dtype]

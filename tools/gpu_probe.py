@@ -1,0 +1,112 @@
+"""On-GPU performance probe (not a test): times the dominant kernels and the full forward / aligner step.
+Usage: python tools/gpu_probe.py [gemm] [attn] [forward] [aligner]"""
+import math
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, '.')
+from dust3r_amd import ops  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def timeit(fn, warm=3, reps=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps
+
+
+def gemm_probe():
+    print('== GEMM (bf16), ms and TFLOP/s')
+    for (M, N, K) in [(49152, 3072, 1024), (49152, 1024, 1024), (49152, 4096, 1024), (49152, 1024, 4096), (24576, 2304, 768),
+                      (24576, 3072, 768), (24576, 768, 3072), (4096, 4096, 4096), (8192, 8192, 8192)]:
+        for dt in (torch.bfloat16, torch.float16, torch.float32):
+            if dt == torch.float32 and M * N * K > 2e11:
+                continue
+            a = torch.randn((M, K), device=dev).to(dt)
+            w = ops.pad_rows((torch.randn((N, K), device=dev) / math.sqrt(K)).to(dt))
+            b = torch.randn(N, device=dev)
+            out = torch.empty((M, N), dtype=dt, device=dev)
+            from dust3r_amd._lib import lib, ptr, current_stream, check
+
+            def run():
+                check(lib.d3r_linear(ptr(a), ptr(w), ptr(b), ptr(out), None, M, N, K, 0, ops._dt(a), current_stream()))
+            ms = timeit(run)
+            print(f'  M={M} N={N} K={K} {str(dt)[6:]:9s} {ms:8.3f} ms  {2 * M * N * K / ms / 1e9:8.1f} TF/s')
+            if dt == torch.bfloat16:
+                ms2 = timeit(lambda: torch.nn.functional.linear(a, w[:N], None))
+                print(f'      (torch/hipBLASLt same shape: {ms2:8.3f} ms  {2 * M * N * K / ms2 / 1e9:8.1f} TF/s)')
+
+
+def attn_probe():
+    print('== attention (N=768, d=64)')
+    for (B, H, dt) in [(64, 16, torch.bfloat16), (64, 16, torch.float16), (32, 12, torch.bfloat16), (8, 16, torch.float32)]:
+        N = 768
+        q = torch.randn((B, H, N, 64), device=dev).to(dt)
+        k = torch.randn((B, H, N, 64), device=dev).to(dt)
+        vt = torch.randn((B, H, 64, N), device=dev).to(dt)
+        ms = timeit(lambda: ops.attention(q, k, vt))
+        fl = 4 * B * H * N * N * 64
+        print(f'  B={B} H={H} {str(dt)[6:]:9s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s')
+
+
+def forward_probe():
+    from dust3r_amd.model import AsymmetricCroCo3DStereo
+    from dust3r_amd.synthetic import MODEL_CONFIGS, OUT_GAIN, synthetic_state_dict, synthetic_views
+    cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
+    print('== forward', cfg)
+    m = AsymmetricCroCo3DStereo(precision='bf16', landscape_only=False, **MODEL_CONFIGS[cfg])
+    t = time.time()
+    m.load_state_dict(synthetic_state_dict({k: torch.empty(v, device='meta') for k, v in m._spec.items()}, 0, OUT_GAIN[cfg]))
+    print(f'  synthetic weights {time.time() - t:.1f}s')
+    t = time.time()
+    m.to(dev)
+    print(f'  upload+pack {time.time() - t:.1f}s  weights {m.device_bytes() / 2**30:.2f} GiB')
+    for prec in ('bf16', 'fp16', 'fp32'):
+        m.set_precision(prec)
+        for B in ((1, 4, 16, 32) if prec != 'fp32' else (1, 4)):
+            v1, v2 = synthetic_views(B, 384, 512, seed=0, device=dev)
+            ms = timeit(lambda: m(v1, v2), warm=2, reps=3 if B >= 16 else 5)
+            print(f'  {prec} B={B:3d}: {ms:9.2f} ms/forward  {B / ms * 1e3:8.2f} pairs/s  {B * 1856.8 / ms:8.1f} TF/s eff  mem {m.device_bytes() / 2**30:.1f} GiB')
+
+
+def aligner_probe():
+    from dust3r_amd.cloud_opt import global_aligner
+    from dust3r_amd.cloud_opt.base_opt import global_alignment_loop
+    from dust3r_amd.synthetic import synthetic_scene
+    print('== aligner')
+    for (n, sym) in ((20, False), (20, True)):
+        out, init, gt = synthetic_scene(n, 384, 512, seed=0, symmetrize=sym, device=dev)
+        scene = global_aligner(out, dev, verbose=False)
+        scene.load_state_dict(init)
+        E = scene.n_edges
+        global_alignment_loop(scene, niter=10)
+        torch.cuda.synchronize()
+        t = time.time()
+        loss = global_alignment_loop(scene, niter=300)
+        torch.cuda.synchronize()
+        dt = time.time() - t
+        by = E * 196608 * 32 + n * 196608 * 4 * 6
+        print(f'  n={n} E={E}: 300 iters {dt * 1e3:.1f} ms  {300 / dt:.1f} it/s  {by * 300 / dt / 1e12:.2f} TB/s algorithmic  final loss {loss:.5f}')
+        del scene, out
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['gemm', 'attn', 'forward', 'aligner']
+    print(torch.cuda.get_device_name(0))
+    for w in which:
+        try:
+            {'gemm': gemm_probe, 'attn': attn_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
+        except Exception as e:  # keep going: this is a probe
+            import traceback
+            traceback.print_exc()
+            print('!!', w, 'failed:', e)
