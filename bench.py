@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's measurement contract for the DUSt3R hot path on MI355X.
+
+Metric (BASELINE.json): image-pairs/s of `AsymmetricCroCo3DStereo.forward`, DUSt3R_ViTLarge_BaseDecoder_512_dpt,
+synthetic 512x384 pairs (configs[1]: 32 pairs per GPU per step, inputs resident in HBM), at 1/2/4/8 GPUs; the
+second half of the metric, global_aligner iterations/s (configs[3]: 20 views, 190 edges, 300 cosine iterations),
+is reported in the same JSON line under "aligner".
+
+One step = one engine forward over `--pairs` image pairs per rank. At N > 1 ranks the pairs shard across ranks
+(weak scaling: fixed pairs per GPU) and every step ends with the path's ONE collective, the all-gather of the
+pairwise predictions (dust3r_amd/parallel.py), issued asynchronously so that it overlaps the next step's compute.
+
+Usage: python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+Prints ONE JSON line on rank 0. Extra objects: "roofline" (dominant kernel, live HIP-event timing), "cpu_baseline"
+(the CPU oracle timed on this host's cores on a bounded sample, rank 0 at N=1 only), "aligner", "kernels".
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MODEL = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
+H, W = 384, 512
+GFLOP_PER_PAIR = 1856.8          # 2*MAC over every GEMM / conv / attention contraction of one pair
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0            # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_model(precision, device):
+    from dust3r_amd.model import AsymmetricCroCo3DStereo
+    from dust3r_amd.synthetic import MODEL_CONFIGS, OUT_GAIN, synthetic_state_dict
+    m = AsymmetricCroCo3DStereo(precision=precision, landscape_only=False, **MODEL_CONFIGS[MODEL])
+    t = time.time()
+    # weights are generated in HBM and packed by the engine's device kernels: no host copy of the 0.65 G parameters
+    m.load_state_dict(synthetic_state_dict({k: torch.empty(v, device='meta') for k, v in m._spec.items()}, 0, OUT_GAIN[MODEL], device=device))
+    t1 = time.time()
+    m.to(device)
+    log(f'[bench] synthetic weights {t1 - t:.1f}s, pack+upload {time.time() - t1:.1f}s, device bytes {m.device_bytes() / 2**30:.2f} GiB')
+    return m
+
+
+def read_profile(model):
+    from dust3r_amd._lib import lib
+    out = {}
+    for kind, name in enumerate(('gemm', 'conv', 'attention', 'other')):
+        n, ms, work = C.c_int(), C.c_double(), C.c_double()
+        rc = lib.d3r_model_profile_read(model._engine, kind, C.byref(n), C.byref(ms), C.byref(work))
+        if rc != 0:
+            return None
+        out[name] = dict(launches=n.value, ms=ms.value, gflop=work.value / 1e9)
+    return out
+
+
+def bench_aligner(device, niter=300, n_views=20):
+    """configs[3]: PointCloudOptimizer, 20 synthetic views -> 190 edges, 300 iterations, cosine schedule, one GPU."""
+    from dust3r_amd.cloud_opt import global_aligner
+    from dust3r_amd.cloud_opt.base_opt import global_alignment_loop
+    from dust3r_amd.synthetic import synthetic_scene
+    out, init, gt = synthetic_scene(n_views, H, W, seed=0, symmetrize=False, device=device)
+    scene = global_aligner(out, device, verbose=False)
+    scene.load_state_dict(init)
+    E, n, A = scene.n_edges, scene.n_imgs, H * W
+    global_alignment_loop(scene, niter=5)                      # warm-up (also builds the engine)
+    scene.load_state_dict(init)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    loss = global_alignment_loop(scene, niter=niter, schedule='cosine', lr=0.01)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    bytes_iter = E * A * 32 + n * A * 4 * 6                    # preds + weights once, depth param/Adam r/w
+    gbs = bytes_iter * niter / (ms * 1e-3) / 1e9
+    res = dict(metric='global_aligner_iters_per_sec', value=niter / (ms * 1e-3), unit='iters/s', n_views=n, n_edges=E, niter=niter,
+               ms_total=ms, final_loss=loss,
+               roofline=dict(bound='hbm', kernel='aligner_main_kernel', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS,
+                             bytes_per_iter=bytes_iter, traffic=None))
+    return res, (out, init)
+
+
+def cpu_baseline_forward(budget_s=25.0):
+    """The CPU oracle (fp32 PyTorch restatement of the reference path, oracle/dust3r_ref.py) on this host's cores,
+    on a bounded sample of the same workload: single 512x384 pairs of the same model, until ~budget_s of CPU time."""
+    from oracle.dust3r_ref import build_ref_model_fast
+    from dust3r_amd.synthetic import synthetic_views
+    torch.set_num_threads(os.cpu_count() or 1)
+    t = time.time()
+    oracle = build_ref_model_fast(MODEL)
+    log(f'[bench] cpu oracle built in {time.time() - t:.1f}s, threads {torch.get_num_threads()}')
+    v1, v2 = synthetic_views(1, H, W, seed=0)
+    times = []
+    t_all = time.time()
+    with torch.no_grad():
+        while len(times) < 3 and (time.time() - t_all) < budget_s:
+            t = time.time()
+            oracle(v1, v2)
+            times.append(time.time() - t)
+    best = min(times)
+    return dict(value=1.0 / best, unit='pairs/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{len(times)} x 1 pair 512x384 {MODEL} fp32 (oracle/dust3r_ref.py), best of {len(times)}: {best:.2f} s/pair')
+
+
+def cpu_baseline_aligner(scene_io, niter=2):
+    from oracle.aligner_ref import AlignerRef
+    out, init = scene_io
+    out = {k: ({kk: (vv.cpu() if isinstance(vv, torch.Tensor) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v)
+           for k, v in out.items()}
+    ref = AlignerRef(out).load_state(init)
+    t = time.time()
+    ref.run(niter=niter)
+    dt = (time.time() - t) / niter
+    return dict(value=1.0 / dt, unit='iters/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{niter} iterations of the 20-view / 190-edge scene (oracle/aligner_ref.py, torch autograd + Adam): {dt:.2f} s/iter')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--pairs', type=int, default=32, help='image pairs per GPU per step (configs[1]: 32)')
+    ap.add_argument('--precision', default=os.environ.get('DUST3R_AMD_PRECISION', 'bf16'))
+    ap.add_argument('--no-aligner', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    assert world == args.gpus or world == 1 and args.gpus == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    from dust3r_amd import _lib
+    from dust3r_amd.parallel import all_gather_packed, pack_predictions
+    from dust3r_amd.synthetic import synthetic_views
+    _lib.require_device()
+    model = build_model(args.precision, device)
+    B = args.pairs
+    v1, v2 = synthetic_views(B, H, W, seed=rank, device=device)      # resident in HBM before the timed region
+
+    gather_stream = torch.cuda.Stream(device=device) if world > 1 else None
+    gather_out = [torch.empty((world * B, H, W, 8), dtype=torch.float32, device=device) for _ in range(2)] if world > 1 else None
+    pending = []
+
+    def step(i):
+        r1, r2 = model(v1, v2)
+        if world > 1:
+            packed = pack_predictions(r1, r2)
+            ev = torch.cuda.Event()
+            ev.record()
+            gather_stream.wait_event(ev)
+            with torch.cuda.stream(gather_stream):
+                packed.record_stream(gather_stream)
+                _, work = all_gather_packed(packed, async_op=True, out=gather_out[i & 1])
+            pending.append(work)
+            if len(pending) > 1:                                        # at most one all-gather in flight behind the compute
+                pending.pop(0).wait()
+        return r1, r2
+
+    def drain():
+        while pending:
+            pending.pop(0).wait()
+        if gather_stream is not None:
+            torch.cuda.current_stream().wait_stream(gather_stream)
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        pairs_total = world * B * args.steps
+        value = pairs_total / dt
+        result = {
+            'metric': 'image_pairs_per_sec_forward_512x384', 'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': f'{MODEL} AsymmetricCroCo3DStereo.forward, {B} synthetic 512x384 pairs per GPU per step (BASELINE configs[1]), '
+                                   'random-init weights, inputs resident in HBM' + ('; pairs sharded over ranks + one all-gather of the pairwise predictions per step' if world > 1 else ''),
+                       'pairs_per_gpu': B, 'global_pairs_per_step': world * B, 'parallelism': f'pair-sharded dp{world}'},
+            'forward_tflops_per_gpu': value / world * GFLOP_PER_PAIR / 1e3,
+            'forward_frac_of_bf16_mfma_peak': value / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS,
+        }
+        log(f'[bench] {value:.2f} pairs/s on {world} GPU(s), {dt / args.steps * 1e3:.1f} ms/step')
+
+    # ---- live per-kernel timing (HIP events on the launch stream, outside the timed region) ---------------------
+    if rank == 0 and not args.no_profile:
+        from dust3r_amd._lib import lib
+        lib.d3r_model_set_option(model._engine, 1, 1)
+        model(v1, v2)
+        torch.cuda.synchronize()
+        prof = read_profile(model)
+        lib.d3r_model_set_option(model._engine, 1, 0)
+        if prof:
+            g = prof['gemm']
+            cv = prof['conv']
+            launches = g['launches'] + cv['launches']
+            ms = g['ms'] + cv['ms']
+            gflop = g['gflop'] + cv['gflop']
+            ach = gflop / ms                                     # GFLOP / ms == TFLOP/s
+            result['roofline'] = {
+                'bound': 'mfma', 'kernel': f'gemm_kernel<{args.precision}> (nn.Linear GEMMs + implicit-GEMM convolutions: one kernel)',
+                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
+                'launches_per_step': launches, 'avg_launch_ms': ms / launches, 'gflop_per_launch': gflop / launches,
+                'share_of_step_time': ms / sum(v['ms'] for v in prof.values())}
+            result['kernels'] = {k: dict(v, tflops=(v['gflop'] / v['ms'] if v['ms'] > 0 else 0.0)) for k, v in prof.items()}
+            log('[bench] per-class: ' + ', '.join(f"{k} {v['ms']:.1f} ms / {v['launches']} launches / {v['gflop'] / max(v['ms'], 1e-9):.0f} TF/s" for k, v in prof.items()))
+
+    if world > 1:
+        dist.barrier()
+    # ---- second half of the metric + CPU baselines: rank 0 at N = 1 only ----------------------------------------
+    if rank == 0 and world == 1:
+        del v1, v2
+        scene_io = None
+        if not args.no_aligner:
+            try:
+                result['aligner'], scene_io = bench_aligner(device)
+                log(f"[bench] aligner {result['aligner']['value']:.1f} iters/s, {result['aligner']['roofline']['achieved']:.0f} GB/s algorithmic")
+            except Exception as e:  # keep the forward line even if the second leg fails
+                result['aligner'] = {'error': repr(e)}
+        if not args.no_cpu_baseline:
+            try:
+                result['cpu_baseline'] = cpu_baseline_forward()
+                result['cpu_baseline']['gpu_over_cpu'] = result['value'] / result['cpu_baseline']['value']
+                if scene_io is not None:
+                    cb = cpu_baseline_aligner(scene_io)
+                    cb['gpu_over_cpu'] = result['aligner']['value'] / cb['value']
+                    result['aligner']['cpu_baseline'] = cb
+            except Exception as e:
+                result['cpu_baseline'] = {'error': repr(e)}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -49,10 +49,13 @@ def _load():
         'd3r_model_create': (i, [C.POINTER(vp), C.POINTER(ModelConfig)]),
         'd3r_model_destroy': (i, [vp]),
         'd3r_model_load_tensor': (i, [vp, C.c_char_p, fp, i, C.POINTER(C.c_int64)]),
+        'd3r_model_load_tensor_device': (i, [vp, C.c_char_p, fp, i, C.POINTER(C.c_int64)]),
         'd3r_model_missing': (i, [vp]),
         'd3r_model_forward': (i, [vp, fp, fp, i, i, i, fp, fp, fp, fp, vp]),
         'd3r_model_device_bytes': (C.c_size_t, [vp]),
         'd3r_model_debug_read': (i, [vp, i, fp, C.c_size_t, vp]),
+        'd3r_model_set_option': (i, [vp, i, i]),
+        'd3r_model_profile_read': (i, [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         'd3r_aligner_create': (i, [C.POINTER(vp), i, i, ip, ip, ip, ip, i, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, f, f, f,
                                    i, i, i, i, i]),
         'd3r_aligner_destroy': (i, [vp]),

@@ -307,4 +307,53 @@ hipError_t launch_linear_head_post(const float* feat, float* pts, float* conf, i
 
 hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s); }
 
+// ---- weight packing (load time): fp32 checkpoint tensor (PyTorch layout, device) -> engine layout -------------
+// One thread per SOURCE element; the destination buffers are zero-initialised at allocation, so the padding
+// (rows up to n_pad, channels up to cin_pad / cout_pad) stays zero.
+template <int DT> __global__ __launch_bounds__(256) void pack_weight_kernel(PackParams p) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.numel) return;
+    const float v = p.src[i];
+    size_t d;
+    if (p.kind == PACK_MAT) {                    // [rows][cols] -> [row_off + r][c]
+        const size_t r = i / p.cols, c = i - r * p.cols;
+        d = (r + p.row_off) * (size_t)p.dst_cols + c;
+    } else if (p.kind == PACK_CONV) {            // [Cout][Cin][k][k] -> [co][(ky*k+kx)*cin_pad + ci]
+        const int kk = p.ksize * p.ksize;
+        const size_t co = i / ((size_t)p.cin * kk);
+        const int rem = (int)(i - co * (size_t)p.cin * kk);
+        const int ci = rem / kk, t = rem - ci * kk;
+        d = co * (size_t)p.dst_cols + (size_t)t * p.cin_pad + ci;
+    } else {                                     // PACK_CONVT: [Cin][Cout][k][k] -> [(ky*k+kx)*cout_pad + co][ci]
+        const int kk = p.ksize * p.ksize;
+        const size_t ci = i / ((size_t)p.cols * kk);
+        const int rem = (int)(i - ci * (size_t)p.cols * kk);
+        const int co = rem / kk, t = rem - co * kk;
+        d = ((size_t)t * p.cout_pad + co) * (size_t)p.dst_cols + ci;
+    }
+    store1<DT>(p.dst, d, v);
+}
+hipError_t launch_pack_weight(int dt, const PackParams& p, hipStream_t s) {
+    if (p.numel == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((p.numel + 255) / 256);
+    switch (dt) {
+        case D3R_BF16: hipLaunchKernelGGL(pack_weight_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, p); break;
+        case D3R_F16: hipLaunchKernelGGL(pack_weight_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, p); break;
+        case D3R_F32: hipLaunchKernelGGL(pack_weight_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+// ConvTranspose bias [Cout] -> fp32 [k*k][cout_pad]
+__global__ __launch_bounds__(256) void pack_convt_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cout_pad, int taps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cout * taps) return;
+    const int t = i / cout, co = i - t * cout;
+    dst[(size_t)t * cout_pad + co] = src[co];
+}
+hipError_t launch_pack_convt_bias(const float* src, float* dst, int cout, int cout_pad, int taps, hipStream_t s) {
+    hipLaunchKernelGGL(pack_convt_bias_kernel, dim3((cout * taps + 255) / 256), dim3(256), 0, s, src, dst, cout, cout_pad, taps);
+    return hipGetLastError();
+}
+
 }  // namespace d3r

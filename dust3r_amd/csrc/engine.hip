@@ -27,32 +27,6 @@ namespace {
 
 inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 
-// ---- host-side dtype conversion for weight packing ---------------------------------------------------
-inline uint16_t f2bf(float f) {  // round to nearest even
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-inline uint16_t f2h(float f) {
-    _Float16 h = (_Float16)f;
-    uint16_t u;
-    memcpy(&u, &h, 2);
-    return u;
-}
-struct HostPack {  // a [rows][cols] matrix in the engine dtype, zero initialised
-    int dt;
-    size_t rows, cols;
-    std::vector<uint8_t> bytes;
-    HostPack(int dt_, size_t r, size_t c) : dt(dt_), rows(r), cols(c), bytes(r * c * dt_bytes(dt_), 0) {}
-    inline void set(size_t r, size_t c, float v) {
-        const size_t i = r * cols + c;
-        if (dt == D3R_F32) reinterpret_cast<float*>(bytes.data())[i] = v;
-        else reinterpret_cast<uint16_t*>(bytes.data())[i] = dt == D3R_BF16 ? f2bf(v) : f2h(v);
-    }
-};
-
 enum PackKind { PK_VEC, PK_MAT, PK_CONV, PK_CONVT, PK_CONVT_BIAS, PK_IGNORE };
 
 struct Slot {
@@ -102,8 +76,14 @@ struct d3r_model {
     float* rope_table = nullptr;
     void* zero_page = nullptr;
     void* ws = nullptr; size_t ws_bytes = 0;
+    void* stage = nullptr; size_t stage_bytes = 0;   // load-time staging of host tensors
     // last forward (debug hook)
     const void* last_encn = nullptr; size_t last_encn_elems = 0;
+    // optional per-launch HIP-event timing (d3r_model_set_option(D3R_MODEL_OPT_PROFILE)); off in timed runs
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    struct ProfRec { int kind; double work; };
+    std::vector<ProfRec> prof_rec;
 
     void* dalloc(size_t bytes) {
         void* p = nullptr;
@@ -258,54 +238,37 @@ bool build_slots(d3r_model* m) {
     return true;
 }
 
+// `data` is a DEVICE fp32 tensor in the checkpoint's (PyTorch) layout; the conversion to the engine's dtype and
+// layout runs on the GPU (elementwise.hip: pack_weight_kernel), ordered on the default stream.
 int pack_slot(d3r_model* m, Slot& s, const float* data, int ndim, const int64_t* shape) {
     size_t numel = 1;
     for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
     const size_t eb = dt_bytes(m->dt);
+    PackParams pp;
+    pp.src = data; pp.numel = numel; pp.dst = s.dst; pp.dst_cols = s.dst_cols;
     switch (s.kind) {
         case PK_IGNORE: return D3R_OK;
         case PK_VEC:
             if (numel != (size_t)s.rows) return D3R_ERR_SHAPE;
-            return hipMemcpy(s.dst, data, numel * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
-        case PK_MAT: {
+            return hipMemcpyAsync(s.dst, data, numel * sizeof(float), hipMemcpyDeviceToDevice, nullptr) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
+        case PK_MAT:
             if (ndim < 2 || shape[0] != s.rows || numel != (size_t)s.rows * s.cols) return D3R_ERR_SHAPE;
-            HostPack hp(m->dt, s.rows, s.dst_cols);
-            for (int r = 0; r < s.rows; ++r)
-                for (int c = 0; c < s.cols; ++c) hp.set(r, c, data[(size_t)r * s.cols + c]);
-            char* d = (char*)s.dst + (size_t)s.row_off * s.dst_cols * eb;
-            return hipMemcpy(d, hp.bytes.data(), hp.bytes.size(), hipMemcpyHostToDevice) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
-        }
-        case PK_CONV: {
-            const int k = s.ksize;
-            if (ndim != 4 || shape[0] != s.rows || shape[1] != s.cin || shape[2] != k || shape[3] != k) return D3R_ERR_SHAPE;
-            HostPack hp(m->dt, s.rows, s.dst_cols);
-            for (int co = 0; co < s.rows; ++co)
-                for (int ci = 0; ci < s.cin; ++ci)
-                    for (int ky = 0; ky < k; ++ky)
-                        for (int kx = 0; kx < k; ++kx)
-                            hp.set(co, (size_t)(ky * k + kx) * s.cin_pad + ci, data[(((size_t)co * s.cin + ci) * k + ky) * k + kx]);
-            return hipMemcpy(s.dst, hp.bytes.data(), hp.bytes.size(), hipMemcpyHostToDevice) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
-        }
-        case PK_CONVT: {
-            const int k = s.ksize, Cin = s.rows, Cout = s.cols;
-            if (ndim != 4 || shape[0] != Cin || shape[1] != Cout || shape[2] != k || shape[3] != k) return D3R_ERR_SHAPE;
-            HostPack hp(m->dt, (size_t)k * k * s.cout_pad, s.dst_cols);
-            for (int ci = 0; ci < Cin; ++ci)
-                for (int co = 0; co < Cout; ++co)
-                    for (int ky = 0; ky < k; ++ky)
-                        for (int kx = 0; kx < k; ++kx)
-                            hp.set((size_t)(ky * k + kx) * s.cout_pad + co, ci, data[(((size_t)ci * Cout + co) * k + ky) * k + kx]);
-            return hipMemcpy(s.dst, hp.bytes.data(), hp.bytes.size(), hipMemcpyHostToDevice) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
-        }
-        case PK_CONVT_BIAS: {
+            pp.kind = PACK_MAT; pp.cols = s.cols; pp.row_off = s.row_off;
+            break;
+        case PK_CONV:
+            if (ndim != 4 || shape[0] != s.rows || shape[1] != s.cin || shape[2] != s.ksize || shape[3] != s.ksize) return D3R_ERR_SHAPE;
+            pp.kind = PACK_CONV; pp.cin = s.cin; pp.cin_pad = s.cin_pad; pp.ksize = s.ksize;
+            break;
+        case PK_CONVT:
+            if (ndim != 4 || shape[0] != s.rows || shape[1] != s.cols || shape[2] != s.ksize || shape[3] != s.ksize) return D3R_ERR_SHAPE;
+            pp.kind = PACK_CONVT; pp.cols = s.cols; pp.ksize = s.ksize; pp.cout_pad = s.cout_pad;
+            break;
+        case PK_CONVT_BIAS:
             if (numel != (size_t)s.rows) return D3R_ERR_SHAPE;
-            std::vector<float> b((size_t)s.ksize * s.ksize * s.cout_pad, 0.f);
-            for (int t = 0; t < s.ksize * s.ksize; ++t)
-                for (int co = 0; co < s.rows; ++co) b[(size_t)t * s.cout_pad + co] = data[co];
-            return hipMemcpy(s.dst, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
-        }
+            return launch_pack_convt_bias(data, (float*)s.dst, s.rows, s.cout_pad, s.ksize * s.ksize, nullptr) == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
     }
-    return D3R_ERR_INVALID;
+    (void)eb;
+    return launch_pack_weight(m->dt, pp, nullptr) == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------------------
@@ -314,7 +277,21 @@ struct Ctx {
     hipStream_t st;
     int rc = D3R_OK;
     void chk(hipError_t e) { if (e != hipSuccess && rc == D3R_OK) rc = 1000 + (int)e; }
+    // profiling: one event BEFORE every launch; a launch's duration is event[i+1] - event[i]
+    void mark(int kind, double work) {
+        if (!m->prof_on) return;
+        const size_t i = m->prof_rec.size();
+        if (i >= m->prof_ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            m->prof_ev.push_back(e);
+        }
+        (void)hipEventRecord(m->prof_ev[i], st);
+        m->prof_rec.push_back({kind, work});
+    }
 };
+enum { PRF_GEMM = 0, PRF_CONV = 1, PRF_ATTN = 2, PRF_OTHER = 3, PRF_END = 4 };
+#define D3R_OTHER(call) do { c.mark(PRF_OTHER, 0.0); c.chk(call); } while (0)
 
 void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi, void* out, int ldo, const void* res1 = nullptr,
                  void* out2 = nullptr, int ldo2 = 0, int n_store = -1, int flags = 0) {
@@ -322,6 +299,7 @@ void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi,
     p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad;
     p.n_store = n_store >= 0 ? n_store : L.N;
     p.epi = epi; p.out = out; p.ldo = ldo; p.res1 = res1; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo2; p.flags = flags;
+    c.mark(PRF_GEMM, 2.0 * M * (double)L.N * L.K);
     c.chk(launch_gemm(c.m->dt, p, c.st));
 }
 
@@ -332,6 +310,7 @@ void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_
     p.epi = EPI_HEADS; p.head_c = head_c;
     for (int i = 0; i < nreg; ++i) { p.head_kind[i] = kinds[i]; p.head_dst[i] = dsts[i]; }
     p.heads = heads; p.ntok = ntok; p.tok_w = tok_w; p.ldv = ldv; p.rope_table = c.m->rope_table;
+    c.mark(PRF_GEMM, 2.0 * M * (double)L.N * L.K);
     c.chk(launch_gemm(c.m->dt, p, c.st));
 }
 
@@ -344,6 +323,7 @@ void conv(Ctx& c, const void* in, int B, int Hin, int Win, int cstride, const Co
     p.M = B * p.Hout * p.Wout; p.K = w.K; p.n_pad = w.n_pad; p.n_store = n_store >= 0 ? n_store : w.Cout;
     p.zero_page = c.m->zero_page;
     p.epi = EPI_T; p.flags = flags; p.out = out; p.ldo = ldo; p.res1 = res1; p.res2 = res2; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo;
+    c.mark(PRF_CONV, 2.0 * p.M * (double)w.Cout * w.k * w.k * w.Cin);
     c.chk(launch_gemm(c.m->dt, p, c.st));
 }
 
@@ -393,13 +373,14 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
 extern "C" int d3r_model_destroy(d3r_model* m) {
     if (!m) return D3R_OK;
     for (void* p : m->allocs) (void)hipFree(p);
+    for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     if (m->ws) (void)hipFree(m->ws);
+    if (m->stage) (void)hipFree(m->stage);
     delete m;
     return D3R_OK;
 }
 
-extern "C" int d3r_model_load_tensor(d3r_model* m, const char* key, const float* data, int ndim, const int64_t* shape) {
-    if (!m || !key || !data) return D3R_ERR_INVALID;
+static int load_tensor_dev(d3r_model* m, const char* key, const float* data_dev, int ndim, const int64_t* shape) {
     auto it = m->slots.find(key);
     if (it == m->slots.end()) {
         const std::string k(key);
@@ -407,19 +388,43 @@ extern "C" int d3r_model_load_tensor(d3r_model* m, const char* key, const float*
         return D3R_ERR_UNKNOWN_KEY;
     }
     Slot& s = it->second;
-    int rc = pack_slot(m, s, data, ndim, shape);
+    int rc = pack_slot(m, s, data_dev, ndim, shape);
     if (rc != D3R_OK) return rc;
     s.loaded = true;
     if (std::string(key).rfind("dec_blocks2.", 0) == 0) s.explicit_loaded = true;
     if (!s.mirror.empty()) {
         Slot& t = m->slots[s.mirror];
         if (!t.explicit_loaded) {
-            rc = pack_slot(m, t, data, ndim, shape);
+            rc = pack_slot(m, t, data_dev, ndim, shape);
             if (rc != D3R_OK) return rc;
             t.loaded = true;
         }
     }
     return D3R_OK;
+}
+
+extern "C" int d3r_model_load_tensor_device(d3r_model* m, const char* key, const float* data_dev, int ndim, const int64_t* shape) {
+    if (!m || !key || !data_dev || ndim < 0 || ndim > 8) return D3R_ERR_INVALID;
+    return load_tensor_dev(m, key, data_dev, ndim, shape);
+}
+
+extern "C" int d3r_model_load_tensor(d3r_model* m, const char* key, const float* data, int ndim, const int64_t* shape) {
+    if (!m || !key || !data || ndim < 0 || ndim > 8) return D3R_ERR_INVALID;
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    const size_t bytes = (numel ? numel : 1) * sizeof(float);
+    if (bytes > m->stage_bytes) {                 // host tensors are staged through one device buffer, packed on the GPU
+        (void)hipDeviceSynchronize();
+        if (m->stage) (void)hipFree(m->stage);
+        m->stage = nullptr; m->stage_bytes = 0;
+        if (hipMalloc(&m->stage, bytes) != hipSuccess) return D3R_ERR_ALLOC;
+        m->stage_bytes = bytes;
+    }
+    // synchronous copy on the default stream: ordered after the previous tensor's pack kernels
+    if (hipMemcpy(m->stage, data, numel * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return D3R_ERR_ALLOC;
+    const int rc = load_tensor_dev(m, key, (const float*)m->stage, ndim, shape);
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return D3R_ERR_LAUNCH;   // the staging buffer is reused by the next call
+    return rc;
 }
 
 extern "C" int d3r_model_missing(const d3r_model* m) {
@@ -439,6 +444,30 @@ extern "C" int d3r_model_debug_read(d3r_model* m, int what, float* out, size_t m
     return D3R_ERR_INVALID;  // 16-bit modes: read through the Python side (torch view of the raw buffer is not exposed)
 }
 
+extern "C" int d3r_model_set_option(d3r_model* m, int option, int value) {
+    if (!m) return D3R_ERR_INVALID;
+    if (option == D3R_MODEL_OPT_PROFILE) { m->prof_on = value != 0; m->prof_rec.clear(); return D3R_OK; }
+    return D3R_ERR_INVALID;
+}
+
+// Per-class totals of the LAST forward run with profiling on: kind 0 GEMM (linear), 1 implicit-GEMM conv (same
+// kernel), 2 attention, 3 everything else. Synchronises on the recorded events.
+extern "C" int d3r_model_profile_read(d3r_model* m, int kind, int* launches, double* ms, double* work) {
+    if (!m || kind < 0 || kind > 3 || m->prof_rec.size() < 2) return D3R_ERR_STATE;
+    int n = 0; double t = 0.0, w = 0.0;
+    if (hipEventSynchronize(m->prof_ev[m->prof_rec.size() - 1]) != hipSuccess) return D3R_ERR_LAUNCH;
+    for (size_t i = 0; i + 1 < m->prof_rec.size(); ++i) {
+        if (m->prof_rec[i].kind != kind) continue;
+        float dt = 0.f;
+        if (hipEventElapsedTime(&dt, m->prof_ev[i], m->prof_ev[i + 1]) != hipSuccess) return D3R_ERR_LAUNCH;
+        ++n; t += dt; w += m->prof_rec[i].work;
+    }
+    if (launches) *launches = n;
+    if (ms) *ms = t;
+    if (work) *work = w;
+    return D3R_OK;
+}
+
 // ---- the forward ---------------------------------------------------------------------------------------------
 namespace {
 
@@ -449,6 +478,7 @@ void self_attention(Ctx& c, const void* xn, const Lin& qkv, int M, int C, int he
     gemm_heads(c, xn, C, qkv, M, C, 3, kinds, dsts, heads, ntok, tok_w, ldv);
     AttnParams a;
     a.q = q; a.k = k; a.vt = vt; a.out = ao; a.B = nimg; a.H = heads; a.Nq = ntok; a.Nk = ntok; a.ldv = ldv; a.scale = 0.125f;
+    c.mark(PRF_ATTN, 4.0 * nimg * heads * (double)ntok * ntok * 64);
     c.chk(launch_attention(c.m->dt, a, c.st));
 }
 
@@ -471,6 +501,8 @@ void run_dpt(Ctx& c, const DptHead& D, Arena ar, const void* const hooks[4], con
             p.act = t1; p.lda = D.cstride[i]; p.wgt = D.convt[i].w; p.bias = D.convt[i].b; p.M = B * N; p.K = D.convt[i].K;
             p.n_pad = D.convt[i].n_pad; p.n_store = D.convt[i].N; p.epi = EPI_CONVT; p.ksize = D.convt_k[i]; p.ct_cout = D.convt_coutp[i];
             p.Hin = th; p.Win = tw; p.out = cmap[i]; p.ldo = D.cstride[i];
+            const int ldi[2] = {96, 192};
+            c.mark(PRF_CONV, 2.0 * p.M * (double)(D.convt_k[i] * D.convt_k[i] * ldi[i]) * ldi[i]);
             c.chk(launch_gemm(m->dt, p, c.st));
         } else if (i == 3) {
             conv(c, t1, B, th, tw, D.cstride[3], D.act3conv, 2, 1, cmap[3], D.cstride[3], 0);
@@ -505,7 +537,7 @@ void run_dpt(Ctx& c, const DptHead& D, Arena ar, const void* const hooks[4], con
         gemm_linear(c, o, 256, R.outc, B * H * W, EPI_T, tA, 256);
         const int Ho = lvl == 3 ? Hl[2] : 2 * H, Wo = lvl == 3 ? Wl[2] : 2 * W;  // dpt_head.py:57 crops refinenet4 to layer 3's size
         void* np = ar.take((size_t)B * Ho * Wo * 256 * eb);
-        c.chk(launch_upsample2x(m->dt, tA, np, nullptr, B, H, W, 256, 256, Ho, Wo, c.st));
+        D3R_OTHER(launch_upsample2x(m->dt, tA, np, nullptr, B, H, W, 256, 256, Ho, Wo, c.st));
         path = np;
     }
     // head: 3x3 256->128, x2, 3x3 128->128 + ReLU, 1x1 128->4 + postprocess
@@ -513,10 +545,10 @@ void run_dpt(Ctx& c, const DptHead& D, Arena ar, const void* const hooks[4], con
     void* h0 = ar.take((size_t)B * H8 * W8 * 128 * eb);
     conv(c, path, B, H8, W8, 256, D.head0, 1, 1, h0, 128, 0);
     void* h1 = ar.take((size_t)B * 4 * H8 * W8 * 128 * eb);
-    c.chk(launch_upsample2x(m->dt, h0, h1, nullptr, B, H8, W8, 128, 128, 2 * H8, 2 * W8, c.st));
+    D3R_OTHER(launch_upsample2x(m->dt, h0, h1, nullptr, B, H8, W8, 128, 128, 2 * H8, 2 * W8, c.st));
     void* h2 = ar.take((size_t)B * 4 * H8 * W8 * 128 * eb);
     conv(c, h1, B, 2 * H8, 2 * W8, 128, D.head2, 1, 1, h2, 128, GF_RELU);
-    c.chk(launch_head_final(m->dt, h2, 128, D.head4_w, D.head4_b, pts, conf, (size_t)B * 4 * H8 * W8, c.st));
+    D3R_OTHER(launch_head_final(m->dt, h2, 128, D.head4_w, D.head4_b, pts, conf, (size_t)B * 4 * H8 * W8, c.st));
     if (ar.base && ar.off > ar.cap) c.rc = D3R_ERR_ALLOC;
 }
 
@@ -549,22 +581,22 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
     const size_t common_end = ar.off;
 
     if (!dry) {
-        if (ldv != N) c.chk(hipMemsetAsync(vt, 0, (size_t)2 * B * He * 64 * ldv * eb, st));
+        if (ldv != N) D3R_OTHER(hipMemsetAsync(vt, 0, (size_t)2 * B * He * 64 * ldv * eb, st));
         // ---- encoder: both image batches in one pass (model.py:142-151) ----------------------------------
         const size_t pk = 3 * (size_t)ps * ps;
-        c.chk(launch_patchify(m->dt, img1, hb, B, H, W, ps, st));
-        c.chk(launch_patchify(m->dt, img2, (char*)hb + (size_t)M1 * pk * eb, B, H, W, ps, st));
+        D3R_OTHER(launch_patchify(m->dt, img1, hb, B, H, W, ps, st));
+        D3R_OTHER(launch_patchify(m->dt, img2, (char*)hb + (size_t)M1 * pk * eb, B, H, W, ps, st));
         gemm_linear(c, hb, (int)pk, m->patch, M2, EPI_F32, x, Ce);
         for (int l = 0; l < cf.enc_depth; ++l) {
             const EncBlk& b = m->enc[l];
-            c.chk(launch_layernorm(m->dt, x, b.n1.g, b.n1.b, xn, M2, Ce, 1e-6f, st));
+            D3R_OTHER(launch_layernorm(m->dt, x, b.n1.g, b.n1.b, xn, M2, Ce, 1e-6f, st));
             self_attention(c, xn, b.qkv, M2, Ce, He, 2 * B, N, tw, ldv, q, k, vt, ao);
             gemm_linear(c, ao, Ce, b.proj, M2, EPI_F32, x, Ce, x);
-            c.chk(launch_layernorm(m->dt, x, b.n2.g, b.n2.b, xn, M2, Ce, 1e-6f, st));
+            D3R_OTHER(launch_layernorm(m->dt, x, b.n2.g, b.n2.b, xn, M2, Ce, 1e-6f, st));
             gemm_linear(c, xn, Ce, b.fc1, M2, EPI_GELU, hb, 4 * Ce);
             gemm_linear(c, hb, 4 * Ce, b.fc2, M2, EPI_F32, x, Ce, x);
         }
-        c.chk(launch_layernorm(m->dt, x, m->enc_norm.g, m->enc_norm.b, encn, M2, Ce, 1e-6f, st));
+        D3R_OTHER(launch_layernorm(m->dt, x, m->enc_norm.g, m->enc_norm.b, encn, M2, Ce, 1e-6f, st));
         m->last_encn = encn; m->last_encn_elems = (size_t)M2 * Ce;
         // ---- decoder (model.py:172-191): side s reads the PREVIOUS layer's (f_s, f_other) ---------------------
         gemm_linear(c, encn, Ce, m->dec_embed, M2, EPI_F32, f[0], Cd);
@@ -576,12 +608,12 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
                 const float* xo = f[cur] + (size_t)s * M1 * Cd;         // own stream (old)
                 const float* yo = f[cur] + (size_t)(1 - s) * M1 * Cd;   // other view (old)
                 float* xw = f[cur ^ 1] + (size_t)s * M1 * Cd;           // own stream (new)
-                c.chk(launch_layernorm(m->dt, xo, b.n1.g, b.n1.b, xn, M1, Cd, 1e-6f, st));
+                D3R_OTHER(launch_layernorm(m->dt, xo, b.n1.g, b.n1.b, xn, M1, Cd, 1e-6f, st));
                 self_attention(c, xn, b.qkv, M1, Cd, Hd, B, N, tw, ldv, q, k, vt, ao);
                 gemm_linear(c, ao, Cd, b.proj, M1, EPI_F32, xw, Cd, xo);
                 // cross attention: q from norm2(x), k/v from norm_y(y)
-                c.chk(launch_layernorm(m->dt, yo, b.ny.g, b.ny.b, yn, M1, Cd, 1e-6f, st));
-                c.chk(launch_layernorm(m->dt, xw, b.n2.g, b.n2.b, xn, M1, Cd, 1e-6f, st));
+                D3R_OTHER(launch_layernorm(m->dt, yo, b.ny.g, b.ny.b, yn, M1, Cd, 1e-6f, st));
+                D3R_OTHER(launch_layernorm(m->dt, xw, b.n2.g, b.n2.b, xn, M1, Cd, 1e-6f, st));
                 {
                     const int kq[1] = {HEAD_ROPE};
                     void* dq[1] = {q};
@@ -591,10 +623,11 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
                     gemm_heads(c, yn, Cd, b.ckv, M1, Cd, 2, kkv, dkv, Hd, N, tw, ldv);
                     AttnParams a;
                     a.q = q; a.k = k; a.vt = vt; a.out = ao; a.B = B; a.H = Hd; a.Nq = N; a.Nk = N; a.ldv = ldv; a.scale = 0.125f;
+                    c.mark(PRF_ATTN, 4.0 * B * Hd * (double)N * N * 64);
                     c.chk(launch_attention(m->dt, a, st));
                 }
                 gemm_linear(c, ao, Cd, b.cproj, M1, EPI_F32, xw, Cd, xw);
-                c.chk(launch_layernorm(m->dt, xw, b.n3.g, b.n3.b, xn, M1, Cd, 1e-6f, st));
+                D3R_OTHER(launch_layernorm(m->dt, xw, b.n3.g, b.n3.b, xn, M1, Cd, 1e-6f, st));
                 gemm_linear(c, xn, Cd, b.fc1, M1, EPI_GELU, hb, 4 * Cd);
                 const int layer_no = l + 1;
                 void* hcopy = (cf.head_type == 1 && (layer_no == hk6 || layer_no == hk9)) ? hook[s][layer_no == hk6 ? 0 : 1] : nullptr;
@@ -603,7 +636,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
             cur ^= 1;
         }
         for (int s = 0; s < 2; ++s)
-            c.chk(launch_layernorm(m->dt, f[cur] + (size_t)s * M1 * Cd, m->dec_norm.g, m->dec_norm.b, hook[s][2], M1, Cd, 1e-6f, st));
+            D3R_OTHER(launch_layernorm(m->dt, f[cur] + (size_t)s * M1 * Cd, m->dec_norm.g, m->dec_norm.b, hook[s][2], M1, Cd, 1e-6f, st));
     }
     // ---- heads -----------------------------------------------------------------------------------------------
     size_t peak = common_end;
@@ -613,7 +646,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
         if (!dry)
             for (int s = 0; s < 2; ++s) {
                 gemm_linear(c, hook[s][2], Cd, m->lin_head[s], M1, EPI_F32, lin_out, 4 * ps * ps);
-                c.chk(launch_linear_head_post(lin_out, pts[s], cnf[s], B, th, tw, ps, st));
+                D3R_OTHER(launch_linear_head_post(lin_out, pts[s], cnf[s], B, th, tw, ps, st));
             }
     } else {
         const int chunk = B < 4 ? B : 4;
@@ -650,6 +683,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
                 }
             }
     }
+    if (!dry) c.mark(PRF_END, 0.0);
     if (rc_out) *rc_out = c.rc;
     return peak + 256;
 }
@@ -672,6 +706,7 @@ extern "C" int d3r_model_forward(d3r_model* m, const float* img1, const float* i
         m->ws_bytes = need;
     }
     int rc = D3R_OK;
+    m->prof_rec.clear();
     forward_impl(m, m->ws, m->ws_bytes, img1, img2, B, H, W, pts1, conf1, pts2, conf2, st, &rc);
     return rc;
 }

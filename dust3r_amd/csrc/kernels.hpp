@@ -71,6 +71,16 @@ hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, co
 hipError_t launch_linear_head_post(const float* feat, float* pts, float* conf, int B, int th, int tw, int ps, hipStream_t s);
 hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 
+// load-time weight packing on the device (fp32 PyTorch-layout source -> engine layout in DT)
+enum { PACK_MAT = 0, PACK_CONV = 1, PACK_CONVT = 2 };
+struct PackParams {
+    const float* src = nullptr; void* dst = nullptr;
+    size_t numel = 0;
+    int kind = PACK_MAT, cols = 0, row_off = 0, dst_cols = 0, cin = 0, cin_pad = 0, ksize = 1, cout_pad = 0;
+};
+hipError_t launch_pack_weight(int dt, const PackParams& p, hipStream_t s);
+hipError_t launch_pack_convt_bias(const float* src, float* dst, int cout, int cout_pad, int taps, hipStream_t s);
+
 // ------------------------------------------------------------------------------ aligner
 struct AlignerDev;  // defined in aligner.hip
 

@@ -136,7 +136,7 @@ class AsymmetricCroCo3DStereo(nn.Module):
         self._cfg = dict(enc_embed_dim=enc_embed_dim, enc_depth=enc_depth, dec_embed_dim=dec_embed_dim, dec_depth=dec_depth,
                          patch_size=patch_size, head_type=head_type)
         self._spec = expected_state(self._cfg)
-        self._weights = OrderedDict()        # fp32 CPU master copy, reference key names
+        self._weights = OrderedDict()        # fp32 master copy (CPU, or GPU if the caller loaded GPU tensors), reference key names
         self._engine = None
         self._engine_device = None
         self._device = torch.device('cpu')
@@ -154,7 +154,7 @@ class AsymmetricCroCo3DStereo(nn.Module):
         unexpected = [k for k in new if k not in self._spec]
         for k, shape in self._spec.items():
             if k in new:
-                t = torch.as_tensor(new[k]).detach().to('cpu', torch.float32).contiguous()
+                t = torch.as_tensor(new[k]).detach().to(torch.float32).contiguous()    # stays where the caller put it
                 if tuple(t.shape) != tuple(shape):
                     raise RuntimeError(f'size mismatch for {k}: checkpoint {tuple(t.shape)} vs model {tuple(shape)}')
                 self._weights[k] = t
@@ -218,10 +218,15 @@ class AsymmetricCroCo3DStereo(nn.Module):
 
     def _upload(self):
         with torch.cuda.device(self._engine_device):
+            torch.cuda.synchronize()
             for key, t in self._weights.items():
-                shape = (C.c_int64 * t.ndim)(*t.shape)
-                check(lib.d3r_model_load_tensor(self._engine, key.encode(), C.c_void_p(t.data_ptr()), t.ndim, shape),
-                      f'load_tensor({key})')
+                shape = (C.c_int64 * max(t.ndim, 1))(*t.shape)
+                if t.is_cuda:       # already in HBM: converted / re-laid-out by the engine's pack kernels in place
+                    assert t.device == self._engine_device, f'{key} lives on {t.device}, engine on {self._engine_device}'
+                    fn = lib.d3r_model_load_tensor_device
+                else:               # host tensor: staged H2D by the engine, then the same pack kernels
+                    fn = lib.d3r_model_load_tensor
+                check(fn(self._engine, key.encode(), C.c_void_p(t.data_ptr()), t.ndim, shape), f'load_tensor({key})')
             torch.cuda.synchronize()
 
     @property

@@ -30,26 +30,30 @@ MODEL_CONFIGS = {
 }
 
 
-def synthetic_state_dict(reference_state, seed=0, out_gain=1.0):
+def synthetic_state_dict(reference_state, seed=0, out_gain=1.0, device='cpu'):
     """Deterministic weights addressed by KEY NAME (not by construction order), so the
     reference, this oracle and the HIP engine can all be filled identically:
     every tensor gets its own generator seeded with crc32(name) ^ seed.
     Matrices/convs: N(0, 1/fan_in) (keeps activations O(1) through the depth); LayerNorm
     weight 1 + 0.1 N; every bias 0.02 N (non-zero on purpose: exercises the bias paths).
-    `out_gain` scales the last head layer so that |xyz| is O(1) before expm1."""
+    `out_gain` scales the last head layer so that |xyz| is O(1) before expm1.
+    `device`: where the tensors are generated ('cpu' values are what the golden fixtures were made with; a CUDA
+    device uses that device's generator -- same distributions, different values -- for the full-size bench model,
+    whose weights never need to exist on the host)."""
     out = {}
+    device = torch.device(device)
     for name in sorted(reference_state.keys()):
         ref = reference_state[name]
-        g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+        g = torch.Generator(device=device).manual_seed((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
         shape = tuple(ref.shape)
         if ref.ndim >= 2:
             # ConvTranspose2d weight (act_postprocess.{0,1}.1) is (Cin, Cout, k, k): one tap per output pixel
             fan_in = ref.shape[0] if re.search(r'act_postprocess\.[01]\.1\.weight$', name) else ref[0].numel()
-            t = torch.randn(shape, generator=g) * fan_in ** -0.5
+            t = torch.randn(shape, generator=g, device=device) * fan_in ** -0.5
         elif name.endswith('weight'):
-            t = 1 + 0.1 * torch.randn(shape, generator=g)
+            t = 1 + 0.1 * torch.randn(shape, generator=g, device=device)
         else:
-            t = 0.02 * torch.randn(shape, generator=g)
+            t = 0.02 * torch.randn(shape, generator=g, device=device)
         out[name] = t.to(ref.dtype)
     # aliased tensors (scratch.layerN_rn <-> scratch.layer_rn.N) must stay identical
     for name in list(out):

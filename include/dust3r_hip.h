@@ -101,6 +101,9 @@ int d3r_model_destroy(d3r_model* m);
  * (mask_token, aliased scratch.layerN_rn, ...) return D3R_OK and are ignored; unknown keys -> D3R_ERR_UNKNOWN_KEY.
  * dec_blocks.* also fills dec_blocks2.* until a dec_blocks2 key arrives (dust3r/model.py:91-98). */
 int d3r_model_load_tensor(d3r_model* m, const char* key, const float* data_host, int ndim, const int64_t* shape);
+/* same, but `data_dev` is a DEVICE fp32 tensor (e.g. a checkpoint already uploaded by the caller). Both variants convert
+ * to the engine dtype / layout on the GPU; the call is ordered on the default stream and returns without synchronising. */
+int d3r_model_load_tensor_device(d3r_model* m, const char* key, const float* data_dev, int ndim, const int64_t* shape);
 /* number of tensors still missing (0 = ready) */
 int d3r_model_missing(const d3r_model* m);
 /* forward on B pairs of equal-size images (H, W multiples of patch_size):
@@ -110,6 +113,14 @@ int d3r_model_forward(d3r_model* m, const float* img1, const float* img2, int B,
                       float* conf2, void* stream);
 /* bytes of device memory currently held (weights + workspace) */
 size_t d3r_model_device_bytes(const d3r_model* m);
+/* Measurement hook (bench.py): with D3R_MODEL_OPT_PROFILE = 1 the next forwards record one HIP event before every
+ * kernel launch on the caller's stream; d3r_model_profile_read then returns, for the LAST forward, the number of
+ * launches, their summed duration in ms and their summed algorithmic work (flops) for one kernel class:
+ * kind 0 = GEMM (nn.Linear), 1 = implicit-GEMM convolution (same kernel), 2 = attention, 3 = all other kernels.
+ * Profiling adds event overhead: never enable it inside a timed region. */
+#define D3R_MODEL_OPT_PROFILE 1
+int d3r_model_set_option(d3r_model* m, int option, int value);
+int d3r_model_profile_read(d3r_model* m, int kind, int* launches, double* ms, double* work);
 /* debug/parity hook: copy an internal activation of the last forward to `out_f32` (device fp32).
  * what: 0 = encoder output after enc_norm [2B*N][enc_dim] (img1 batch then img2 batch) */
 int d3r_model_debug_read(d3r_model* m, int what, float* out_f32, size_t max_elems, void* stream);

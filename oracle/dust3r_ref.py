@@ -203,3 +203,28 @@ def build_ref_model(config='DUSt3R_ViTLarge_BaseDecoder_512_dpt', seed=0, out_ga
     model = DUSt3RRef(**cfg).eval()
     model.load_state_dict(synthetic_state_dict(model.state_dict(), seed, out_gain))
     return model
+
+
+def build_ref_model_fast(config='DUSt3R_ViTLarge_BaseDecoder_512_dpt', out_gain=None):
+    """Timing-only construction of the full-size oracle (bench.py's cpu_baseline leg): the modules are created on the
+    meta device and materialised once, then filled in place (N(0, 1/fan_in) matrices, unit LayerNorm weights, small
+    biases) -- first-touch page faults of the 2.6 GB of parameters dominate the normal construction path in the
+    sandboxed containers, so this skips croco's own init passes. Same architecture, same arithmetic per forward."""
+    cfg = MODEL_CONFIGS[config] if isinstance(config, str) else config
+    if out_gain is None:
+        out_gain = OUT_GAIN.get(config, 1.0) if isinstance(config, str) else 1.0
+    with torch.device('meta'):
+        model = DUSt3RRef(**cfg)
+    model = model.to_empty(device='cpu').eval()
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, p[0].numel() ** -0.5, generator=g)
+            elif name.endswith('weight'):
+                p.fill_(1.0)
+            else:
+                p.normal_(0, 0.02, generator=g)
+            if name.endswith('dpt.head.4.weight') or name.endswith('dpt.head.4.bias') or (name.startswith('downstream_head') and '.proj.' in name):
+                p.mul_(out_gain)
+    return model

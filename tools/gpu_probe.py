@@ -66,11 +66,24 @@ def forward_probe():
     print('== forward', cfg)
     m = AsymmetricCroCo3DStereo(precision='bf16', landscape_only=False, **MODEL_CONFIGS[cfg])
     t = time.time()
-    m.load_state_dict(synthetic_state_dict({k: torch.empty(v, device='meta') for k, v in m._spec.items()}, 0, OUT_GAIN[cfg]))
+    m.load_state_dict(synthetic_state_dict({k: torch.empty(v, device='meta') for k, v in m._spec.items()}, 0, OUT_GAIN[cfg], device=dev))
     print(f'  synthetic weights {time.time() - t:.1f}s')
     t = time.time()
     m.to(dev)
     print(f'  upload+pack {time.time() - t:.1f}s  weights {m.device_bytes() / 2**30:.2f} GiB')
+    # precision of the 16-bit modes against the engine's own exact-fp32 mode, full-size model, 2 pairs
+    v1, v2 = synthetic_views(2, 384, 512, seed=0, device=dev)
+    m.set_precision('fp32')
+    r1, r2 = m(v1, v2)
+    ref = [r1['pts3d'].clone(), r2['pts3d_in_other_view'].clone(), r1['conf'].clone()]
+    for prec in ('fp16', 'bf16'):
+        m.set_precision(prec)
+        e1, e2 = m(v1, v2)
+        for name, a, b in (('pts1', e1['pts3d'], ref[0]), ('pts2', e2['pts3d_in_other_view'], ref[1])):
+            rel = (a - b).norm(dim=-1) / b.norm(dim=-1).clamp_min(1e-8)
+            print(f'  {prec} vs fp32-engine {name}: rel err max {float(rel.max()):.3e} p99 {float(rel.flatten().quantile(0.99)):.3e} mean {float(rel.mean()):.3e}')
+        rc = ((e1['conf'] - ref[2]).abs() / ref[2]).max()
+        print(f'  {prec} vs fp32-engine conf1: rel err max {float(rc):.3e}')
     for prec in ('bf16', 'fp16', 'fp32'):
         m.set_precision(prec)
         for B in ((1, 4, 16, 32) if prec != 'fp32' else (1, 4)):

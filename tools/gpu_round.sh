@@ -1,0 +1,25 @@
+#!/bin/bash
+# One gpurun visit: parity tests, kernel probes, bench line and a rocprofv3 kernel trace. Everything lands in gpurun_out/.
+# Usage (from the repo root, on the GPU box): bash tools/gpu_round.sh [tests] [probe] [bench] [prof] [pmc]
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+OUT=gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+WHAT="${*:-tests probe bench prof}"
+rocminfo 2>/dev/null | grep -m2 -E "gfx|Marketing" > $OUT/device.txt
+nproc >> $OUT/device.txt; grep -m1 "model name" /proc/cpuinfo >> $OUT/device.txt
+for w in $WHAT; do
+  case $w in
+    tests) timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log ;;
+    testsall) timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -15 $OUT/pytest_gpu.log ;;
+    probe) timeout 900 python tools/gpu_probe.py gemm attn forward aligner > $OUT/probe.log 2>&1; tail -60 $OUT/probe.log ;;
+    bench) timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.log; tail -12 $OUT/bench.log; cat $OUT/bench.json ;;
+    prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.log); find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
+    pmc) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OLDPWD/$OUT/pmc_fetch -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $OLDPWD/$OUT/pmc_fetch.log);
+         (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OLDPWD/$OUT/pmc_write -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $OLDPWD/$OUT/pmc_write.log); ls $OUT/pmc_fetch $OUT/pmc_write ;;
+  esac
+done
+# keep the merged-back payload small: drop raw traces over 8 MB, keep stats
+find $OUT -type f -size +8M -delete
+du -sh $OUT
