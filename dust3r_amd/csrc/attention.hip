@@ -22,7 +22,7 @@ template <int DT> struct AttnCfg {
     static constexpr int EB = Traits<DT>::EB;
     static constexpr int ROWB = 64 * EB;                      // bytes of one 64-element row
     static constexpr int KROW = ROWB + 16;                    // padded K row stride in LDS
-    static constexpr int VROW = (DT == D3R_F32) ? ROWB + 16 : ROWB + 8;
+    static constexpr int VROW = (DT == D3R_F32) ? ROWB + 16 : ROWB + 8;   // F16X3: 264-byte rows, b64 reads
     static constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row
     static constexpr int NLD = 64 * CPR / 256;                // chunks per thread per tile (2 or 4)
     static constexpr int NKS = ROWB / 32;                     // QK^T k-steps (two chunks each)
@@ -50,13 +50,23 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
     const char* vptr = reinterpret_cast<const char*>(p.vt) + (size_t)bh * 64 * p.ldv * EB;
 
     // ---- Q fragments stay in registers for the whole kernel -------------------------------------
+    // F16X3: a 64-element row is 8 groups [hi x8][lo x8]; k-step ks (16 k) gives lane half hh the group 2*ks+hh,
+    // kept as qf[2*ks] (hi chunk) and qf[2*ks+1] (lo chunk).
     uint4 qf[C::NKS];
     {
         int qrow = q0 + l31;
         qrow = qrow < p.Nq ? qrow : p.Nq - 1;
+        if constexpr (DT == D3R_F16X3) {
 #pragma unroll
-        for (int ks = 0; ks < C::NKS; ++ks)
-            qf[ks] = *reinterpret_cast<const uint4*>(qptr + (size_t)qrow * C::ROWB + (ks * 2 + hh) * 16);
+            for (int ks = 0; ks < 4; ++ks) {
+                qf[2 * ks] = *reinterpret_cast<const uint4*>(qptr + (size_t)qrow * C::ROWB + (2 * ks + hh) * 32);        // hi
+                qf[2 * ks + 1] = *reinterpret_cast<const uint4*>(qptr + (size_t)qrow * C::ROWB + (2 * ks + hh) * 32 + 16);  // lo
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks)
+                qf[ks] = *reinterpret_cast<const uint4*>(qptr + (size_t)qrow * C::ROWB + (ks * 2 + hh) * 16);
+        }
     }
 
     // ---- tile staging (registers carry tile t+1 across the math of tile t). Named scalars, not
@@ -113,12 +123,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
         // S^T[key][query] = K Q^T
         f32x16_t s[2];
         s[0] = s[1] = (f32x16_t){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (DT == D3R_F16X3) {
 #pragma unroll
-        for (int ks = 0; ks < C::NKS; ++ks) {
+            for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(kb + (rb * 32 + l31) * C::KROW + (ks * 2 + hh) * 16);
-                TR::mma32(s[rb], kf, qf[ks]);
+                for (int rb = 0; rb < 2; ++rb) {
+                    const char* kr = kb + (rb * 32 + l31) * C::KROW + (2 * ks + hh) * 32;
+                    const uint4 kh = *reinterpret_cast<const uint4*>(kr), kl = *reinterpret_cast<const uint4*>(kr + 16);
+                    TR::mma32x3(s[rb], kh, kl, qf[2 * ks], qf[2 * ks + 1]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const uint4 kf = *reinterpret_cast<const uint4*>(kb + (rb * 32 + l31) * C::KROW + (ks * 2 + hh) * 16);
+                    TR::mma32(s[rb], kf, qf[ks]);
+                }
             }
         }
         // mask keys beyond Nk (only the last tile of a ragged sequence)
@@ -176,6 +198,20 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
                         TR::mma32(o[db], vlo, plo);
                         TR::mma32(o[db], vhi, phi);
                     }
+                } else if constexpr (DT == D3R_F16X3) {
+                    // keys kbase..+3 sit in 8-group kbase/8 at element offset 4*hh, keys kbase+8..+11 in the next group
+                    uint4 ph, pl;
+                    TR::split2(s[rb][8 * sh + 0], s[rb][8 * sh + 1], ph.x, pl.x);
+                    TR::split2(s[rb][8 * sh + 2], s[rb][8 * sh + 3], ph.y, pl.y);
+                    TR::split2(s[rb][8 * sh + 4], s[rb][8 * sh + 5], ph.z, pl.z);
+                    TR::split2(s[rb][8 * sh + 6], s[rb][8 * sh + 7], ph.w, pl.w);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const char* vrow = vb + (db * 32 + l31) * C::VROW + (kbase >> 3) * 32 + hh * 8;
+                        const uint2 h0 = *reinterpret_cast<const uint2*>(vrow), l0 = *reinterpret_cast<const uint2*>(vrow + 16);
+                        const uint2 h1 = *reinterpret_cast<const uint2*>(vrow + 32), l1 = *reinterpret_cast<const uint2*>(vrow + 48);
+                        TR::mma32x3(o[db], make_uint4(h0.x, h0.y, h1.x, h1.y), make_uint4(l0.x, l0.y, l1.x, l1.y), ph, pl);
+                    }
                 } else {
                     uint4 pf;
                     pf.x = TR::pack2(s[rb][8 * sh + 0], s[rb][8 * sh + 1]);
@@ -230,6 +266,7 @@ hipError_t launch_attention(int dt, const AttnParams& p, hipStream_t s) {
         case D3R_BF16: return launch_t<D3R_BF16>(p, s);
         case D3R_F16: return launch_t<D3R_F16>(p, s);
         case D3R_F32: return launch_t<D3R_F32>(p, s);
+        case D3R_F16X3: return launch_t<D3R_F16X3>(p, s);
     }
     return hipErrorInvalidValue;
 }

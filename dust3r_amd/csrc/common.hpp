@@ -3,6 +3,11 @@
 // Every matrix kernel is written once against `Traits<DT>`; DT selects the MFMA family:
 //   D3R_BF16 / D3R_F16 : v_mfma_f32_{16x16x32,32x32x16}_{bf16,f16}   (2.5 PFLOP/s dense peak)
 //   D3R_F32            : v_mfma_f32_{16x16x4,32x32x2}_f32            (exact f32, 157 TFLOP/s)
+//   D3R_F16X3          : the f16 MFMAs on split operands x = hi + lo (hi = fp16(x), lo = fp16(x - hi), 22
+//                        significand bits together), three MFMAs per product (lo*lo dropped, 2^-22 relative):
+//                        fp32-class results at 1/3 of the 16-bit MFMA rate = 5.3x the exact-f32 MFMA rate.
+//                        Storage: a row of K logical elements is K*4 bytes made of 32-byte groups
+//                        [8 x hi fp16][8 x lo fp16], i.e. the same 16-byte-chunk geometry as every other mode.
 // The f32 instantiation is the "reference-exact" precision mode (the reference runs fp32,
 // dust3r/inference.py:44); it shares tiles, LDS images and epilogues with the 16-bit modes
 // because all of them move operands as 16-byte chunks (8 x 16-bit or 4 x f32) and the MFMA
@@ -14,6 +19,7 @@
 #define D3R_BF16 0
 #define D3R_F16 1
 #define D3R_F32 2
+#define D3R_F16X3 3   // split fp16: every value is a (hi, lo) fp16 pair, products use 3 MFMAs (hi*hi + hi*lo + lo*hi)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
@@ -79,10 +85,54 @@ template <> struct Traits<D3R_F32> {
     }
 };
 
+template <> struct Traits<D3R_F16X3> {
+    static constexpr int EB = 4;   // bytes per LOGICAL element (2 hi + 2 lo)
+    static constexpr int CH = 4;
+    D3R_DEV static f16x8_t h8(const uint4& a) { return __builtin_bit_cast(f16x8_t, a); }
+    // a, b: hi chunks; al, bl: lo chunks (8 consecutive k each). Small terms first.
+    D3R_DEV static void mma16x3(f32x4_t& acc, const uint4& a, const uint4& al, const uint4& b, const uint4& bl) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(al), h8(b), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(a), h8(bl), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(a), h8(b), acc, 0, 0, 0);
+    }
+    D3R_DEV static void mma32x3(f32x16_t& acc, const uint4& a, const uint4& al, const uint4& b, const uint4& bl) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al), h8(b), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a), h8(bl), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a), h8(b), acc, 0, 0, 0);
+    }
+    // split two floats into packed (hi, hi) and (lo, lo) fp16 pairs; inputs saturate at the fp16 range
+    D3R_DEV static void split2(float x, float y, uint32_t& hi, uint32_t& lo) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+        x = fminf(fmaxf(x, -65504.f), 65504.f);
+        y = fminf(fmaxf(y, -65504.f), 65504.f);
+        const _Float16 hx = (_Float16)x, hy = (_Float16)y;
+        v2 h = {hx, hy};
+        v2 l = {(_Float16)(x - (float)hx), (_Float16)(y - (float)hy)};
+        hi = __builtin_bit_cast(uint32_t, h);
+        lo = __builtin_bit_cast(uint32_t, l);
+    }
+    D3R_DEV static float join_lo(uint32_t hi, uint32_t lo) {
+        return (float)__builtin_bit_cast(_Float16, (uint16_t)(hi & 0xFFFFu)) + (float)__builtin_bit_cast(_Float16, (uint16_t)(lo & 0xFFFFu));
+    }
+    D3R_DEV static float join_hi(uint32_t hi, uint32_t lo) {
+        return (float)__builtin_bit_cast(_Float16, (uint16_t)(hi >> 16)) + (float)__builtin_bit_cast(_Float16, (uint16_t)(lo >> 16));
+    }
+    // byte offset of logical element e inside a tensor whose rows start at multiples of 8 elements
+    D3R_DEV static size_t boff(size_t e) { return (e >> 3) * 32 + (e & 7) * 2; }
+};
+
 // ---- typed 4-element (row-contiguous) loads / stores used by every epilogue -----------------
 template <int DT> D3R_DEV void store4(void* base, size_t elem_off, float a, float b, float c, float d) {
     if constexpr (DT == D3R_F32) {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem_off) = make_float4(a, b, c, d);
+    } else if constexpr (DT == D3R_F16X3) {   // elem_off % 4 == 0: the 4 elements share one 8-group
+        using TX = Traits<D3R_F16X3>;
+        uint2 h, l;
+        TX::split2(a, b, h.x, l.x);
+        TX::split2(c, d, h.y, l.y);
+        char* p = reinterpret_cast<char*>(base) + TX::boff(elem_off);
+        *reinterpret_cast<uint2*>(p) = h;
+        *reinterpret_cast<uint2*>(p + 16) = l;
     } else {
         uint2 v;
         v.x = Traits<DT>::pack2(a, b);
@@ -93,6 +143,11 @@ template <int DT> D3R_DEV void store4(void* base, size_t elem_off, float a, floa
 template <int DT> D3R_DEV float4 load4(const void* base, size_t elem_off) {
     if constexpr (DT == D3R_F32) {
         return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
+    } else if constexpr (DT == D3R_F16X3) {
+        using TX = Traits<D3R_F16X3>;
+        const char* p = reinterpret_cast<const char*>(base) + TX::boff(elem_off);
+        const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + 16);
+        return make_float4(TX::join_lo(h.x, l.x), TX::join_hi(h.x, l.x), TX::join_lo(h.y, l.y), TX::join_hi(h.y, l.y));
     } else {
         uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem_off);
         return make_float4(Traits<DT>::unpack_lo(v.x), Traits<DT>::unpack_hi(v.x), Traits<DT>::unpack_lo(v.y),
@@ -101,11 +156,21 @@ template <int DT> D3R_DEV float4 load4(const void* base, size_t elem_off) {
 }
 template <int DT> D3R_DEV void store1(void* base, size_t elem_off, float a) {
     if constexpr (DT == D3R_F32) reinterpret_cast<float*>(base)[elem_off] = a;
-    else reinterpret_cast<uint16_t*>(base)[elem_off] = (uint16_t)(Traits<DT>::pack2(a, 0.f) & 0xFFFFu);
+    else if constexpr (DT == D3R_F16X3) {
+        using TX = Traits<D3R_F16X3>;
+        uint32_t h, l;
+        TX::split2(a, 0.f, h, l);
+        char* p = reinterpret_cast<char*>(base) + TX::boff(elem_off);
+        *reinterpret_cast<uint16_t*>(p) = (uint16_t)(h & 0xFFFFu);
+        *reinterpret_cast<uint16_t*>(p + 16) = (uint16_t)(l & 0xFFFFu);
+    } else reinterpret_cast<uint16_t*>(base)[elem_off] = (uint16_t)(Traits<DT>::pack2(a, 0.f) & 0xFFFFu);
 }
 template <int DT> D3R_DEV float load1(const void* base, size_t elem_off) {
     if constexpr (DT == D3R_F32) return reinterpret_cast<const float*>(base)[elem_off];
-    else return Traits<DT>::unpack_lo((uint32_t)reinterpret_cast<const uint16_t*>(base)[elem_off]);
+    else if constexpr (DT == D3R_F16X3) {
+        const char* p = reinterpret_cast<const char*>(base) + Traits<D3R_F16X3>::boff(elem_off);
+        return (float)*reinterpret_cast<const _Float16*>(p) + (float)*reinterpret_cast<const _Float16*>(p + 16);
+    } else return Traits<DT>::unpack_lo((uint32_t)reinterpret_cast<const uint16_t*>(base)[elem_off]);
 }
 
 D3R_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -119,4 +184,4 @@ D3R_DEV int xcd_remap(int bid, int nwg) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-static inline size_t dt_bytes(int dt) { return dt == D3R_F32 ? 4 : 2; }
+static inline size_t dt_bytes(int dt) { return (dt == D3R_F32 || dt == D3R_F16X3) ? 4 : 2; }

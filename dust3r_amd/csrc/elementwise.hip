@@ -65,6 +65,7 @@ hipError_t launch_layernorm(int dt, const float* x, const float* gamma, const fl
         case D3R_BF16: hipLaunchKernelGGL(layernorm_kernel<D3R_BF16>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
         case D3R_F16: hipLaunchKernelGGL(layernorm_kernel<D3R_F16>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
         case D3R_F32: hipLaunchKernelGGL(layernorm_kernel<D3R_F32>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
+        case D3R_F16X3: hipLaunchKernelGGL(layernorm_kernel<D3R_F16X3>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -85,6 +86,7 @@ hipError_t launch_convert(int dt, const float* x, void* out, size_t n, hipStream
         case D3R_BF16: hipLaunchKernelGGL(convert_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, x, out, n4); break;
         case D3R_F16: hipLaunchKernelGGL(convert_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, x, out, n4); break;
         case D3R_F32: hipLaunchKernelGGL(convert_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, x, out, n4); break;
+        case D3R_F16X3: hipLaunchKernelGGL(convert_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, x, out, n4); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -118,6 +120,7 @@ hipError_t launch_patchify(int dt, const float* img, void* out, int B, int H, in
         case D3R_BF16: hipLaunchKernelGGL(patchify_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, img, out, B, H, W, ps); break;
         case D3R_F16: hipLaunchKernelGGL(patchify_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, img, out, B, H, W, ps); break;
         case D3R_F32: hipLaunchKernelGGL(patchify_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, img, out, B, H, W, ps); break;
+        case D3R_F16X3: hipLaunchKernelGGL(patchify_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, img, out, B, H, W, ps); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -222,6 +225,7 @@ hipError_t launch_upsample2x(int dt, const void* in, void* out, void* out_relu, 
         case D3R_BF16: hipLaunchKernelGGL(upsample2x_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo); break;
         case D3R_F16: hipLaunchKernelGGL(upsample2x_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo); break;
         case D3R_F32: hipLaunchKernelGGL(upsample2x_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo); break;
+        case D3R_F16X3: hipLaunchKernelGGL(upsample2x_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -277,6 +281,7 @@ hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, co
         case D3R_BF16: hipLaunchKernelGGL(head_final_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix); break;
         case D3R_F16: hipLaunchKernelGGL(head_final_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix); break;
         case D3R_F32: hipLaunchKernelGGL(head_final_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix); break;
+        case D3R_F16X3: hipLaunchKernelGGL(head_final_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -340,6 +345,7 @@ hipError_t launch_pack_weight(int dt, const PackParams& p, hipStream_t s) {
         case D3R_BF16: hipLaunchKernelGGL(pack_weight_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, p); break;
         case D3R_F16: hipLaunchKernelGGL(pack_weight_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, p); break;
         case D3R_F32: hipLaunchKernelGGL(pack_weight_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, p); break;
+        case D3R_F16X3: hipLaunchKernelGGL(pack_weight_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -353,7 +353,7 @@ extern "C" int d3r_device_check(void) {
 
 extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     if (!out || !cfg) return D3R_ERR_INVALID;
-    if (cfg->dtype < 0 || cfg->dtype > 2 || cfg->patch_size % 4 != 0) return D3R_ERR_INVALID;
+    if (cfg->dtype < 0 || cfg->dtype > 3 || cfg->patch_size % 4 != 0) return D3R_ERR_INVALID;
     if (cfg->enc_embed_dim != cfg->enc_num_heads * 64 || cfg->dec_embed_dim != cfg->dec_num_heads * 64) return D3R_ERR_INVALID;  // head dim 64
     d3r_model* m = new (std::nothrow) d3r_model();
     if (!m) return D3R_ERR_ALLOC;

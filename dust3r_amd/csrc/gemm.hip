@@ -113,19 +113,38 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         __syncthreads();  // compiler drains vmcnt here: tile kt has landed; buf^1 is free again
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
         const char* sb = smem + buf * STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
-            uint4 pf[4], qf[4];
+        if constexpr (DT == D3R_F16X3) {
+            // 128 bytes of a row = 32 logical k = 4 groups [hi x8][lo x8]; lane group fgrp owns group fgrp
+            const int chi = ((2 * fgrp) ^ fsw) * 16, clo = ((2 * fgrp + 1) ^ fsw) * 16;
+            uint4 pf[4], pl[4], qf[4], ql[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                pf[f] = *reinterpret_cast<const uint4*>(sb + p_off + (wi * 64 + f * 16 + frow) * KTB + coff);
-                qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (wj * 64 + f * 16 + frow) * KTB + coff);
+                const char* pr = sb + p_off + (wi * 64 + f * 16 + frow) * KTB;
+                const char* qr = sb + q_off + (wj * 64 + f * 16 + frow) * KTB;
+                pf[f] = *reinterpret_cast<const uint4*>(pr + chi);
+                pl[f] = *reinterpret_cast<const uint4*>(pr + clo);
+                qf[f] = *reinterpret_cast<const uint4*>(qr + chi);
+                ql[f] = *reinterpret_cast<const uint4*>(qr + clo);
             }
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
-                for (int fj = 0; fj < 4; ++fj) TR::mma16(acc[fi][fj], pf[fi], qf[fj]);
+                for (int fj = 0; fj < 4; ++fj) TR::mma16x3(acc[fi][fj], pf[fi], pl[fi], qf[fj], ql[fj]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
+                uint4 pf[4], qf[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    pf[f] = *reinterpret_cast<const uint4*>(sb + p_off + (wi * 64 + f * 16 + frow) * KTB + coff);
+                    qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (wj * 64 + f * 16 + frow) * KTB + coff);
+                }
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                    for (int fj = 0; fj < 4; ++fj) TR::mma16(acc[fi][fj], pf[fi], qf[fj]);
+            }
         }
     }
 
@@ -277,6 +296,7 @@ hipError_t launch_gemm(int dt, const GemmParams& p, hipStream_t s) {
         case D3R_BF16: return launch_t<D3R_BF16>(p, s);
         case D3R_F16: return launch_t<D3R_F16>(p, s);
         case D3R_F32: return launch_t<D3R_F32>(p, s);
+        case D3R_F16X3: return launch_t<D3R_F16X3>(p, s);
     }
     return hipErrorInvalidValue;
 }

@@ -36,6 +36,8 @@ extern "C" {
 #define D3R_DTYPE_BF16 0 /* v_mfma_*_bf16: the throughput mode named by BASELINE.json */
 #define D3R_DTYPE_F16 1  /* v_mfma_*_f16: same rate, 3 more mantissa bits */
 #define D3R_DTYPE_F32 2  /* v_mfma_f32_*_f32: exact fp32 like the reference (dust3r/inference.py:44), 1/16 rate */
+#define D3R_DTYPE_F16X3 3 /* split fp16 (hi + lo pairs, 3 f16 MFMAs per product): fp32-class accuracy at 1/3 of the 16-bit rate.
+                           * Model engine only: the building-block entry points take D3R_DTYPE_BF16 / F16 / F32 tensors. */
 
 const char* d3r_version(void);
 /* 0 when a gfx950 device is visible to the HIP runtime, else an error code (used to fail loudly) */

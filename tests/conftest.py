@@ -20,3 +20,13 @@ def gpu():
     from dust3r_amd import _lib
     _lib.require_device()
     return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _cpu_threads():
+    """The CPU oracle runs inside the GPU tests too: size torch's thread pool by measurement, not by os.cpu_count()
+    (256 logical CPUs on the GPU boxes, of which the container can use far fewer)."""
+    from oracle import tune_threads
+    n = tune_threads()
+    print(f'[conftest] torch CPU threads = {n}')
+    yield

