@@ -21,7 +21,7 @@ extern "C" int d3r_linear(const void* act, const void* wgt, const float* bias, v
                           int dtype, void* stream) {
     if (!act || !wgt || !out || N % 4 != 0) return D3R_ERR_INVALID;
     GemmParams p;
-    p.act = act; p.lda = K; p.wgt = wgt; p.bias = bias; p.M = M; p.K = K; p.n_pad = rup(N, 128); p.n_store = N;
+    p.act = act; p.lda = K; p.wgt = wgt; p.bias = bias; p.M = M; p.K = K; p.n_pad = rup(N, 128); p.n_rows = rup(N, 256); p.n_store = N;
     p.epi = epilogue == 1 ? EPI_F32 : (epilogue == 2 ? EPI_GELU : EPI_T);
     p.out = out; p.ldo = N; p.res1 = epilogue == 1 ? residual : nullptr; p.ldr = N;
     return rc_of(launch_gemm(dtype, p, (hipStream_t)stream));
@@ -35,7 +35,7 @@ extern "C" int d3r_conv2d_nhwc(const void* in, const void* wgt, const float* bia
     p.amode = AMODE_CONV; p.act = in; p.wgt = wgt; p.bias = bias;
     p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.cstride = Cin; p.ksize = ksize; p.stride = stride; p.pad = pad;
     p.Hout = (Hin + 2 * pad - ksize) / stride + 1; p.Wout = (Win + 2 * pad - ksize) / stride + 1;
-    p.M = B * p.Hout * p.Wout; p.K = ksize * ksize * Cin; p.n_pad = rup(Cout, 128); p.n_store = Cout; p.zero_page = zero_page;
+    p.M = B * p.Hout * p.Wout; p.K = ksize * ksize * Cin; p.n_pad = rup(Cout, 128); p.n_rows = rup(Cout, 256); p.n_store = Cout; p.zero_page = zero_page;
     p.epi = EPI_T; p.flags = relu ? GF_RELU : 0; p.out = out; p.ldo = Cout; p.res1 = res1; p.res2 = res2; p.ldr = Cout;
     p.out2 = out_relu_copy; p.ldo2 = Cout;
     return rc_of(launch_gemm(dtype, p, (hipStream_t)stream));

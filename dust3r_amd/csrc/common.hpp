@@ -173,6 +173,25 @@ template <int DT> D3R_DEV float load1(const void* base, size_t elem_off) {
     } else return Traits<DT>::unpack_lo((uint32_t)reinterpret_cast<const uint16_t*>(base)[elem_off]);
 }
 
+// ---- LDS-DMA (global_load_lds_dwordx4) issued from inline asm ---------------------------------------------
+// hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first ds_read that follows a
+// __builtin_amdgcn_global_load_lds (it cannot prove the read does not alias the DMA's LDS destination), which
+// serialises a double-buffered K loop: the next tile's loads are drained before the current tile is computed.
+// Issued from asm the loads are invisible to the compiler's counters; the kernels wait for them explicitly
+// (d3r_wait_vm0) in front of the barrier that publishes the tile. lds_dst: wave-uniform LDS byte address (the DMA
+// writes lane l's 16 bytes at lds_dst + 16 l); gsrc: this lane's source address.
+D3R_DEV void glds16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+D3R_DEV void d3r_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+D3R_DEV uint32_t lds_addr(const void* p) {
+    return (uint32_t)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
 D3R_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // XCD-aware bijective block remap (8 XCDs, block b runs on XCD b % 8): gives each XCD a

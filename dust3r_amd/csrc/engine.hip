@@ -40,11 +40,11 @@ struct Slot {
     std::string mirror;       // dec_blocks.* -> dec_blocks2.* duplication
 };
 
-struct Lin { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, n_pad = 0; };
+struct Lin { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, n_pad = 0, n_rows = 0; };
 struct LNp { float* g = nullptr; float* b = nullptr; };
 struct EncBlk { LNp n1, n2; Lin qkv, proj, fc1, fc2; };
 struct DecBlk { LNp n1, n2, n3, ny; Lin qkv, proj, cq, ckv, cproj, fc1, fc2; };
-struct ConvW { void* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0, cin_pad = 0, k = 1, n_pad = 0, K = 0; };
+struct ConvW { void* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0, cin_pad = 0, k = 1, n_pad = 0, n_rows = 0, K = 0; };
 struct Refine { ConvW r1c1, r1c2, r2c1, r2c2; Lin outc; };
 struct DptHead {
     Lin act1x1[4];
@@ -113,9 +113,9 @@ bool reg_vec_at(d3r_model* m, const std::string& key, float* base, int off, int 
     return true;
 }
 bool alloc_lin(d3r_model* m, Lin& L, int N, int K, bool bias = true) {
-    L.N = N; L.K = K; L.n_pad = rup(N, 128);
-    L.w = m->dalloc((size_t)L.n_pad * K * dt_bytes(m->dt));
-    L.b = bias ? (float*)m->dalloc((size_t)L.n_pad * sizeof(float)) : nullptr;
+    L.N = N; L.K = K; L.n_pad = rup(N, 128); L.n_rows = rup(N, 256);   // rows up to a 256-wide tile stay zero
+    L.w = m->dalloc((size_t)L.n_rows * K * dt_bytes(m->dt));
+    L.b = bias ? (float*)m->dalloc((size_t)L.n_rows * sizeof(float)) : nullptr;
     return L.w && (!bias || L.b);
 }
 void reg_mat(d3r_model* m, const std::string& key, const Lin& L, int rows, int row_off) {
@@ -132,22 +132,22 @@ bool reg_ln(d3r_model* m, const std::string& prefix, LNp& p, int C) {
     return reg_vec(m, prefix + ".weight", &p.g, C) && reg_vec(m, prefix + ".bias", &p.b, C);
 }
 bool reg_conv(d3r_model* m, const std::string& prefix, ConvW& c, int Cout, int Cin, int k, bool bias) {
-    c.Cout = Cout; c.Cin = Cin; c.k = k; c.cin_pad = rup(Cin, m->ktile); c.n_pad = rup(Cout, 128); c.K = k * k * c.cin_pad;
-    c.w = m->dalloc((size_t)c.n_pad * c.K * dt_bytes(m->dt));
+    c.Cout = Cout; c.Cin = Cin; c.k = k; c.cin_pad = rup(Cin, m->ktile); c.n_pad = rup(Cout, 128); c.n_rows = rup(Cout, 256); c.K = k * k * c.cin_pad;
+    c.w = m->dalloc((size_t)c.n_rows * c.K * dt_bytes(m->dt));
     if (!c.w) return false;
     Slot s; s.kind = PK_CONV; s.dst = c.w; s.rows = Cout; s.cin = Cin; s.cin_pad = c.cin_pad; s.ksize = k; s.dst_cols = c.K;
     m->slots[prefix + ".weight"] = s;
     if (bias) {
-        c.b = (float*)m->dalloc((size_t)c.n_pad * sizeof(float));
+        c.b = (float*)m->dalloc((size_t)c.n_rows * sizeof(float));
         if (!c.b) return false;
         reg_vec_at(m, prefix + ".bias", c.b, 0, Cout);
     }
     return true;
 }
 bool reg_convt(d3r_model* m, const std::string& prefix, Lin& L, int Cin, int Cout, int k, int cin_pad, int cout_pad) {
-    L.N = k * k * cout_pad; L.K = cin_pad; L.n_pad = rup(L.N, 128);
-    L.w = m->dalloc((size_t)L.n_pad * L.K * dt_bytes(m->dt));
-    L.b = (float*)m->dalloc((size_t)L.n_pad * sizeof(float));
+    L.N = k * k * cout_pad; L.K = cin_pad; L.n_pad = rup(L.N, 128); L.n_rows = rup(L.N, 256);
+    L.w = m->dalloc((size_t)L.n_rows * L.K * dt_bytes(m->dt));
+    L.b = (float*)m->dalloc((size_t)L.n_rows * sizeof(float));
     if (!L.w || !L.b) return false;
     Slot s; s.kind = PK_CONVT; s.dst = L.w; s.rows = Cin; s.cols = Cout; s.ksize = k; s.cin_pad = cin_pad; s.cout_pad = cout_pad; s.dst_cols = L.K;
     m->slots[prefix + ".weight"] = s;
@@ -296,7 +296,7 @@ enum { PRF_GEMM = 0, PRF_CONV = 1, PRF_ATTN = 2, PRF_OTHER = 3, PRF_END = 4 };
 void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi, void* out, int ldo, const void* res1 = nullptr,
                  void* out2 = nullptr, int ldo2 = 0, int n_store = -1, int flags = 0) {
     GemmParams p;
-    p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad;
+    p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_rows = L.n_rows;
     p.n_store = n_store >= 0 ? n_store : L.N;
     p.epi = epi; p.out = out; p.ldo = ldo; p.res1 = res1; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo2; p.flags = flags;
     c.mark(PRF_GEMM, 2.0 * M * (double)L.N * L.K);
@@ -306,7 +306,7 @@ void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi,
 void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_c, int nreg, const int* kinds, void* const* dsts, int heads,
                 int ntok, int tok_w, int ldv) {
     GemmParams p;
-    p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_store = L.N;
+    p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_rows = L.n_rows; p.n_store = L.N;
     p.epi = EPI_HEADS; p.head_c = head_c;
     for (int i = 0; i < nreg; ++i) { p.head_kind[i] = kinds[i]; p.head_dst[i] = dsts[i]; }
     p.heads = heads; p.ntok = ntok; p.tok_w = tok_w; p.ldv = ldv; p.rope_table = c.m->rope_table;
@@ -320,7 +320,7 @@ void conv(Ctx& c, const void* in, int B, int Hin, int Win, int cstride, const Co
     p.amode = AMODE_CONV; p.act = in; p.wgt = w.w; p.bias = w.b;
     p.Hin = Hin; p.Win = Win; p.Cin = w.cin_pad; p.cstride = cstride; p.ksize = w.k; p.stride = stride; p.pad = pad;
     p.Hout = (Hin + 2 * pad - w.k) / stride + 1; p.Wout = (Win + 2 * pad - w.k) / stride + 1;
-    p.M = B * p.Hout * p.Wout; p.K = w.K; p.n_pad = w.n_pad; p.n_store = n_store >= 0 ? n_store : w.Cout;
+    p.M = B * p.Hout * p.Wout; p.K = w.K; p.n_pad = w.n_pad; p.n_rows = w.n_rows; p.n_store = n_store >= 0 ? n_store : w.Cout;
     p.zero_page = c.m->zero_page;
     p.epi = EPI_T; p.flags = flags; p.out = out; p.ldo = ldo; p.res1 = res1; p.res2 = res2; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo;
     c.mark(PRF_CONV, 2.0 * p.M * (double)w.Cout * w.k * w.k * w.Cin);
@@ -499,7 +499,7 @@ void run_dpt(Ctx& c, const DptHead& D, Arena ar, const void* const hooks[4], con
         if (i < 2) {
             GemmParams p;
             p.act = t1; p.lda = D.cstride[i]; p.wgt = D.convt[i].w; p.bias = D.convt[i].b; p.M = B * N; p.K = D.convt[i].K;
-            p.n_pad = D.convt[i].n_pad; p.n_store = D.convt[i].N; p.epi = EPI_CONVT; p.ksize = D.convt_k[i]; p.ct_cout = D.convt_coutp[i];
+            p.n_pad = D.convt[i].n_pad; p.n_rows = D.convt[i].n_rows; p.n_store = D.convt[i].N; p.epi = EPI_CONVT; p.ksize = D.convt_k[i]; p.ct_cout = D.convt_coutp[i];
             p.Hin = th; p.Win = tw; p.out = cmap[i]; p.ldo = D.cstride[i];
             const int ldi[2] = {96, 192};
             c.mark(PRF_CONV, 2.0 * p.M * (double)(D.convt_k[i] * D.convt_k[i] * ldi[i]) * ldi[i]);
@@ -649,7 +649,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
                 D3R_OTHER(launch_linear_head_post(lin_out, pts[s], cnf[s], B, th, tw, ps, st));
             }
     } else {
-        const int chunk = B < 4 ? B : 4;
+        const int chunk = B < 32 ? B : 32;   // 288 GB of HBM: batch the head as wide as the encoder (low-resolution stages need the rows)
         for (int s = 0; s < 2; ++s)
             for (int b0 = 0; b0 < B; b0 += chunk) {
                 const int bc = (B - b0) < chunk ? (B - b0) : chunk;

@@ -1,6 +1,6 @@
 // dust3r_amd -- MFMA GEMM / implicit-GEMM convolution with fused epilogues (gfx950).
 //
-// One kernel serves every dense contraction of the DUSt3R forward (reference call sites):
+// One kernel template serves every dense contraction of the DUSt3R forward (reference call sites):
 //   Linear layers of croco Block / DecoderBlock (qkv, proj, fc1, fc2, projq/k/v) and
 //   decoder_embed (dust3r/model.py:136-137,176-186), PatchEmbed's k16s16 conv as a GEMM
 //   over pre-gathered patches (dust3r/patch_embed.py:19-29), the DPT head's 1x1 / 3x3 /
@@ -8,53 +8,83 @@
 //   GEMMs over NHWC activations, and LinearPts3d.proj (dust3r/heads/linear_head.py:30-41).
 //
 // Shape: out[m][n] = sum_k act[m][k] * wgt[n][k]   ("NT": both operands K-contiguous).
-// Tile:  128 (m) x 128 (n) x 128 bytes of K per step; 4 waves (2x2), each 64x64 = 4x4 MFMA
-//        16x16 fragments. Operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR
-//        round trip), double buffered; LDS image is lane-linear, the bank swizzle
-//        (chunk ^= (row>>1)&7, conflict-free for ds_read_b128 on 128-byte rows) is applied on
-//        the per-lane SOURCE address and again on the fragment read.
+// Tile configurations (template Cfg; 128 bytes of K per step = 64 bf16; 16x16x32 MFMA fragments):
+//   256 x 256, 8 waves (2 x 4), each wave 128 (n) x 64 (m) = 8 x 4 fragments   -- the large-GEMM shape
+//   256 x 128, 8 waves, each wave 64 x 64                                       -- N = 128 convolutions
+//   128 x 128, 4 waves (2 x 2), each wave 64 x 64, 2 blocks per CU              -- small problems / tails
+// Operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered; the LDS image is
+// lane-linear, the bank swizzle (chunk ^= (row>>1)&7, conflict-free for ds_read_b128 on 128-byte rows) is applied
+// on the per-lane SOURCE address and again on the fragment read.
+// Block -> tile map: XCD-aware (each XCD owns a contiguous range of tile ids) and panel-rasterised (8 n-tiles wide)
+// so the tiles an XCD works on concurrently share A rows and W rows inside its 4 MiB L2.
 // MFMA operand roles: D[i][j] with 4 consecutive i per lane. Normally i = n (weights) so each
 // lane owns 4 consecutive output columns of one row -> 8/16-byte stores; for V^T tiles of the
 // attention projections the roles are swapped (i = m) so 4 consecutive TOKENS land together.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace d3r {
 
-static constexpr int BM = 128, BN = 128, KTB = 128;  // KTB: bytes of K per tile row
-static constexpr int STAGE_BYTES = (BM + BN) * KTB;  // 32 KiB
-static constexpr int GEMM_LDS = 2 * STAGE_BYTES;     // 64 KiB
+static constexpr int KTB = 128;  // bytes of K per tile row
+
+// NWI x NWJ waves; a wave owns FI x FJ 16x16 fragments. The "i" side (4 consecutive per lane) is n (weights) unless
+// the block works on a V^T region (roles swapped; square configurations only).
+template <int NWI_, int NWJ_, int FI_, int FJ_, int MINW_> struct GemmCfg {
+    static constexpr int NWI = NWI_, NWJ = NWJ_, FI = FI_, FJ = FJ_, MINW = MINW_;
+    static constexpr int NW = NWI * NWJ, NT = NW * 64;
+    static constexpr int BN = NWI * FI * 16, BM = NWJ * FJ * 16;
+    static constexpr int PASS_ROWS = NW * 8;                 // rows staged by one global_load_lds per wave
+    static constexpr int APASS = BM / PASS_ROWS, WPASS = BN / PASS_ROWS;
+    static constexpr int STAGE_BYTES = (BM + BN) * KTB;
+    static constexpr int LDS = 2 * STAGE_BYTES;
+};
+typedef GemmCfg<2, 4, 8, 4, 2> Cfg256;      // 256 x 256, 512 threads, 128 KiB LDS, 1 block / CU
+typedef GemmCfg<2, 4, 4, 4, 2> Cfg256x128;  // M 256 x N 128, 512 threads, 96 KiB LDS, 1 block / CU
+typedef GemmCfg<2, 2, 4, 4, 2> Cfg128;      // 128 x 128, 256 threads, 64 KiB LDS, 2 blocks / CU
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int DT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+template <int DT, class CF>
+__global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TR = Traits<DT>;
     constexpr int EB = TR::EB;
     constexpr int KT = KTB / EB;  // elements of K per tile
+    constexpr int BM = CF::BM, BN = CF::BN, FI = CF::FI, FJ = CF::FJ, STAGE_BYTES = CF::STAGE_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = p.n_pad / BN;
+    // ---- block -> tile: XCD-contiguous ids, then 8-wide column panels walked row by row ------------------
+    const int tiles_n = (p.n_store + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    constexpr int PANEL = 8;
+    const int per_panel = PANEL * tiles_m;
+    const int panel = lid / per_panel, rem_p = lid - panel * per_panel;
+    const int width = min(PANEL, tiles_n - panel * PANEL);
+    const int tm = rem_p / width, tn = panel * PANEL + (rem_p - tm * width);
     const int m0 = tm * BM, n0 = tn * BN;
-    const bool swap = (p.epi == EPI_HEADS) && (p.head_kind[n0 / p.head_c] == HEAD_VT);
+    const bool swap = (BM == BN) && (p.epi == EPI_HEADS) && (p.head_kind[n0 / p.head_c] == HEAD_VT);
 
-    // ---- staging addresses (per lane: 4 rows of each operand, one 16-byte chunk) -------------
-    const int lrow = wave * 8 + (lane >> 3);                       // row inside a 32-row slab
+    // ---- staging addresses (per lane: one 16-byte chunk of APASS activation rows and WPASS weight rows) ---
+    const int lrow = wave * 8 + (lane >> 3);                         // row inside a PASS_ROWS slab
     const int lchunk = (lane & 7) ^ (((lane >> 4) + wave * 4) & 7);  // logical chunk fetched by this lane
-    const char* wsrc[4];
-    const char* asrc[4];
-    int iy0[4], ix0[4], ibase[4];
+    const char* wsrc[CF::WPASS];
+    const char* asrc[CF::APASS];
+    int iy0[CF::APASS], ix0[CF::APASS], ibase[CF::APASS];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = q * 32 + lrow;
+    for (int q = 0; q < CF::WPASS; ++q) {
+        const int r = q * CF::PASS_ROWS + lrow;
         wsrc[q] = reinterpret_cast<const char*>(p.wgt) + ((size_t)(n0 + r) * p.K) * EB + lchunk * 16;
+    }
+#pragma unroll
+    for (int q = 0; q < CF::APASS; ++q) {
+        const int r = q * CF::PASS_ROWS + lrow;
         int m = m0 + r;
         m = m < p.M ? m : p.M - 1;
         if (p.amode == AMODE_LINEAR) {
             asrc[q] = reinterpret_cast<const char*>(p.act) + ((size_t)m * p.lda) * EB + lchunk * 16;
+            iy0[q] = ix0[q] = ibase[q] = 0;
         } else {
             const int hw = p.Hout * p.Wout;
             const int b = m / hw, rem = m - b * hw;
@@ -67,83 +97,87 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
     const char* zsrc = reinterpret_cast<const char*>(p.zero_page) + lchunk * 16;
 
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lds0 = lds_addr(smem) + wave_u * 1024;   // wave-uniform: one 1 KiB DMA piece per wave and pass
     auto stage = [&](int kt, int buf) {
-        char* sb = smem + buf * STAGE_BYTES;
+        const uint32_t sb = lds0 + buf * STAGE_BYTES;
         const size_t koff = (size_t)kt * KTB;
         if (p.amode == AMODE_LINEAR) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + koff), (lptr_t)(sb + (q * 4 + wave) * 1024), 16, 0, 0);
+            for (int q = 0; q < CF::APASS; ++q) glds16(asrc[q] + koff, sb + q * (CF::NW * 1024));
         } else {
             const int kel = kt * KT;
             const int tap = kel / p.Cin, c0 = kel - tap * p.Cin;
             const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < CF::APASS; ++q) {
                 const int iy = iy0[q] + ky, ix = ix0[q] + kx;
                 const bool ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
                 const char* src = reinterpret_cast<const char*>(p.act) +
                                   ((size_t)(ibase[q] + iy * p.Win + ix) * p.cstride + c0) * EB + lchunk * 16;
                 src = ok ? src : zsrc;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (q * 4 + wave) * 1024), 16, 0, 0);
+                glds16(src, sb + q * (CF::NW * 1024));
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[q] + koff), (lptr_t)(sb + BM * KTB + (q * 4 + wave) * 1024), 16, 0, 0);
+        for (int q = 0; q < CF::WPASS; ++q) glds16(wsrc[q] + koff, sb + BM * KTB + q * (CF::NW * 1024));
     };
 
     // ---- fragment read addresses ---------------------------------------------------------------
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = wave / CF::NWJ, wj = wave - wi * CF::NWJ;
     const int frow = lane & 15, fsw = (lane >> 1) & 7, fgrp = lane >> 4;
     // P tile supplies i (4 consecutive per lane), Q tile supplies j
     const int p_off = swap ? 0 : BM * KTB;  // activations live at 0, weights at BM*KTB
     const int q_off = swap ? BM * KTB : 0;
+    const int p_row0 = wi * (FI * 16) + frow, q_row0 = wj * (FJ * 16) + frow;
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[FI][FJ];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < FI; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < FJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // K loop, two LDS stages: [wait own DMA of tile kt] -> barrier (tile kt visible to every wave, every wave is done
+    // reading the other stage) -> issue the DMA of tile kt+1 into the other stage -> math on tile kt. The DMA of tile
+    // kt+1 is in flight during the whole math of tile kt.
     const int nk = p.K / KT;
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        __syncthreads();  // compiler drains vmcnt here: tile kt has landed; buf^1 is free again
+        d3r_wait_vm0();
+        __syncthreads();
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
         const char* sb = smem + buf * STAGE_BYTES;
         if constexpr (DT == D3R_F16X3) {
             // 128 bytes of a row = 32 logical k = 4 groups [hi x8][lo x8]; lane group fgrp owns group fgrp
             const int chi = ((2 * fgrp) ^ fsw) * 16, clo = ((2 * fgrp + 1) ^ fsw) * 16;
-            uint4 pf[4], pl[4], qf[4], ql[4];
+            uint4 qf[FJ], ql[FJ];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const char* pr = sb + p_off + (wi * 64 + f * 16 + frow) * KTB;
-                const char* qr = sb + q_off + (wj * 64 + f * 16 + frow) * KTB;
-                pf[f] = *reinterpret_cast<const uint4*>(pr + chi);
-                pl[f] = *reinterpret_cast<const uint4*>(pr + clo);
+            for (int f = 0; f < FJ; ++f) {
+                const char* qr = sb + q_off + (q_row0 + f * 16) * KTB;
                 qf[f] = *reinterpret_cast<const uint4*>(qr + chi);
                 ql[f] = *reinterpret_cast<const uint4*>(qr + clo);
             }
 #pragma unroll
-            for (int fi = 0; fi < 4; ++fi)
+            for (int fi = 0; fi < FI; ++fi) {
+                const char* pr = sb + p_off + (p_row0 + fi * 16) * KTB;
+                const uint4 pf = *reinterpret_cast<const uint4*>(pr + chi), pl = *reinterpret_cast<const uint4*>(pr + clo);
 #pragma unroll
-                for (int fj = 0; fj < 4; ++fj) TR::mma16x3(acc[fi][fj], pf[fi], pl[fi], qf[fj], ql[fj]);
+                for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], pf, pl, qf[fj], ql[fj]);
+            }
         } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
-                uint4 pf[4], qf[4];
+                uint4 pf[FI], qf[FJ];
 #pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    pf[f] = *reinterpret_cast<const uint4*>(sb + p_off + (wi * 64 + f * 16 + frow) * KTB + coff);
-                    qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (wj * 64 + f * 16 + frow) * KTB + coff);
-                }
+                for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (q_row0 + f * 16) * KTB + coff);
 #pragma unroll
-                for (int fi = 0; fi < 4; ++fi)
+                for (int f = 0; f < FI; ++f) pf[f] = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + f * 16) * KTB + coff);
 #pragma unroll
-                    for (int fj = 0; fj < 4; ++fj) TR::mma16(acc[fi][fj], pf[fi], qf[fj]);
+                for (int fi = 0; fi < FI; ++fi)
+#pragma unroll
+                    for (int fj = 0; fj < FJ; ++fj) TR::mma16(acc[fi][fj], pf[fi], qf[fj]);
             }
         }
     }
@@ -152,55 +186,60 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int i4 = (lane >> 4) * 4;  // first of this lane's 4 consecutive i inside a fragment
     const int jl = lane & 15;
     if (!swap) {
-        const int nb = n0 + wi * 64, mb = m0 + wj * 64;
+        const int nb = n0 + wi * (FI * 16), mb = m0 + wj * (FJ * 16);
         if (p.epi == EPI_HEADS) {
-            // q / k projections: bias, 2-D RoPE on the fp32 accumulator, head-major store
-            const int region = nb / p.head_c;
-            const int h = (nb - region * p.head_c) >> 6;
-            void* dst = p.head_dst[region];
-            const bool rope = p.head_kind[region] == HEAD_ROPE;
-            float4 bias[4];
+            // q / k projections: bias, 2-D RoPE on the fp32 accumulator, head-major store. A wave's n range holds FI/4 heads.
 #pragma unroll
-            for (int fi = 0; fi < 4; ++fi)
-                bias[fi] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb + fi * 16 + i4) : make_float4(0, 0, 0, 0);
+            for (int hb = 0; hb < FI / 4; ++hb) {
+                const int nh = nb + hb * 64;
+                if (nh >= p.n_store) continue;
+                const int region = nh / p.head_c;
+                const int h = (nh - region * p.head_c) >> 6;
+                void* dst = p.head_dst[region];
+                const bool rope = p.head_kind[region] == HEAD_ROPE;
+                float4 bias[4];
 #pragma unroll
-            for (int fj = 0; fj < 4; ++fj) {
-                const int m = mb + fj * 16 + jl;
-                if (m >= p.M) continue;
-                const int b = m / p.ntok, t = m - b * p.ntok;
-                const int ty = t / p.tok_w, tx = t - ty * p.tok_w;
-                const size_t obase = ((size_t)(b * p.heads + h) * p.ntok + t) * 64;
+                for (int fi = 0; fi < 4; ++fi)
+                    bias[fi] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nh + fi * 16 + i4) : make_float4(0, 0, 0, 0);
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    f32x4_t u = acc[half * 2][fj], v = acc[half * 2 + 1][fj];
-                    const float4 bu = bias[half * 2], bv = bias[half * 2 + 1];
-                    float uu[4] = {u[0] + bu.x, u[1] + bu.y, u[2] + bu.z, u[3] + bu.w};
-                    float vv[4] = {v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w};
-                    if (rope) {
-                        const int pos = half ? tx : ty;
-                        const float4* cs = reinterpret_cast<const float4*>(p.rope_table + ((size_t)pos * 16 + i4) * 2);
-                        const float4 c01 = cs[0], c23 = cs[1];  // (cos0,sin0,cos1,sin1), (cos2,sin2,cos3,sin3)
-                        const float cc[4] = {c01.x, c01.z, c23.x, c23.z}, ss[4] = {c01.y, c01.w, c23.y, c23.w};
+                for (int fj = 0; fj < FJ; ++fj) {
+                    const int m = mb + fj * 16 + jl;
+                    if (m >= p.M) continue;
+                    const int b = m / p.ntok, t = m - b * p.ntok;
+                    const int ty = t / p.tok_w, tx = t - ty * p.tok_w;
+                    const size_t obase = ((size_t)(b * p.heads + h) * p.ntok + t) * 64;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float a = uu[r], bq = vv[r];
-                            uu[r] = a * cc[r] - bq * ss[r];
-                            vv[r] = bq * cc[r] + a * ss[r];
+                    for (int half = 0; half < 2; ++half) {
+                        f32x4_t u = acc[hb * 4 + half * 2][fj], v = acc[hb * 4 + half * 2 + 1][fj];
+                        const float4 bu = bias[half * 2], bv = bias[half * 2 + 1];
+                        float uu[4] = {u[0] + bu.x, u[1] + bu.y, u[2] + bu.z, u[3] + bu.w};
+                        float vv[4] = {v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w};
+                        if (rope) {
+                            const int pos = half ? tx : ty;
+                            const float4* cs = reinterpret_cast<const float4*>(p.rope_table + ((size_t)pos * 16 + i4) * 2);
+                            const float4 c01 = cs[0], c23 = cs[1];  // (cos0,sin0,cos1,sin1), (cos2,sin2,cos3,sin3)
+                            const float cc[4] = {c01.x, c01.z, c23.x, c23.z}, ss[4] = {c01.y, c01.w, c23.y, c23.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float a = uu[r], bq = vv[r];
+                                uu[r] = a * cc[r] - bq * ss[r];
+                                vv[r] = bq * cc[r] + a * ss[r];
+                            }
                         }
+                        store4<DT>(dst, obase + half * 32 + i4, uu[0], uu[1], uu[2], uu[3]);
+                        store4<DT>(dst, obase + half * 32 + 16 + i4, vv[0], vv[1], vv[2], vv[3]);
                     }
-                    store4<DT>(dst, obase + half * 32 + i4, uu[0], uu[1], uu[2], uu[3]);
-                    store4<DT>(dst, obase + half * 32 + 16 + i4, vv[0], vv[1], vv[2], vv[3]);
                 }
             }
             return;
         }
 #pragma unroll
-        for (int fi = 0; fi < 4; ++fi) {
+        for (int fi = 0; fi < FI; ++fi) {
             const int n = nb + fi * 16 + i4;
             if (n >= p.n_store) continue;
             const float4 bias = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
 #pragma unroll
-            for (int fj = 0; fj < 4; ++fj) {
+            for (int fj = 0; fj < FJ; ++fj) {
                 const int m = mb + fj * 16 + jl;
                 if (m >= p.M) continue;
                 const f32x4_t a = acc[fi][fj];
@@ -245,17 +284,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             }
         }
     } else {
-        // V^T tiles: lane owns 4 consecutive tokens (i = m) of one feature (j = n)
-        const int mb = m0 + wi * 64, nb = n0 + wj * 64;
+        // V^T tiles: lane owns 4 consecutive tokens (i = m) of one feature (j = n); a wave's n range (FJ*16 = 64) is one head
+        const int mb = m0 + wi * (FI * 16), nb = n0 + wj * (FJ * 16);
+        if (nb >= p.n_store) return;
         const int region = nb / p.head_c;
         const int h = (nb - region * p.head_c) >> 6;
         void* dst = p.head_dst[region];
 #pragma unroll
-        for (int fj = 0; fj < 4; ++fj) {
+        for (int fj = 0; fj < FJ; ++fj) {
             const int dd = fj * 16 + jl;
             const float bias = p.bias ? p.bias[nb + dd] : 0.f;
 #pragma unroll
-            for (int fi = 0; fi < 4; ++fi) {
+            for (int fi = 0; fi < FI; ++fi) {
                 const int m = mb + fi * 16 + i4;
                 if (m >= p.M) continue;
                 const f32x4_t a = acc[fi][fj];
@@ -277,21 +317,63 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
 }
 
-template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
+// ---- host side: configuration choice + launch ------------------------------------------------------------------
+template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<DT, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
         attr_set = true;
     }
-    const int grid = cdiv(p.M, BM) * (p.n_pad / BN);
-    hipLaunchKernelGGL(gemm_kernel<DT>, dim3(grid), dim3(256), GEMM_LDS, s, p);
+    const int grid = cdiv(p.M, CF::BM) * cdiv(p.n_store, CF::BN);
+    hipLaunchKernelGGL((gemm_kernel<DT, CF>), dim3(grid), dim3(CF::NT), CF::LDS, s, p);
     return hipGetLastError();
+}
+
+// Estimated cost of a configuration: rounds of concurrently resident tiles x tile area / relative tile efficiency
+// (bigger tiles move fewer LDS bytes per MFMA). 256 CUs; 256-class tiles run 1 block per CU, 128x128 two.
+static double cfg_cost(int M, int N, int bm, int bn, int blocks_per_cu, double eff) {
+    const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
+    const long slots = 256L * blocks_per_cu;
+    const long rounds = (tiles + slots - 1) / slots;
+    return (double)rounds * bm * bn * blocks_per_cu / eff;   // a round of co-resident blocks shares the CU's MFMA pipes
+}
+
+int gemm_pick_config(const GemmParams& p) {
+    const int n_rows = p.n_rows > 0 ? p.n_rows : p.n_pad;
+    const bool heads = p.epi == EPI_HEADS;
+    const bool ok256 = cdiv(p.n_store, 256) * 256 <= n_rows && (!heads || p.head_c % 256 == 0);
+    int forced = p.force_cfg;
+    if (forced < 0) {   // D3R_GEMM_CFG=0|1|2 pins the tile configuration (parity tests, probes); infeasible choices are ignored
+        const char* e = getenv("D3R_GEMM_CFG");
+        if (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) forced = e[0] - '0';
+    }
+    if (forced == GEMM_CFG_128 || (forced == GEMM_CFG_256 && ok256) || (forced == GEMM_CFG_256x128 && !heads)) return forced;
+    double best = cfg_cost(p.M, p.n_store, 128, 128, 2, 1.0);
+    int pick = GEMM_CFG_128;
+    if (ok256) {
+        const double c = cfg_cost(p.M, p.n_store, 256, 256, 1, 1.25);
+        if (c < best) { best = c; pick = GEMM_CFG_256; }
+    }
+    if (!heads) {
+        const double c = cfg_cost(p.M, p.n_store, 256, 128, 1, 1.1);
+        if (c < best) { best = c; pick = GEMM_CFG_256x128; }
+    }
+    return pick;
+}
+
+template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
+    switch (gemm_pick_config(p)) {
+        case GEMM_CFG_256: return launch_cfg<DT, Cfg256>(p, s);
+        case GEMM_CFG_256x128: return launch_cfg<DT, Cfg256x128>(p, s);
+        default: return launch_cfg<DT, Cfg128>(p, s);
+    }
 }
 
 hipError_t launch_gemm(int dt, const GemmParams& p, hipStream_t s) {
     const int kt = KTB / (int)dt_bytes(dt);
-    if (p.M <= 0 || p.n_pad % BN != 0 || p.K % kt != 0 || p.K <= 0) return hipErrorInvalidValue;
+    if (p.M <= 0 || p.n_pad % 128 != 0 || p.n_store > p.n_pad || p.K % kt != 0 || p.K <= 0) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV && (p.Cin % kt != 0 || p.zero_page == nullptr)) return hipErrorInvalidValue;
+    if (p.epi == EPI_HEADS && p.head_c % 128 != 0 && p.head_c < (1 << 29)) return hipErrorInvalidValue;
     switch (dt) {
         case D3R_BF16: return launch_t<D3R_BF16>(p, s);
         case D3R_F16: return launch_t<D3R_F16>(p, s);

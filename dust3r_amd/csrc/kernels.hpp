@@ -9,12 +9,15 @@ enum { AMODE_LINEAR = 0, AMODE_CONV = 1 };
 enum { EPI_T = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_HEADS = 3, EPI_CONVT = 4 };
 enum { HEAD_ROPE = 1, HEAD_VT = 2, HEAD_PLAIN = 3 };
 enum { GF_RELU = 1 };
+enum { GEMM_CFG_128 = 0, GEMM_CFG_256 = 1, GEMM_CFG_256x128 = 2 };
 
 struct GemmParams {
     const void* act = nullptr;   // [M][lda] (linear) or NHWC image batch (conv), element type DT
     const void* wgt = nullptr;   // [n_pad][K], element type DT, rows >= N zero filled
     const float* bias = nullptr; // [n_pad] or null
-    int M = 0, K = 0, n_pad = 0; // K in elements, multiple of 128/sizeof(DT)
+    int M = 0, K = 0, n_pad = 0; // K in elements, multiple of 128/sizeof(DT); n_pad: multiple of 128, >= n_store
+    int n_rows = 0;              // weight rows actually allocated (>= n_pad; 0 = n_pad): bounds the tile width choice
+    int force_cfg = -1;          // GEMM_CFG_* to override the heuristic (tests / probes)
     int n_store = 0;             // columns written (multiple of 4, <= n_pad)
     int lda = 0;
     int amode = AMODE_LINEAR;
@@ -37,6 +40,7 @@ struct GemmParams {
 };
 
 hipError_t launch_gemm(int dt, const GemmParams& p, hipStream_t s);
+int gemm_pick_config(const GemmParams& p);
 
 // ------------------------------------------------------------------------------ attention
 struct AttnParams {

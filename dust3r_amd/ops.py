@@ -34,7 +34,7 @@ def layernorm(x, gamma, beta, eps=1e-6, dtype=torch.bfloat16):
     return out
 
 
-def pad_rows(w, mult=128):
+def pad_rows(w, mult=256):
     n = w.shape[0]
     n_pad = (n + mult - 1) // mult * mult
     if n_pad == n:
@@ -56,7 +56,7 @@ def linear(act, weight, bias=None, epilogue='store', residual=None):
 
 
 def pack_conv_weight(w):
-    """torch (Cout, Cin, kh, kw) -> (round_up(Cout,128), kh*kw*Cin) with K index (ky, kx, cin)."""
+    """torch (Cout, Cin, kh, kw) -> (round_up(Cout,256), kh*kw*Cin) with K index (ky, kx, cin)."""
     return pad_rows(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
 
 

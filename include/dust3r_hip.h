@@ -59,12 +59,13 @@ int d3r_rope2d(void* tokens, const int64_t* positions, int B, int N, int H, int 
 int d3r_layernorm(const float* x, const float* gamma, const float* beta, void* out, int rows, int C, float eps, int dtype, void* stream);
 
 /* out = epilogue(act[M][K] . wgt[N][K]^T + bias): nn.Linear of croco Mlp/Attention (dust3r/model.py:136-137,176-186).
- * act, wgt in `dtype`; wgt must hold n_pad = round_up(N,128) rows (extra rows zero); K % (128/sizeof(dtype)) == 0.
+ * act, wgt in `dtype`; wgt (and bias) must hold round_up(N,256) rows (extra rows zero: the widest tile is 256 columns);
+ * K % (128/sizeof(dtype)) == 0.
  * epilogue: 0 store dtype | 1 fp32 out (+ optional fp32 residual, may alias out) | 2 GELU(erf) store dtype */
 int d3r_linear(const void* act, const void* wgt, const float* bias, void* out, const float* residual, int M, int N, int K,
                int epilogue, int dtype, void* stream);
 
-/* 2-D convolution, NHWC, as implicit GEMM: in [B][Hin][Win][Cin] dtype, wgt [round_up(Cout,128)][k*k*Cin] dtype with
+/* 2-D convolution, NHWC, as implicit GEMM: in [B][Hin][Win][Cin] dtype, wgt [round_up(Cout,256)][k*k*Cin] dtype with
  * K index (ky, kx, cin); out [B][Hout][Wout][Cout] dtype = [relu](conv + bias + res1 + res2)   (DPT head convs,
  * dust3r/heads/dpt_head.py:34-65). zero_page: >= 256 bytes of zeros. */
 int d3r_conv2d_nhwc(const void* in, const void* wgt, const float* bias, void* out, const void* res1, const void* res2,

@@ -74,6 +74,19 @@ def test_forward_matches_oracle(gpu, precision, config, B, H, W):
     compare(eng, oracle, v1, v2, *TOLS[precision], tag=f'{config} {precision} {B}x{H}x{W}')
 
 
+@pytest.mark.parametrize('cfg', ['0', '1', '2'])
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+def test_forward_with_pinned_gemm_tile(gpu, precision, cfg, monkeypatch):
+    """The whole network with the GEMM tile configuration pinned (D3R_GEMM_CFG): the 256-wide tiles' q/k RoPE scatter,
+    V^T role swap and implicit-GEMM paths must give the same pointmaps as the 128x128 tiles (all <= 1e-3 vs the oracle)."""
+    from oracle.dust3r_ref import build_ref_model
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg)
+    oracle = build_ref_model('tiny_dpt')
+    eng = engine_from_oracle(oracle, 'tiny_dpt', precision, gpu)
+    v1, v2 = synthetic_views(3, 64, 96, seed=5)
+    compare(eng, oracle, v1, v2, *TOLS[precision], tag=f'tiny_dpt {precision} cfg{cfg}')
+
+
 @pytest.mark.parametrize('name', ['forward_tiny_dpt.pt', 'forward_tiny_linear.pt'])
 def test_forward_matches_reference_golden(gpu, name):
     """fp32 engine against vectors produced by the unmodified reference files (oracle/make_golden.py)."""

@@ -74,6 +74,28 @@ def test_conv2d_nhwc(gpu, dtype, B, H, W, Cin, Cout, k, stride, pad):
     assert relerr(out, (ref - b).clamp_min(0)) < OUT_TOL[dtype]
 
 
+@pytest.mark.parametrize('cfg', ['0', '1', '2'])
+def test_gemm_tile_configurations(gpu, cfg, monkeypatch):
+    """Every tile configuration of the GEMM template (128x128, 256x256, 256x128) on shapes with ragged M / N edges,
+    K long enough to cycle both LDS stages many times, linear and implicit-GEMM convolution operands."""
+    from dust3r_amd import ops
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg)
+    g = torch.Generator(device='cpu').manual_seed(17)
+    for dtype in (torch.bfloat16, torch.float32):
+        for (M, N, K) in [(1000, 768, 1024), (515, 320, 256), (2048, 1024, 4096 if dtype == torch.bfloat16 else 512)]:
+            a = torch.randn((M, K), generator=g).to(gpu).to(dtype)
+            w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(gpu).to(dtype)
+            b = torch.randn(N, generator=g).to(gpu)
+            ref = a.float() @ w.float().T + b
+            assert relerr(ops.linear(a, w, b, 'f32'), ref) < 2e-5, (cfg, dtype, M, N, K)
+            assert relerr(ops.linear(a, w, b, 'gelu'), F.gelu(ref)) < OUT_TOL[dtype]
+        x = torch.randn((2, 21, 32, 128), generator=g).to(gpu).to(dtype)
+        w = (torch.randn((256, 128, 3, 3), generator=g) / math.sqrt(128 * 9)).to(gpu).to(dtype)
+        b = torch.randn(256, generator=g).to(gpu)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b, stride=1, padding=1).permute(0, 2, 3, 1)
+        assert relerr(ops.conv2d_nhwc(x, w, b, stride=1, pad=1), ref) < OUT_TOL[dtype]
+
+
 def _attention_ref(q, k, v, scale):
     a = (q.float() @ k.float().transpose(-1, -2)) * scale
     return (a.softmax(-1) @ v.float()).transpose(1, 2).flatten(2)
