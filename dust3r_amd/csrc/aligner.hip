@@ -97,41 +97,75 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
 
     const int slot = chunk * 4 + wave;
     const int a0 = a.adj_off[img], a1 = a.adj_off[img + 1];
-    for (int ai = a0; ai < a1; ++ai) {
-        const int es = a.adj_es[ai];
-        const int e = es >> 1, side = es & 1;
-        const float* Mp = a.d_edge + e * 12;
-        float M[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) M[k] = Mp[k];
-        float gm[12], loss = 0.f;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) gm[k] = 0.f;
-        if (active) {
-            const float4* pp = reinterpret_cast<const float4*>(a.pred[side] + ((size_t)e * a.maxA + p0) * 3);
-            const float4 q0 = pp[0], q1 = pp[1], q2 = pp[2];
-            const float4 ww = *reinterpret_cast<const float4*>(a.wgt[side] + (size_t)e * a.maxA + p0);
-            const float pr[PPT][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, {q1.z, q1.w, q2.x}, {q2.y, q2.z, q2.w}};
-            const float wv[PPT] = {ww.x * a.inv_area[side], ww.y * a.inv_area[side], ww.z * a.inv_area[side], ww.w * a.inv_area[side]};
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) residual_accumulate(X[k], M, pr[k], wv[k], a.l2 != 0, loss, g[k], gm);
+    // Edge walk. The adjacency entries and the 3x4 matrices of up to EBATCH incident edge sides are staged in LDS first,
+    // so that inside the walk the ONLY vector-memory traffic is the pred / weight stream (and the partial stores): any
+    // other in-loop global load would force an in-order vmcnt wait that drains the prefetch. The stream is software
+    // pipelined: the 64 bytes per lane of edge j+1 are requested before the math of edge j.
+    constexpr int EBATCH = 64;
+    __shared__ int sh_es[EBATCH];
+    __shared__ __attribute__((aligned(16))) float sh_M[EBATCH][12];
+    const int pl = active ? p0 : 0;   // inactive lanes (beyond maxA in the last chunk) stream pixel 0 and discard it
+    for (int base = a0; base < a1; base += EBATCH) {
+        const int nb = min(EBATCH, a1 - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb * 12; i += 256) {
+            const int j = i / 12, k = i - j * 12;
+            const int es = a.adj_es[base + j];
+            if (k == 0) sh_es[j] = es;
+            sh_M[j][k] = a.d_edge[(es >> 1) * 12 + k];
         }
-        float red[13];
-        if (a.use_dpp) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) red[k] = wave_sum_dpp(gm[k]);
-            red[12] = wave_sum_dpp(loss);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) red[k] = wave_sum_shfl(gm[k]);
-            red[12] = wave_sum_shfl(loss);
+        __syncthreads();
+        float4 nq0, nq1, nq2, nww;
+        {
+            const int es = sh_es[0];
+            const float4* pp = reinterpret_cast<const float4*>(a.pred[es & 1] + ((size_t)(es >> 1) * a.maxA + pl) * 3);
+            nq0 = pp[0]; nq1 = pp[1]; nq2 = pp[2];
+            nww = *reinterpret_cast<const float4*>(a.wgt[es & 1] + (size_t)(es >> 1) * a.maxA + pl);
         }
-        if (lane == 63) {
-            float4* dst = reinterpret_cast<float4*>(a.part_edge + ((size_t)es * a.nslot + slot) * PW);
-            dst[0] = make_float4(red[0], red[1], red[2], red[3]);
-            dst[1] = make_float4(red[4], red[5], red[6], red[7]);
-            dst[2] = make_float4(red[8], red[9], red[10], red[11]);
-            dst[3] = make_float4(red[12], 0.f, 0.f, 0.f);
+        for (int j = 0; j < nb; ++j) {
+            const int es = sh_es[j];
+            const int side = es & 1;
+            const float4 q0 = nq0, q1 = nq1, q2 = nq2, ww = nww;
+            {   // unconditional (index clamped): a branch here would make the compiler wait for the loads at its join
+                const int es2 = sh_es[j + 1 < nb ? j + 1 : j];
+                const float4* pp = reinterpret_cast<const float4*>(a.pred[es2 & 1] + ((size_t)(es2 >> 1) * a.maxA + pl) * 3);
+                nq0 = pp[0]; nq1 = pp[1]; nq2 = pp[2];
+                nww = *reinterpret_cast<const float4*>(a.wgt[es2 & 1] + (size_t)(es2 >> 1) * a.maxA + pl);
+            }
+            float M[12];
+            {
+                const float4* Mp = reinterpret_cast<const float4*>(sh_M[j]);
+                const float4 m0 = Mp[0], m1 = Mp[1], m2 = Mp[2];
+                M[0] = m0.x; M[1] = m0.y; M[2] = m0.z; M[3] = m0.w; M[4] = m1.x; M[5] = m1.y; M[6] = m1.z; M[7] = m1.w;
+                M[8] = m2.x; M[9] = m2.y; M[10] = m2.z; M[11] = m2.w;
+            }
+            float gm[12], loss = 0.f;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) gm[k] = 0.f;
+            {
+                const float pr[PPT][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, {q1.z, q1.w, q2.x}, {q2.y, q2.z, q2.w}};
+                const float ia = active ? a.inv_area[side] : 0.f;   // zero weight: inactive lanes contribute nothing
+                const float wv[PPT] = {ww.x * ia, ww.y * ia, ww.z * ia, ww.w * ia};
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) residual_accumulate(X[k], M, pr[k], wv[k], a.l2 != 0, loss, g[k], gm);
+            }
+            float red[13];
+            if (a.use_dpp) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) red[k] = wave_sum_dpp(gm[k]);
+                red[12] = wave_sum_dpp(loss);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) red[k] = wave_sum_shfl(gm[k]);
+                red[12] = wave_sum_shfl(loss);
+            }
+            if (lane == 63) {
+                float4* dst = reinterpret_cast<float4*>(a.part_edge + ((size_t)es * a.nslot + slot) * PW);
+                dst[0] = make_float4(red[0], red[1], red[2], red[3]);
+                dst[1] = make_float4(red[4], red[5], red[6], red[7]);
+                dst[2] = make_float4(red[8], red[9], red[10], red[11]);
+                dst[3] = make_float4(red[12], 0.f, 0.f, 0.f);
+            }
         }
     }
 
@@ -223,21 +257,29 @@ D3R_DEV float pw_scale_factor(const SmallView& s, double mean_p7) {
     return s.norm_pw_scale ? expf(logf(s.base_scale) - (float)mean_p7) : 1.0f;
 }
 
-// single workgroup; E and n are a few hundred at most per call site (E <= 600)
+// fixed-order block sum (256 threads): wave butterfly in fp64, then the four wave totals in wave order
+D3R_DEV double block_sum_f64(double v, double* sh4) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+}
+
+// single workgroup; E and n are a few hundred at most per call site (E <= 600). Every sum over edges is
+// a block reduction (thread t owns edges t, t+256, ...): no thread-0 serial chains of dependent L2 loads.
 __global__ __launch_bounds__(256) void aligner_small_kernel(SmallView s) {
-    __shared__ double sh_sum;
-    __shared__ double sh_mean;
+    __shared__ double sh4[4];
     const int tid = threadIdx.x;
     if (s.update || s.g_pw) {
         // mean of P7 BEFORE the update defines the s~ the gradients were taken at
-        if (tid == 0) {
-            double m = 0.0;
-            for (int e = 0; e < s.E; ++e) m += (double)s.pw_poses[e * 8 + 7];
-            sh_mean = m / (double)s.E;
-        }
-        __syncthreads();
-        const float nf = pw_scale_factor(s, sh_mean);
-        // pass 1: dL/ds~_e * s~_e
+        double acc = 0.0;
+        for (int e = tid; e < s.E; e += 256) acc += (double)s.pw_poses[e * 8 + 7];
+        const double mean7 = block_sum_f64(acc, sh4) / (double)s.E;
+        const float nf = pw_scale_factor(s, mean7);
+        // pass 1: dL/ds~_e * s~_e (kept in scratch) and its sum over edges; loss = sum of the per-side partials
+        double gsum = 0.0, lsum = 0.0;
         for (int e = tid; e < s.E; e += 256) {
             const float* P = s.pw_poses + e * 8;
             float R[9];
@@ -254,19 +296,12 @@ __global__ __launch_bounds__(256) void aligner_small_kernel(SmallView s) {
             for (int k = 0; k < 12; ++k) GM[k] = s.red_edge[(size_t)(2 * e) * PW + k] + s.red_edge[(size_t)(2 * e + 1) * PW + k];
             edge_chain(P, R, st, adapt, GM, gP, gs);
             s.scratch[e] = gs * (double)st;
+            gsum += gs * (double)st;
+            lsum += s.red_edge[(size_t)(2 * e) * PW + 12] + s.red_edge[(size_t)(2 * e + 1) * PW + 12];
         }
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-            for (int e = 0; e < s.E; ++e) t += s.scratch[e];
-            sh_sum = t;
-            if (s.loss_hist) {
-                double l = 0.0;
-                for (int k = 0; k < 2 * s.E; ++k) l += s.red_edge[(size_t)k * PW + 12];
-                s.loss_hist[s.iter] = (float)l;
-            }
-        }
-        __syncthreads();
+        const double sum_gs = block_sum_f64(gsum, sh4);
+        const double loss = block_sum_f64(lsum, sh4);
+        if (tid == 0 && s.loss_hist) s.loss_hist[s.iter] = (float)loss;
         // pass 2: gradients + Adam on pairwise poses
         for (int e = tid; e < s.E; e += 256) {
             float* P = s.pw_poses + e * 8;
@@ -283,7 +318,7 @@ __global__ __launch_bounds__(256) void aligner_small_kernel(SmallView s) {
             double GM[12], gP[8], gs;
             for (int k = 0; k < 12; ++k) GM[k] = s.red_edge[(size_t)(2 * e) * PW + k] + s.red_edge[(size_t)(2 * e + 1) * PW + k];
             edge_chain(P, R, st, adapt, GM, gP, gs);
-            gP[7] = s.scratch[e] - (s.norm_pw_scale ? sh_sum / (double)s.E : 0.0);
+            gP[7] = s.scratch[e] - (s.norm_pw_scale ? sum_gs / (double)s.E : 0.0);
             if (s.g_pw)
                 for (int k = 0; k < 8; ++k) s.g_pw[e * 8 + k] = (float)gP[k];
             if (s.update)
@@ -305,16 +340,12 @@ __global__ __launch_bounds__(256) void aligner_small_kernel(SmallView s) {
                 for (int k = 0; k < 7; ++k) P[k] = adam_update(P[k], (float)gP[k], s.imp_m[i * 7 + k], s.imp_v[i * 7 + k], s.adam);
             if (s.update && s.opt_focals) s.im_focals[i] = adam_update(s.im_focals[i], (float)gf, s.foc_m[i], s.foc_v[i], s.adam);
         }
-        __syncthreads();
+        __syncthreads();   // the updated P7 values are read by other threads below
     }
     // ---- derived quantities for the next main pass ---------------------------------------------------
-    if (tid == 0) {
-        double m = 0.0;
-        for (int e = 0; e < s.E; ++e) m += (double)s.pw_poses[e * 8 + 7];
-        sh_mean = m / (double)s.E;
-    }
-    __syncthreads();
-    const float nf = pw_scale_factor(s, sh_mean);
+    double acc2 = 0.0;
+    for (int e = tid; e < s.E; e += 256) acc2 += (double)s.pw_poses[e * 8 + 7];
+    const float nf = pw_scale_factor(s, block_sum_f64(acc2, sh4) / (double)s.E);
     for (int e = tid; e < s.E; e += 256) {
         const float* P = s.pw_poses + e * 8;
         float R[9];

@@ -26,25 +26,37 @@ def timeit(fn, warm=3, reps=10):
 
 
 def gemm_probe():
-    print('== GEMM (bf16), ms and TFLOP/s')
-    for (M, N, K) in [(49152, 3072, 1024), (49152, 1024, 1024), (49152, 4096, 1024), (49152, 1024, 4096), (24576, 2304, 768),
-                      (24576, 3072, 768), (24576, 768, 3072), (4096, 4096, 4096), (8192, 8192, 8192)]:
-        for dt in (torch.bfloat16, torch.float16, torch.float32):
+    import os
+    print('== GEMM: ms and TFLOP/s per tile configuration (D3R_GEMM_CFG: 0 = 128x128, 1 = 256x256, 2 = 256x128, auto = heuristic)')
+    from dust3r_amd._lib import lib, ptr, current_stream, check
+    shapes = [(49152, 3072, 1024), (49152, 1024, 1024), (49152, 4096, 1024), (49152, 1024, 4096), (24576, 2304, 768), (24576, 768, 768),
+              (24576, 3072, 768), (24576, 768, 3072), (4096, 4096, 4096), (8192, 8192, 8192)]
+    for (M, N, K) in shapes:
+        for dt in (torch.bfloat16, torch.float32):
             if dt == torch.float32 and M * N * K > 2e11:
                 continue
             a = torch.randn((M, K), device=dev).to(dt)
             w = ops.pad_rows((torch.randn((N, K), device=dev) / math.sqrt(K)).to(dt))
-            b = torch.randn(N, device=dev)
+            b = ops.pad_rows(torch.randn(N, device=dev))
             out = torch.empty((M, N), dtype=dt, device=dev)
-            from dust3r_amd._lib import lib, ptr, current_stream, check
 
             def run():
                 check(lib.d3r_linear(ptr(a), ptr(w), ptr(b), ptr(out), None, M, N, K, 0, ops._dt(a), current_stream()))
-            ms = timeit(run)
-            print(f'  M={M} N={N} K={K} {str(dt)[6:]:9s} {ms:8.3f} ms  {2 * M * N * K / ms / 1e9:8.1f} TF/s')
+            line = f'  M={M} N={N} K={K} {str(dt)[6:]:9s}'
+            for cfg in (('0', '1', '2', None) if dt == torch.bfloat16 else (None,)):
+                if cfg is None:
+                    os.environ.pop('D3R_GEMM_CFG', None)
+                else:
+                    os.environ['D3R_GEMM_CFG'] = cfg
+                ms = timeit(run)
+                line += f' | cfg {cfg or "auto"}: {ms:7.3f} ms {2 * M * N * K / ms / 1e9:7.1f} TF/s'
+            os.environ.pop('D3R_GEMM_CFG', None)
             if dt == torch.bfloat16:
                 ms2 = timeit(lambda: torch.nn.functional.linear(a, w[:N], None))
-                print(f'      (torch/hipBLASLt same shape: {ms2:8.3f} ms  {2 * M * N * K / ms2 / 1e9:8.1f} TF/s)')
+                line += f' | hipBLASLt {ms2:7.3f} ms {2 * M * N * K / ms2 / 1e9:7.1f} TF/s'
+            print(line)
+    from oracle import tune_threads
+    print('cpu threads chosen:', tune_threads(verbose=True))
 
 
 def attn_probe():
@@ -76,7 +88,7 @@ def forward_probe():
     m.set_precision('fp32')
     r1, r2 = m(v1, v2)
     ref = [r1['pts3d'].clone(), r2['pts3d_in_other_view'].clone(), r1['conf'].clone()]
-    for prec in ('fp16', 'bf16'):
+    for prec in ('fp16x3', 'fp16', 'bf16'):
         m.set_precision(prec)
         e1, e2 = m(v1, v2)
         for name, a, b in (('pts1', e1['pts3d'], ref[0]), ('pts2', e2['pts3d_in_other_view'], ref[1])):
@@ -84,9 +96,9 @@ def forward_probe():
             print(f'  {prec} vs fp32-engine {name}: rel err max {float(rel.max()):.3e} p99 {float(rel.flatten().quantile(0.99)):.3e} mean {float(rel.mean()):.3e}')
         rc = ((e1['conf'] - ref[2]).abs() / ref[2]).max()
         print(f'  {prec} vs fp32-engine conf1: rel err max {float(rc):.3e}')
-    for prec in ('bf16', 'fp16', 'fp32'):
+    for prec in ('bf16', 'fp16x3', 'fp32'):
         m.set_precision(prec)
-        for B in ((1, 4, 16, 32) if prec != 'fp32' else (1, 4)):
+        for B in ((1, 8, 32) if prec != 'fp32' else (4,)):
             v1, v2 = synthetic_views(B, 384, 512, seed=0, device=dev)
             ms = timeit(lambda: m(v1, v2), warm=2, reps=3 if B >= 16 else 5)
             print(f'  {prec} B={B:3d}: {ms:9.2f} ms/forward  {B / ms * 1e3:8.2f} pairs/s  {B * 1856.8 / ms:8.1f} TF/s eff  mem {m.device_bytes() / 2**30:.1f} GiB')
