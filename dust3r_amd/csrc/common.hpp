@@ -193,6 +193,20 @@ D3R_DEV uint32_t lds_addr(const void* p) {
 }
 
 D3R_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. below the rounding of every 16-bit and split-16-bit
+// operand type): one v_rcp, one v_exp and six FMAs instead of libm's branchy erff -- the GELU epilogue runs once per
+// accumulator element, 128 times per lane per 256x256 tile. The exact-fp32 mode keeps erff.
+D3R_DEV float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
+    return __builtin_copysignf(r, x);
+}
+template <int DT> D3R_DEV float gelu(float x) {
+    if constexpr (DT == D3R_F32) return gelu_erf(x);
+    else return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+}
 
 // XCD-aware bijective block remap (8 XCDs, block b runs on XCD b % 8): gives each XCD a
 // contiguous range of logical tile ids so neighbouring tiles share operand panels in one L2.

@@ -77,6 +77,10 @@ struct d3r_model {
     void* zero_page = nullptr;
     void* ws = nullptr; size_t ws_bytes = 0;
     void* stage = nullptr; size_t stage_bytes = 0;   // load-time staging of host tensors
+    // the two decoder sides (and the two heads) are independent inside a layer: side 1 runs on this second stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    bool two_streams = true;
     // last forward (debug hook)
     const void* last_encn = nullptr; size_t last_encn_elems = 0;
     // optional per-launch HIP-event timing (d3r_model_set_option(D3R_MODEL_OPT_PROFILE)); off in timed runs
@@ -365,6 +369,8 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     m->zero_page = m->dalloc(4096);
     if (!m->rope_table || !m->zero_page) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
     if (launch_rope_table(m->rope_table, 512, cfg->rope_freq, 1.0f, nullptr) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_LAUNCH; }
+    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
     (void)hipDeviceSynchronize();
     *out = m;
     return D3R_OK;
@@ -374,6 +380,9 @@ extern "C" int d3r_model_destroy(d3r_model* m) {
     if (!m) return D3R_OK;
     for (void* p : m->allocs) (void)hipFree(p);
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
+    if (m->ev_main) (void)hipEventDestroy(m->ev_main);
+    if (m->ev_side) (void)hipEventDestroy(m->ev_side);
+    if (m->side) (void)hipStreamDestroy(m->side);
     if (m->ws) (void)hipFree(m->ws);
     if (m->stage) (void)hipFree(m->stage);
     delete m;
@@ -447,6 +456,7 @@ extern "C" int d3r_model_debug_read(d3r_model* m, int what, float* out, size_t m
 extern "C" int d3r_model_set_option(d3r_model* m, int option, int value) {
     if (!m) return D3R_ERR_INVALID;
     if (option == D3R_MODEL_OPT_PROFILE) { m->prof_on = value != 0; m->prof_rec.clear(); return D3R_OK; }
+    if (option == D3R_MODEL_OPT_TWO_STREAMS) { m->two_streams = value != 0; return D3R_OK; }
     return D3R_ERR_INVALID;
 }
 
@@ -552,6 +562,27 @@ void run_dpt(Ctx& c, const DptHead& D, Arena ar, const void* const hooks[4], con
     if (ar.base && ar.off > ar.cap) c.rc = D3R_ERR_ALLOC;
 }
 
+// bytes of the DPT head arena for `bc` images (the allocation sequence of run_dpt)
+size_t dpt_arena_bytes(const d3r_model* m, const DptHead& D, int bc, int th, int tw) {
+    const size_t eb = dt_bytes(m->dt);
+    const int N = th * tw;
+    const int th2 = (th - 1) / 2 + 1, tw2 = (tw - 1) / 2 + 1;
+    const int Hl[4] = {4 * th, 2 * th, th, th2}, Wl[4] = {4 * tw, 2 * tw, tw, tw2};
+    Arena sub(nullptr, 0);
+    for (int i = 0; i < 4; ++i) sub.take((size_t)bc * Hl[i] * Wl[i] * D.cstride[i] * eb);
+    sub.take((size_t)bc * N * 768 * eb);
+    for (int i = 0; i < 4; ++i) { sub.take((size_t)bc * Hl[i] * Wl[i] * 256 * eb); sub.take((size_t)bc * Hl[i] * Wl[i] * 256 * eb); }
+    for (int i = 0; i < 3; ++i) sub.take((size_t)bc * Hl[0] * Wl[0] * 256 * eb);
+    for (int lvl = 3; lvl >= 0; --lvl) {
+        const int Ho = lvl == 3 ? Hl[2] : 2 * Hl[lvl], Wo = lvl == 3 ? Wl[2] : 2 * Wl[lvl];
+        sub.take((size_t)bc * Ho * Wo * 256 * eb);
+    }
+    sub.take((size_t)bc * 64 * N * 128 * eb);
+    sub.take((size_t)bc * 256 * N * 128 * eb);
+    sub.take((size_t)bc * 256 * N * 128 * eb);
+    return ((sub.off + 255) & ~(size_t)255) + 256;
+}
+
 // returns bytes needed when ws == nullptr (dry run), else runs
 size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1,
                     float* pts2, float* conf2, hipStream_t st, int* rc_out) {
@@ -573,14 +604,28 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
     void* hb = ar.take((size_t)M2 * 4 * Ce * eb);   // MLP hidden; also holds the gathered patches
     void* encn = ar.take((size_t)M2 * Ce * eb);
     float* f[2] = {(float*)ar.take((size_t)M2 * Cd * 4), (float*)ar.take((size_t)M2 * Cd * 4)};
-    void* yn = ar.take((size_t)M1 * Cd * eb);
+    void* yn = ar.take((size_t)M2 * Cd * eb);
     void* hook[2][3];
     for (int s = 0; s < 2; ++s)
         for (int j = 0; j < 3; ++j) hook[s][j] = ar.take((size_t)M1 * Cd * eb);
-    float* lin_out = cf.head_type == 0 ? (float*)ar.take((size_t)M1 * 4 * ps * ps * 4) : nullptr;
-    const size_t common_end = ar.off;
+    float* lin_out = cf.head_type == 0 ? (float*)ar.take((size_t)M2 * 4 * ps * ps * 4) : nullptr;
+    const size_t common_end = (ar.off + 255) & ~(size_t)255;
+    const int chunk = B < 32 ? B : 32;   // 288 GB of HBM: batch the head as wide as the encoder (low-resolution stages need the rows)
+    const size_t head_arena = cf.head_type == 1 ? dpt_arena_bytes(m, m->dpt[0], chunk, th, tw) : 0;
 
     if (!dry) {
+        // stream plan: encoder on the caller's stream; then side 0 stays there and side 1 runs on the model's second
+        // stream, re-joined at every layer boundary (each side reads the other's previous-layer output) and at the end.
+        // Each side has its own half of every scratch buffer and its own head arena.
+        const bool two = m->two_streams && !m->prof_on && m->side != nullptr;
+        hipStream_t S[2] = {st, two ? m->side : st};
+        auto cross_sync = [&]() {
+            if (!two) return;
+            c.chk(hipEventRecord(m->ev_main, S[0]));
+            c.chk(hipEventRecord(m->ev_side, S[1]));
+            c.chk(hipStreamWaitEvent(S[0], m->ev_side, 0));
+            c.chk(hipStreamWaitEvent(S[1], m->ev_main, 0));
+        };
         if (ldv != N) D3R_OTHER(hipMemsetAsync(vt, 0, (size_t)2 * B * He * 64 * ldv * eb, st));
         // ---- encoder: both image batches in one pass (model.py:142-151) ----------------------------------
         const size_t pk = 3 * (size_t)ps * ps;
@@ -600,92 +645,85 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
         m->last_encn = encn; m->last_encn_elems = (size_t)M2 * Ce;
         // ---- decoder (model.py:172-191): side s reads the PREVIOUS layer's (f_s, f_other) ---------------------
         gemm_linear(c, encn, Ce, m->dec_embed, M2, EPI_F32, f[0], Cd);
+        if (two) {
+            c.chk(hipEventRecord(m->ev_main, S[0]));
+            c.chk(hipStreamWaitEvent(S[1], m->ev_main, 0));
+        }
         int cur = 0;
         const int hk6 = cf.dec_depth * 2 / 4, hk9 = cf.dec_depth * 3 / 4;
         for (int l = 0; l < cf.dec_depth; ++l) {
             for (int s = 0; s < 2; ++s) {
+                c.st = S[s];
+                // this side's half of the scratch buffers (the encoder used them whole)
+                void* sxn = (char*)xn + (size_t)s * M1 * Ce * eb;
+                void* sq = (char*)q + (size_t)s * M1 * Ce * eb;
+                void* sk = (char*)k + (size_t)s * M1 * Ce * eb;
+                void* svt = (char*)vt + (size_t)s * B * He * 64 * ldv * eb;
+                void* sao = (char*)ao + (size_t)s * M1 * Ce * eb;
+                void* shb = (char*)hb + (size_t)s * M1 * 4 * Ce * eb;
+                void* syn = (char*)yn + (size_t)s * M1 * Cd * eb;
                 const DecBlk& b = m->dec[s][l];
                 const float* xo = f[cur] + (size_t)s * M1 * Cd;         // own stream (old)
                 const float* yo = f[cur] + (size_t)(1 - s) * M1 * Cd;   // other view (old)
                 float* xw = f[cur ^ 1] + (size_t)s * M1 * Cd;           // own stream (new)
-                D3R_OTHER(launch_layernorm(m->dt, xo, b.n1.g, b.n1.b, xn, M1, Cd, 1e-6f, st));
-                self_attention(c, xn, b.qkv, M1, Cd, Hd, B, N, tw, ldv, q, k, vt, ao);
-                gemm_linear(c, ao, Cd, b.proj, M1, EPI_F32, xw, Cd, xo);
+                D3R_OTHER(launch_layernorm(m->dt, xo, b.n1.g, b.n1.b, sxn, M1, Cd, 1e-6f, c.st));
+                self_attention(c, sxn, b.qkv, M1, Cd, Hd, B, N, tw, ldv, sq, sk, svt, sao);
+                gemm_linear(c, sao, Cd, b.proj, M1, EPI_F32, xw, Cd, xo);
                 // cross attention: q from norm2(x), k/v from norm_y(y)
-                D3R_OTHER(launch_layernorm(m->dt, yo, b.ny.g, b.ny.b, yn, M1, Cd, 1e-6f, st));
-                D3R_OTHER(launch_layernorm(m->dt, xw, b.n2.g, b.n2.b, xn, M1, Cd, 1e-6f, st));
+                D3R_OTHER(launch_layernorm(m->dt, yo, b.ny.g, b.ny.b, syn, M1, Cd, 1e-6f, c.st));
+                D3R_OTHER(launch_layernorm(m->dt, xw, b.n2.g, b.n2.b, sxn, M1, Cd, 1e-6f, c.st));
                 {
                     const int kq[1] = {HEAD_ROPE};
-                    void* dq[1] = {q};
-                    gemm_heads(c, xn, Cd, b.cq, M1, Cd, 1, kq, dq, Hd, N, tw, ldv);
+                    void* dq[1] = {sq};
+                    gemm_heads(c, sxn, Cd, b.cq, M1, Cd, 1, kq, dq, Hd, N, tw, ldv);
                     const int kkv[2] = {HEAD_ROPE, HEAD_VT};
-                    void* dkv[2] = {k, vt};
-                    gemm_heads(c, yn, Cd, b.ckv, M1, Cd, 2, kkv, dkv, Hd, N, tw, ldv);
+                    void* dkv[2] = {sk, svt};
+                    gemm_heads(c, syn, Cd, b.ckv, M1, Cd, 2, kkv, dkv, Hd, N, tw, ldv);
                     AttnParams a;
-                    a.q = q; a.k = k; a.vt = vt; a.out = ao; a.B = B; a.H = Hd; a.Nq = N; a.Nk = N; a.ldv = ldv; a.scale = 0.125f;
+                    a.q = sq; a.k = sk; a.vt = svt; a.out = sao; a.B = B; a.H = Hd; a.Nq = N; a.Nk = N; a.ldv = ldv; a.scale = 0.125f;
                     c.mark(PRF_ATTN, 4.0 * B * Hd * (double)N * N * 64);
-                    c.chk(launch_attention(m->dt, a, st));
+                    c.chk(launch_attention(m->dt, a, c.st));
                 }
-                gemm_linear(c, ao, Cd, b.cproj, M1, EPI_F32, xw, Cd, xw);
-                D3R_OTHER(launch_layernorm(m->dt, xw, b.n3.g, b.n3.b, xn, M1, Cd, 1e-6f, st));
-                gemm_linear(c, xn, Cd, b.fc1, M1, EPI_GELU, hb, 4 * Cd);
+                gemm_linear(c, sao, Cd, b.cproj, M1, EPI_F32, xw, Cd, xw);
+                D3R_OTHER(launch_layernorm(m->dt, xw, b.n3.g, b.n3.b, sxn, M1, Cd, 1e-6f, c.st));
+                gemm_linear(c, sxn, Cd, b.fc1, M1, EPI_GELU, shb, 4 * Cd);
                 const int layer_no = l + 1;
                 void* hcopy = (cf.head_type == 1 && (layer_no == hk6 || layer_no == hk9)) ? hook[s][layer_no == hk6 ? 0 : 1] : nullptr;
-                gemm_linear(c, hb, 4 * Cd, b.fc2, M1, EPI_F32, xw, Cd, xw, hcopy, Cd);
+                gemm_linear(c, shb, 4 * Cd, b.fc2, M1, EPI_F32, xw, Cd, xw, hcopy, Cd);
             }
+            cross_sync();
             cur ^= 1;
         }
-        for (int s = 0; s < 2; ++s)
-            D3R_OTHER(launch_layernorm(m->dt, f[cur] + (size_t)s * M1 * Cd, m->dec_norm.g, m->dec_norm.b, hook[s][2], M1, Cd, 1e-6f, st));
-    }
-    // ---- heads -----------------------------------------------------------------------------------------------
-    size_t peak = common_end;
-    float* pts[2] = {pts1, pts2};
-    float* cnf[2] = {conf1, conf2};
-    if (cf.head_type == 0) {
-        if (!dry)
-            for (int s = 0; s < 2; ++s) {
-                gemm_linear(c, hook[s][2], Cd, m->lin_head[s], M1, EPI_F32, lin_out, 4 * ps * ps);
-                D3R_OTHER(launch_linear_head_post(lin_out, pts[s], cnf[s], B, th, tw, ps, st));
-            }
-    } else {
-        const int chunk = B < 32 ? B : 32;   // 288 GB of HBM: batch the head as wide as the encoder (low-resolution stages need the rows)
-        for (int s = 0; s < 2; ++s)
-            for (int b0 = 0; b0 < B; b0 += chunk) {
-                const int bc = (B - b0) < chunk ? (B - b0) : chunk;
-                Arena sub(dry ? nullptr : (char*)ws + common_end, ws_cap > common_end ? ws_cap - common_end : 0);
-                const void* hooks[4] = {(const char*)encn + ((size_t)s * M1 + (size_t)b0 * N) * Ce * eb, (const char*)hook[s][0] + (size_t)b0 * N * Cd * eb,
-                                        (const char*)hook[s][1] + (size_t)b0 * N * Cd * eb, (const char*)hook[s][2] + (size_t)b0 * N * Cd * eb};
-                const int hc[4] = {Ce, Cd, Cd, Cd};
-                if (dry) {
-                    // size only: replay the allocation pattern
-                    Ctx dc{m, st};
-                    struct Probe { };
-                    (void)dc;
-                    const size_t ebb = eb;
-                    const int th2 = (th - 1) / 2 + 1, tw2 = (tw - 1) / 2 + 1;
-                    const int Hl[4] = {4 * th, 2 * th, th, th2}, Wl[4] = {4 * tw, 2 * tw, tw, tw2};
-                    const DptHead& D = m->dpt[s];
-                    for (int i = 0; i < 4; ++i) sub.take((size_t)bc * Hl[i] * Wl[i] * D.cstride[i] * ebb);
-                    sub.take((size_t)bc * N * 768 * ebb);
-                    for (int i = 0; i < 4; ++i) { sub.take((size_t)bc * Hl[i] * Wl[i] * 256 * ebb); sub.take((size_t)bc * Hl[i] * Wl[i] * 256 * ebb); }
-                    for (int i = 0; i < 3; ++i) sub.take((size_t)bc * Hl[0] * Wl[0] * 256 * ebb);
-                    for (int lvl = 3; lvl >= 0; --lvl) {
-                        const int Ho = lvl == 3 ? Hl[2] : 2 * Hl[lvl], Wo = lvl == 3 ? Wl[2] : 2 * Wl[lvl];
-                        sub.take((size_t)bc * Ho * Wo * 256 * ebb);
-                    }
-                    sub.take((size_t)bc * 64 * N * 128 * ebb);
-                    sub.take((size_t)bc * 256 * N * 128 * ebb);
-                    sub.take((size_t)bc * 256 * N * 128 * ebb);
-                    if (common_end + sub.off > peak) peak = common_end + sub.off;
-                } else {
+        // ---- dec_norm + heads, each side on its own stream ---------------------------------------------------
+        float* pts[2] = {pts1, pts2};
+        float* cnf[2] = {conf1, conf2};
+        for (int s = 0; s < 2; ++s) {
+            c.st = S[s];
+            D3R_OTHER(launch_layernorm(m->dt, f[cur] + (size_t)s * M1 * Cd, m->dec_norm.g, m->dec_norm.b, hook[s][2], M1, Cd, 1e-6f, c.st));
+            if (cf.head_type == 0) {
+                float* lo = lin_out + (size_t)s * M1 * 4 * ps * ps;
+                gemm_linear(c, hook[s][2], Cd, m->lin_head[s], M1, EPI_F32, lo, 4 * ps * ps);
+                D3R_OTHER(launch_linear_head_post(lo, pts[s], cnf[s], B, th, tw, ps, c.st));
+            } else {
+                for (int b0 = 0; b0 < B; b0 += chunk) {
+                    const int bc = (B - b0) < chunk ? (B - b0) : chunk;
+                    Arena sub((char*)ws + common_end + (size_t)s * head_arena, head_arena);
+                    const void* hooks[4] = {(const char*)encn + ((size_t)s * M1 + (size_t)b0 * N) * Ce * eb, (const char*)hook[s][0] + (size_t)b0 * N * Cd * eb,
+                                            (const char*)hook[s][1] + (size_t)b0 * N * Cd * eb, (const char*)hook[s][2] + (size_t)b0 * N * Cd * eb};
+                    const int hc[4] = {Ce, Cd, Cd, Cd};
                     run_dpt(c, m->dpt[s], sub, hooks, hc, bc, th, tw, pts[s] + (size_t)b0 * H * W * 3, cnf[s] + (size_t)b0 * H * W);
                 }
             }
+        }
+        c.st = st;
+        if (two) {   // join: the caller's stream continues only after side 1 has finished
+            c.chk(hipEventRecord(m->ev_side, S[1]));
+            c.chk(hipStreamWaitEvent(S[0], m->ev_side, 0));
+        }
+        c.mark(PRF_END, 0.0);
     }
-    if (!dry) c.mark(PRF_END, 0.0);
     if (rc_out) *rc_out = c.rc;
-    return peak + 256;
+    return common_end + 2 * head_arena + 256;
 }
 
 }  // namespace

@@ -10,7 +10,8 @@
 // Shape: out[m][n] = sum_k act[m][k] * wgt[n][k]   ("NT": both operands K-contiguous).
 // Tile configurations (template Cfg; 128 bytes of K per step = 64 bf16; 16x16x32 MFMA fragments):
 //   256 x 256, 8 waves (2 x 4), each wave 128 (n) x 64 (m) = 8 x 4 fragments   -- the large-GEMM shape
-//   256 x 128, 8 waves, each wave 64 x 64                                       -- N = 128 convolutions
+//   256 x 128, 8 waves, each wave 64 x 64                                       -- mid-size problems
+//   512 x 128, 8 waves (1 x 8), each wave 128 (n) x 64 (m)                      -- N <= 128 convolutions (DPT head)
 //   128 x 128, 4 waves (2 x 2), each wave 64 x 64, 2 blocks per CU              -- small problems / tails
 // Operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered; the LDS image is
 // lane-linear, the bank swizzle (chunk ^= (row>>1)&7, conflict-free for ds_read_b128 on 128-byte rows) is applied
@@ -42,6 +43,8 @@ template <int NWI_, int NWJ_, int FI_, int FJ_, int MINW_> struct GemmCfg {
 typedef GemmCfg<2, 4, 8, 4, 2> Cfg256;      // 256 x 256, 512 threads, 128 KiB LDS, 1 block / CU
 typedef GemmCfg<2, 4, 4, 4, 2> Cfg256x128;  // M 256 x N 128, 512 threads, 96 KiB LDS, 1 block / CU
 typedef GemmCfg<2, 2, 4, 4, 2> Cfg128;      // 128 x 128, 256 threads, 64 KiB LDS, 2 blocks / CU
+typedef GemmCfg<1, 8, 8, 4, 2> Cfg512x128;  // M 512 x N 128, 512 threads, 160 KiB LDS (all of it): N <= 128 convolutions with the
+                                            // 128 x 64 per-wave tile of Cfg256 (12 ds_read_b128 per 32 MFMAs instead of 8 per 16)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                         if (p.out2) store4<DT>(p.out2, (size_t)m * p.ldo2 + n, v0, v1, v2, v3);
                     } break;
                     case EPI_GELU:
-                        store4<DT>(p.out, (size_t)m * p.ldo + n, gelu_erf(v0), gelu_erf(v1), gelu_erf(v2), gelu_erf(v3));
+                        store4<DT>(p.out, (size_t)m * p.ldo + n, gelu<DT>(v0), gelu<DT>(v1), gelu<DT>(v2), gelu<DT>(v3));
                         break;
                     case EPI_CONVT: {
                         // ConvTranspose2d(k == stride): column n = (tap, co); row m = input pixel
@@ -329,42 +332,36 @@ template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hi
     return hipGetLastError();
 }
 
-// Estimated cost of a configuration: rounds of concurrently resident tiles x tile area / relative tile efficiency
-// (bigger tiles move fewer LDS bytes per MFMA). 256 CUs; 256-class tiles run 1 block per CU, 128x128 two.
-static double cfg_cost(int M, int N, int bm, int bn, int blocks_per_cu, double eff) {
-    const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
-    const long slots = 256L * blocks_per_cu;
-    const long rounds = (tiles + slots - 1) / slots;
-    return (double)rounds * bm * bn * blocks_per_cu / eff;   // a round of co-resident blocks shares the CU's MFMA pipes
-}
-
+// Tile configuration choice, from measurements on MI355X (tools/gpu_probe.py gemm, profiles/): the 256x256 tile wins
+// once there are at least ~3 full rounds of 256 resident blocks (M = 49152: 760-1070 vs 640-830 TF/s), the 128x128 tile
+// (2 blocks per CU: one block's prologue / epilogue hides behind the other's K loop) wins below that; N <= 128 problems
+// (DPT head convolutions) take the 512x128 / 256x128 tiles so that no half-empty 256-wide tile is computed.
 int gemm_pick_config(const GemmParams& p) {
     const int n_rows = p.n_rows > 0 ? p.n_rows : p.n_pad;
     const bool heads = p.epi == EPI_HEADS;
     const bool ok256 = cdiv(p.n_store, 256) * 256 <= n_rows && (!heads || p.head_c % 256 == 0);
     int forced = p.force_cfg;
-    if (forced < 0) {   // D3R_GEMM_CFG=0|1|2 pins the tile configuration (parity tests, probes); infeasible choices are ignored
+    if (forced < 0) {   // D3R_GEMM_CFG=0|1|2|3 pins the tile configuration (parity tests, probes); infeasible choices are ignored
         const char* e = getenv("D3R_GEMM_CFG");
-        if (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) forced = e[0] - '0';
+        if (e && e[0] >= '0' && e[0] <= '3' && e[1] == 0) forced = e[0] - '0';
     }
-    if (forced == GEMM_CFG_128 || (forced == GEMM_CFG_256 && ok256) || (forced == GEMM_CFG_256x128 && !heads)) return forced;
-    double best = cfg_cost(p.M, p.n_store, 128, 128, 2, 1.0);
-    int pick = GEMM_CFG_128;
-    if (ok256) {
-        const double c = cfg_cost(p.M, p.n_store, 256, 256, 1, 1.25);
-        if (c < best) { best = c; pick = GEMM_CFG_256; }
+    if (forced == GEMM_CFG_128 || (forced == GEMM_CFG_256 && ok256) || ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128) && !heads))
+        return forced;
+    if (!heads && p.n_store <= 128) {
+        if (cdiv(p.M, 512) >= 512) return GEMM_CFG_512x128;
+        if (cdiv(p.M, 256) >= 512) return GEMM_CFG_256x128;
+        return GEMM_CFG_128;
     }
-    if (!heads) {
-        const double c = cfg_cost(p.M, p.n_store, 256, 128, 1, 1.1);
-        if (c < best) { best = c; pick = GEMM_CFG_256x128; }
-    }
-    return pick;
+    const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.n_store, 256);
+    if (ok256 && tiles256 >= 700) return GEMM_CFG_256;
+    return GEMM_CFG_128;
 }
 
 template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     switch (gemm_pick_config(p)) {
         case GEMM_CFG_256: return launch_cfg<DT, Cfg256>(p, s);
         case GEMM_CFG_256x128: return launch_cfg<DT, Cfg256x128>(p, s);
+        case GEMM_CFG_512x128: return launch_cfg<DT, Cfg512x128>(p, s);
         default: return launch_cfg<DT, Cfg128>(p, s);
     }
 }

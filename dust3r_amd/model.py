@@ -231,6 +231,11 @@ class AsymmetricCroCo3DStereo(nn.Module):
                 check(fn(self._engine, key.encode(), C.c_void_p(t.data_ptr()), t.ndim, shape), f'load_tensor({key})')
             torch.cuda.synchronize()
 
+    def set_two_streams(self, flag=True):
+        """Decoder side 2 / head 2 on the engine's second HIP stream (default) or everything on the caller's stream."""
+        check(lib.d3r_model_set_option(self._engine, 2, int(bool(flag))), 'set_option(two_streams)')
+        return self
+
     @property
     def device(self):
         return self._device

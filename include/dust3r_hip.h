@@ -122,6 +122,8 @@ size_t d3r_model_device_bytes(const d3r_model* m);
  * kind 0 = GEMM (nn.Linear), 1 = implicit-GEMM convolution (same kernel), 2 = attention, 3 = all other kernels.
  * Profiling adds event overhead: never enable it inside a timed region. */
 #define D3R_MODEL_OPT_PROFILE 1
+#define D3R_MODEL_OPT_TWO_STREAMS 2 /* 1 (default): decoder side 2 and head 2 run on an engine-owned second HIP stream, joined back
+                                     * into the caller's stream before d3r_model_forward's work completes; 0: everything on the caller's stream */
 int d3r_model_set_option(d3r_model* m, int option, int value);
 int d3r_model_profile_read(d3r_model* m, int kind, int* launches, double* ms, double* work);
 /* debug/parity hook: copy an internal activation of the last forward to `out_f32` (device fp32).

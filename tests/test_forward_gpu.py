@@ -74,7 +74,7 @@ def test_forward_matches_oracle(gpu, precision, config, B, H, W):
     compare(eng, oracle, v1, v2, *TOLS[precision], tag=f'{config} {precision} {B}x{H}x{W}')
 
 
-@pytest.mark.parametrize('cfg', ['0', '1', '2'])
+@pytest.mark.parametrize('cfg', ['0', '1', '2', '3'])
 @pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
 def test_forward_with_pinned_gemm_tile(gpu, precision, cfg, monkeypatch):
     """The whole network with the GEMM tile configuration pinned (D3R_GEMM_CFG): the 256-wide tiles' q/k RoPE scatter,
@@ -113,6 +113,23 @@ def test_forward_batch_position_independence(gpu):
         s2 = dict(img=v2['img'][b:b + 1], true_shape=v2['true_shape'][b:b + 1], idx=[1], instance=['1'])
         o1, o2 = eng(s1, s2)
         assert torch.equal(o1['pts3d'][0], full1['pts3d'][b]) and torch.equal(o2['conf'][0], full2['conf'][b])
+
+
+def test_two_stream_decoder_is_bit_identical(gpu):
+    """The second-stream schedule of decoder side 2 / head 2 only reorders independent launches: outputs are bit-identical
+    to the single-stream schedule, repeatedly (a missing cross-stream dependency would show as run-to-run differences)."""
+    from oracle.dust3r_ref import build_ref_model
+    eng = engine_from_oracle(build_ref_model('tiny_dpt'), 'tiny_dpt', 'bf16', gpu)
+    v1, v2 = synthetic_views(4, 64, 96, seed=21)
+    eng.set_two_streams(False)
+    a1, a2 = eng(v1, v2)
+    torch.cuda.synchronize()
+    eng.set_two_streams(True)
+    for _ in range(5):
+        b1, b2 = eng(v1, v2)
+        torch.cuda.synchronize()
+        assert torch.equal(a1['pts3d'], b1['pts3d']) and torch.equal(a1['conf'], b1['conf'])
+        assert torch.equal(a2['pts3d_in_other_view'], b2['pts3d_in_other_view']) and torch.equal(a2['conf'], b2['conf'])
 
 
 def test_inference_api_end_to_end(gpu):
@@ -159,3 +176,31 @@ def test_full_size_fp32_pair_matches_oracle(gpu):
         mx, mean = pix_rel(e1['pts3d'], r1['pts3d'])
         print(f'[512_dpt {prec}] pts1 rel err max {mx:.3e} mean {mean:.3e}')
         assert mean < bound
+
+
+def test_config1_pairviewer_pipeline(gpu):
+    """BASELINE configs[0] plumbing on the engine: a 224x224 linear-head model, 2 images -> 1 symmetrised pair ->
+    inference() -> GlobalAlignerMode.PairViewer -> getters, with demo.py's call sequence and the reference's shapes."""
+    from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.inference import inference
+    from dust3r_amd.synthetic import synthetic_image_list
+    from oracle.dust3r_ref import build_ref_model
+    oracle = build_ref_model('tiny_linear')
+    eng = engine_from_oracle(oracle, 'tiny_linear', 'fp16x3', gpu)
+    imgs = synthetic_image_list(2, 224, 224, seed=9)
+    pairs = make_pairs(imgs, scene_graph='complete', prefilter=None, symmetrize=True)
+    assert len(pairs) == 2
+    out = inference(pairs, eng, gpu, batch_size=1, verbose=False)
+    assert out['pred1']['pts3d'].shape == (2, 224, 224, 3) and out['pred2']['conf'].shape == (2, 224, 224)
+    # same numbers as the oracle's inference on the same pairs (<= 1e-3)
+    with torch.no_grad():
+        for e, (a, b) in enumerate(pairs):
+            r1, r2 = oracle(a, b)
+            mx, _ = pix_rel(out['pred1']['pts3d'][e:e + 1], r1['pts3d'])
+            assert mx < 1e-3
+    scene = global_aligner(out, gpu, mode=GlobalAlignerMode.PairViewer, verbose=False)
+    poses, focals = scene.get_im_poses(), scene.get_focals()
+    assert poses.shape == (2, 4, 4) and focals.shape[0] == 2 and torch.isfinite(poses).all() and torch.isfinite(focals).all()
+    pts = scene.get_pts3d()
+    assert len(pts) == 2 and pts[0].shape == (224, 224, 3) and len(scene.get_masks()) == 2

@@ -59,6 +59,28 @@ def gemm_probe():
     print('cpu threads chosen:', tune_threads(verbose=True))
 
 
+def conv_probe():
+    import os
+    print('== DPT-head convolutions (implicit GEMM, NHWC bf16, B = 32 images): ms and TFLOP/s per tile configuration')
+    for (H, W, Cin, Cout) in [(192, 256, 256, 128), (384, 512, 128, 128), (96, 128, 256, 256), (192, 256, 256, 256), (48, 64, 256, 256)]:
+        B = 32
+        x = torch.randn((B, H, W, Cin), device=dev).to(torch.bfloat16)
+        w = (torch.randn((Cout, Cin, 3, 3), device=dev) / math.sqrt(9 * Cin)).to(torch.bfloat16)
+        b = torch.randn(Cout, device=dev)
+        fl = 2 * B * H * W * Cout * 9 * Cin
+        line = f'  {H}x{W} {Cin}->{Cout}'
+        for cfg in ('0', '1', '2', '3', None):
+            if cfg is None:
+                os.environ.pop('D3R_GEMM_CFG', None)
+            else:
+                os.environ['D3R_GEMM_CFG'] = cfg
+            ms = timeit(lambda: ops.conv2d_nhwc(x, w, b, stride=1, pad=1), warm=2, reps=5)
+            line += f' | cfg {cfg or "auto"}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s'
+        os.environ.pop('D3R_GEMM_CFG', None)
+        print(line)
+        del x
+
+
 def attn_probe():
     print('== attention (N=768, d=64)')
     for (B, H, dt) in [(64, 16, torch.bfloat16), (64, 16, torch.float16), (32, 12, torch.bfloat16), (8, 16, torch.float32)]:
@@ -130,7 +152,7 @@ if __name__ == '__main__':
     print(torch.cuda.get_device_name(0))
     for w in which:
         try:
-            {'gemm': gemm_probe, 'attn': attn_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
+            {'gemm': gemm_probe, 'conv': conv_probe, 'attn': attn_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
         except Exception as e:  # keep going: this is a probe
             import traceback
             traceback.print_exc()
