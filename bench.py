@@ -157,6 +157,7 @@ def main():
     ap.add_argument('--no-aligner', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--single-stream', action='store_true', help='keep decoder side 2 / head 2 on the main stream (serialised kernels: use under rocprofv3 so that per-kernel durations are not inflated by overlap)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -176,6 +177,8 @@ def main():
     from dust3r_amd.synthetic import synthetic_views
     _lib.require_device()
     model = build_model(args.precision, device)
+    if args.single_stream:
+        model.set_two_streams(False)
     B = args.pairs
     v1, v2 = synthetic_views(B, H, W, seed=rank, device=device)      # resident in HBM before the timed region
 

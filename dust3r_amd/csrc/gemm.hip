@@ -58,66 +58,77 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     constexpr int BM = CF::BM, BN = CF::BN, FI = CF::FI, FJ = CF::FJ, STAGE_BYTES = CF::STAGE_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // ---- block -> tile: XCD-contiguous ids, then 8-wide column panels walked row by row ------------------
+    // ---- tile walk: persistent blocks. Tile ids are XCD-contiguous (block b runs on XCD b % 8 and only ever takes ids
+    // congruent to b mod 8), then 8-wide column panels walked row by row, so the tiles an XCD works on at any moment share
+    // A rows and W rows inside its L2.
     const int tiles_n = (p.n_store + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    constexpr int PANEL = 8;
-    const int per_panel = PANEL * tiles_m;
-    const int panel = lid / per_panel, rem_p = lid - panel * per_panel;
-    const int width = min(PANEL, tiles_n - panel * PANEL);
-    const int tm = rem_p / width, tn = panel * PANEL + (rem_p - tm * width);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const bool swap = (BM == BN) && (p.epi == EPI_HEADS) && (p.head_kind[n0 / p.head_c] == HEAD_VT);
+    const int ntiles = tiles_m * tiles_n;
+    auto tile_origin = [&](int t, int& m0_, int& n0_) __attribute__((always_inline)) {
+        const int lid = xcd_remap(t, ntiles);
+        constexpr int PANEL = 8;
+        const int per_panel = PANEL * tiles_m;
+        const int panel = lid / per_panel, rem_p = lid - panel * per_panel;
+        const int width = min(PANEL, tiles_n - panel * PANEL);
+        const int tm = rem_p / width, tn = panel * PANEL + (rem_p - tm * width);
+        m0_ = tm * BM;
+        n0_ = tn * BN;
+    };
 
     // ---- staging addresses (per lane: one 16-byte chunk of APASS activation rows and WPASS weight rows) ---
     const int lrow = wave * 8 + (lane >> 3);                         // row inside a PASS_ROWS slab
     const int lchunk = (lane & 7) ^ (((lane >> 4) + wave * 4) & 7);  // logical chunk fetched by this lane
     const char* wsrc[CF::WPASS];
-    const char* asrc[CF::APASS];
-    int iy0[CF::APASS], ix0[CF::APASS], ibase[CF::APASS];
+    // per activation row of a pass: linear operand -> the row's source address; implicit-GEMM operand -> the packed
+    // (image base pixel | top-left input y << 16 | top-left input x) of the output pixel. One 64-bit slot either way.
+    unsigned long long arow[CF::APASS];
+    auto setup_stage = [&](int m0_, int n0_) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < CF::WPASS; ++q) {
-        const int r = q * CF::PASS_ROWS + lrow;
-        wsrc[q] = reinterpret_cast<const char*>(p.wgt) + ((size_t)(n0 + r) * p.K) * EB + lchunk * 16;
-    }
-#pragma unroll
-    for (int q = 0; q < CF::APASS; ++q) {
-        const int r = q * CF::PASS_ROWS + lrow;
-        int m = m0 + r;
-        m = m < p.M ? m : p.M - 1;
-        if (p.amode == AMODE_LINEAR) {
-            asrc[q] = reinterpret_cast<const char*>(p.act) + ((size_t)m * p.lda) * EB + lchunk * 16;
-            iy0[q] = ix0[q] = ibase[q] = 0;
-        } else {
-            const int hw = p.Hout * p.Wout;
-            const int b = m / hw, rem = m - b * hw;
-            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            iy0[q] = oy * p.stride - p.pad;
-            ix0[q] = ox * p.stride - p.pad;
-            ibase[q] = b * p.Hin * p.Win;
-            asrc[q] = nullptr;
+        for (int q = 0; q < CF::WPASS; ++q) {
+            const int r = q * CF::PASS_ROWS + lrow;
+            wsrc[q] = reinterpret_cast<const char*>(p.wgt) + ((size_t)(n0_ + r) * p.K) * EB + lchunk * 16;
         }
-    }
+#pragma unroll
+        for (int q = 0; q < CF::APASS; ++q) {
+            const int r = q * CF::PASS_ROWS + lrow;
+            int m = m0_ + r;
+            m = m < p.M ? m : p.M - 1;
+            if (p.amode == AMODE_LINEAR) {
+                arow[q] = (unsigned long long)(size_t)(reinterpret_cast<const char*>(p.act) + ((size_t)m * p.lda) * EB + lchunk * 16);
+            } else {
+                const int hw = p.Hout * p.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;   // |.| < 32768
+                const unsigned pk = ((unsigned)iy0 << 16) | ((unsigned)ix0 & 0xFFFFu);
+                arow[q] = ((unsigned long long)pk << 32) | (unsigned)(b * p.Hin * p.Win);
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    int m0, n0;
+    tile_origin(tile, m0, n0);
+    setup_stage(m0, n0);
     const char* zsrc = reinterpret_cast<const char*>(p.zero_page) + lchunk * 16;
 
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
     const uint32_t lds0 = lds_addr(smem) + wave_u * 1024;   // wave-uniform: one 1 KiB DMA piece per wave and pass
-    auto stage = [&](int kt, int buf) {
+    auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
         const uint32_t sb = lds0 + buf * STAGE_BYTES;
         const size_t koff = (size_t)kt * KTB;
         if (p.amode == AMODE_LINEAR) {
 #pragma unroll
-            for (int q = 0; q < CF::APASS; ++q) glds16(asrc[q] + koff, sb + q * (CF::NW * 1024));
+            for (int q = 0; q < CF::APASS; ++q) glds16(reinterpret_cast<const char*>((size_t)arow[q]) + koff, sb + q * (CF::NW * 1024));
         } else {
             const int kel = kt * KT;
             const int tap = kel / p.Cin, c0 = kel - tap * p.Cin;
             const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
 #pragma unroll
             for (int q = 0; q < CF::APASS; ++q) {
-                const int iy = iy0[q] + ky, ix = ix0[q] + kx;
+                const int pk = (int)(arow[q] >> 32), ibase = (int)(unsigned)arow[q];
+                const int iy = (pk >> 16) + ky, ix = (int)(short)(pk & 0xFFFF) + kx;
                 const bool ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
                 const char* src = reinterpret_cast<const char*>(p.act) +
-                                  ((size_t)(ibase[q] + iy * p.Win + ix) * p.cstride + c0) * EB + lchunk * 16;
+                                  ((size_t)(ibase + iy * p.Win + ix) * p.cstride + c0) * EB + lchunk * 16;
                 src = ok ? src : zsrc;
                 glds16(src, sb + q * (CF::NW * 1024));
             }
@@ -129,65 +140,78 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     // ---- fragment read addresses ---------------------------------------------------------------
     const int wi = wave / CF::NWJ, wj = wave - wi * CF::NWJ;
     const int frow = lane & 15, fsw = (lane >> 1) & 7, fgrp = lane >> 4;
-    // P tile supplies i (4 consecutive per lane), Q tile supplies j
-    const int p_off = swap ? 0 : BM * KTB;  // activations live at 0, weights at BM*KTB
-    const int q_off = swap ? BM * KTB : 0;
     const int p_row0 = wi * (FI * 16) + frow, q_row0 = wj * (FJ * 16) + frow;
-
-    f32x4_t acc[FI][FJ];
-#pragma unroll
-    for (int a = 0; a < FI; ++a)
-#pragma unroll
-        for (int b = 0; b < FJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    // K loop, two LDS stages: [wait own DMA of tile kt] -> barrier (tile kt visible to every wave, every wave is done
-    // reading the other stage) -> issue the DMA of tile kt+1 into the other stage -> math on tile kt. The DMA of tile
-    // kt+1 is in flight during the whole math of tile kt.
-    const int nk = p.K / KT;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        d3r_wait_vm0();
-        __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const char* sb = smem + buf * STAGE_BYTES;
-        if constexpr (DT == D3R_F16X3) {
-            // 128 bytes of a row = 32 logical k = 4 groups [hi x8][lo x8]; lane group fgrp owns group fgrp
-            const int chi = ((2 * fgrp) ^ fsw) * 16, clo = ((2 * fgrp + 1) ^ fsw) * 16;
-            uint4 qf[FJ], ql[FJ];
-#pragma unroll
-            for (int f = 0; f < FJ; ++f) {
-                const char* qr = sb + q_off + (q_row0 + f * 16) * KTB;
-                qf[f] = *reinterpret_cast<const uint4*>(qr + chi);
-                ql[f] = *reinterpret_cast<const uint4*>(qr + clo);
-            }
-#pragma unroll
-            for (int fi = 0; fi < FI; ++fi) {
-                const char* pr = sb + p_off + (p_row0 + fi * 16) * KTB;
-                const uint4 pf = *reinterpret_cast<const uint4*>(pr + chi), pl = *reinterpret_cast<const uint4*>(pr + clo);
-#pragma unroll
-                for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], pf, pl, qf[fj], ql[fj]);
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
-                uint4 pf[FI], qf[FJ];
-#pragma unroll
-                for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (q_row0 + f * 16) * KTB + coff);
-#pragma unroll
-                for (int f = 0; f < FI; ++f) pf[f] = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + f * 16) * KTB + coff);
-#pragma unroll
-                for (int fi = 0; fi < FI; ++fi)
-#pragma unroll
-                    for (int fj = 0; fj < FJ; ++fj) TR::mma16(acc[fi][fj], pf[fi], qf[fj]);
-            }
-        }
-    }
-
-    // ---- epilogue ------------------------------------------------------------------------------
     const int i4 = (lane >> 4) * 4;  // first of this lane's 4 consecutive i inside a fragment
     const int jl = lane & 15;
+
+    f32x4_t acc[FI][FJ];
+    const int nk = p.K / KT;
+    int it = 0;  // K steps done by this block over all its tiles: LDS stage = it & 1
+    stage(0, 0);
+    for (;;) {
+        const bool swap = (BM == BN) && (p.epi == EPI_HEADS) && (p.head_kind[n0 / p.head_c] == HEAD_VT);
+        // P tile supplies i (4 consecutive per lane), Q tile supplies j
+        const int p_off = swap ? 0 : BM * KTB;  // activations live at 0, weights at BM*KTB
+        const int q_off = swap ? BM * KTB : 0;
+        const int next_tile = tile + (int)gridDim.x;
+        int nm0 = 0, nn0 = 0;
+#pragma unroll
+        for (int a = 0; a < FI; ++a)
+#pragma unroll
+            for (int b = 0; b < FJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        // K loop, two LDS stages: [wait own DMA of step it] -> barrier (the step's tile is visible to every wave, every
+        // wave is done reading the other stage) -> issue the DMA of the next step into the other stage -> math. The next
+        // step is K-tile kt+1 of this output tile or, on the last K-tile, K-tile 0 of the block's NEXT output tile, whose
+        // load latency is thereby hidden behind this tile's last math step and its epilogue.
+        for (int kt = 0; kt < nk; ++kt, ++it) {
+            const int buf = it & 1;
+            d3r_wait_vm0();
+            __syncthreads();
+            if (kt + 1 < nk) {
+                stage(kt + 1, buf ^ 1);
+            } else if (next_tile < ntiles) {
+                tile_origin(next_tile, nm0, nn0);
+                setup_stage(nm0, nn0);
+                stage(0, buf ^ 1);
+            }
+            const char* sb = smem + buf * STAGE_BYTES;
+            if constexpr (DT == D3R_F16X3) {
+                // 128 bytes of a row = 32 logical k = 4 groups [hi x8][lo x8]; lane group fgrp owns group fgrp
+                const int chi = ((2 * fgrp) ^ fsw) * 16, clo = ((2 * fgrp + 1) ^ fsw) * 16;
+                uint4 qf[FJ], ql[FJ];
+#pragma unroll
+                for (int f = 0; f < FJ; ++f) {
+                    const char* qr = sb + q_off + (q_row0 + f * 16) * KTB;
+                    qf[f] = *reinterpret_cast<const uint4*>(qr + chi);
+                    ql[f] = *reinterpret_cast<const uint4*>(qr + clo);
+                }
+#pragma unroll
+                for (int fi = 0; fi < FI; ++fi) {
+                    const char* pr = sb + p_off + (p_row0 + fi * 16) * KTB;
+                    const uint4 pf = *reinterpret_cast<const uint4*>(pr + chi), pl = *reinterpret_cast<const uint4*>(pr + clo);
+#pragma unroll
+                    for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], pf, pl, qf[fj], ql[fj]);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
+                    uint4 pf[FI], qf[FJ];
+#pragma unroll
+                    for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (q_row0 + f * 16) * KTB + coff);
+#pragma unroll
+                    for (int f = 0; f < FI; ++f) pf[f] = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + f * 16) * KTB + coff);
+#pragma unroll
+                    for (int fi = 0; fi < FI; ++fi)
+#pragma unroll
+                        for (int fj = 0; fj < FJ; ++fj) TR::mma16(acc[fi][fj], pf[fi], qf[fj]);
+                }
+            }
+        }
+
+        auto epilogue = [&]() __attribute__((always_inline)) {
+    // ---- epilogue (of the tile at m0, n0) -------------------------------------------------------
     if (!swap) {
         const int nb = n0 + wi * (FI * 16), mb = m0 + wj * (FJ * 16);
         if (p.epi == EPI_HEADS) {
@@ -318,6 +342,11 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             }
         }
     }
+        };  // epilogue
+        epilogue();
+        if (next_tile >= ntiles) break;
+        tile = next_tile; m0 = nm0; n0 = nn0;
+    }
 }
 
 // ---- host side: configuration choice + launch ------------------------------------------------------------------
@@ -327,7 +356,11 @@ template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hi
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<DT, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
         attr_set = true;
     }
-    const int grid = cdiv(p.M, CF::BM) * cdiv(p.n_store, CF::BN);
+    // persistent grid: one resident block per CU slot (256 CUs x blocks that fit in 160 KiB of LDS); a multiple of 8
+    // so that a block's tile ids stay on its own XCD's range
+    const int ntiles = cdiv(p.M, CF::BM) * cdiv(p.n_store, CF::BN);
+    const int slots = 256 * (CF::LDS * 2 <= 160 * 1024 ? 2 : 1);
+    const int grid = ntiles < slots ? ntiles : slots;
     hipLaunchKernelGGL((gemm_kernel<DT, CF>), dim3(grid), dim3(CF::NT), CF::LDS, s, p);
     return hipGetLastError();
 }

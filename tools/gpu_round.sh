@@ -15,9 +15,9 @@ for w in $WHAT; do
     testsall) timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -15 $OUT/pytest_gpu.log ;;
     probe) timeout 900 python tools/gpu_probe.py gemm conv attn forward aligner > $OUT/probe.log 2>&1; tail -60 $OUT/probe.log ;;
     bench) timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.log; tail -12 $OUT/bench.log; cat $OUT/bench.json ;;
-    prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.log); find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
-    pmc) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_fetch -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $OLDPWD/$OUT/pmc_fetch.log);
-         (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_write -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $OLDPWD/$OUT/pmc_write.log); ls $OUT/pmc_fetch $OUT/pmc_write ;;
+    prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.log); find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
+    pmc) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_fetch -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --single-stream > /dev/null 2> $OLDPWD/$OUT/pmc_fetch.log);
+         (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_write -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --single-stream > /dev/null 2> $OLDPWD/$OUT/pmc_write.log); ls $OUT/pmc_fetch $OUT/pmc_write ;;
   esac
 done
 # summarise the per-dispatch PMC csvs (sum / mean per kernel) and keep the merged-back payload small
