@@ -25,7 +25,7 @@ static constexpr int CHUNK = 256 * PPT;  // pixels per workgroup
 static constexpr int PW = 16;            // floats per partial record
 
 struct AlignerView {
-    int n, E, maxA, nslot;  // nslot = waves per image = nchunk * 4
+    int n, E, maxA, nslot;  // nslot = workgroups (1024-pixel chunks) per image: one partial record per workgroup
     const int* img_w;       // [n]
     const int* img_area;    // [n]
     const int* adj_off;     // [n+1]
@@ -62,7 +62,7 @@ D3R_DEV float wave_sum_shfl(float v) {
 }
 
 __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
-    const int nchunk = a.nslot >> 2;
+    const int nchunk = a.nslot;
     const int img = blockIdx.x / nchunk, chunk = blockIdx.x - img * nchunk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p0 = chunk * CHUNK + threadIdx.x * PPT;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
         g[k][0] = g[k][1] = g[k][2] = 0.f;
     }
 
-    const int slot = chunk * 4 + wave;
+    const int slot = chunk;
     const int a0 = a.adj_off[img], a1 = a.adj_off[img + 1];
     // Edge walk. The adjacency entries and the 3x4 matrices of up to EBATCH incident edge sides are staged in LDS first,
     // so that inside the walk the ONLY vector-memory traffic is the pred / weight stream (and the partial stores): any
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
     constexpr int EBATCH = 64;
     __shared__ int sh_es[EBATCH];
     __shared__ __attribute__((aligned(16))) float sh_M[EBATCH][12];
+    __shared__ __attribute__((aligned(16))) float sh_part[4][EBATCH][PW];   // per-wave sums, combined once per batch
     const int pl = active ? p0 : 0;   // inactive lanes (beyond maxA in the last chunk) stream pixel 0 and discard it
     for (int base = a0; base < a1; base += EBATCH) {
         const int nb = min(EBATCH, a1 - base);
@@ -160,12 +161,19 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
                 red[12] = wave_sum_shfl(loss);
             }
             if (lane == 63) {
-                float4* dst = reinterpret_cast<float4*>(a.part_edge + ((size_t)es * a.nslot + slot) * PW);
+                float4* dst = reinterpret_cast<float4*>(sh_part[wave][j]);
                 dst[0] = make_float4(red[0], red[1], red[2], red[3]);
                 dst[1] = make_float4(red[4], red[5], red[6], red[7]);
                 dst[2] = make_float4(red[8], red[9], red[10], red[11]);
                 dst[3] = make_float4(red[12], 0.f, 0.f, 0.f);
             }
+        }
+        // the four waves' sums of every edge of the batch -> one record per (edge side, workgroup), fixed order
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb * PW; i += 256) {
+            const int j = i / PW, v = i - j * PW;
+            const float t = (sh_part[0][j][v] + sh_part[1][j][v]) + (sh_part[2][j][v] + sh_part[3][j][v]);
+            a.part_edge[((size_t)sh_es[j] * a.nslot + slot) * PW + v] = t;
         }
     }
 
@@ -205,12 +213,18 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
     float red[15];
 #pragma unroll
     for (int k = 0; k < 15; ++k) red[k] = a.use_dpp ? wave_sum_dpp(pi[k]) : wave_sum_shfl(pi[k]);
+    __syncthreads();   // sh_part[.][0] is free again (the last batch's combine has been read)
     if (lane == 63) {
-        float4* dst = reinterpret_cast<float4*>(a.part_img + ((size_t)img * a.nslot + slot) * PW);
+        float4* dst = reinterpret_cast<float4*>(sh_part[wave][0]);
         dst[0] = make_float4(red[0], red[1], red[2], red[3]);
         dst[1] = make_float4(red[4], red[5], red[6], red[7]);
         dst[2] = make_float4(red[8], red[9], red[10], red[11]);
         dst[3] = make_float4(red[12], red[13], red[14], 0.f);
+    }
+    __syncthreads();
+    if (threadIdx.x < PW) {
+        const int v = threadIdx.x;
+        a.part_img[((size_t)img * a.nslot + slot) * PW + v] = (sh_part[0][0][v] + sh_part[1][0][v]) + (sh_part[2][0][v] + sh_part[3][0][v]);
     }
 }
 
@@ -416,7 +430,7 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     d3r_aligner* a = new (std::nothrow) d3r_aligner();
     if (!a) return D3R_ERR_ALLOC;
     a->n = n_imgs; a->E = n_edges; a->maxA = max_area;
-    a->nslot = cdiv(max_area, CHUNK) * 4;
+    a->nslot = cdiv(max_area, CHUNK);
     a->h_w.assign(img_w, img_w + n_imgs);
     a->h_h.assign(img_h, img_h + n_imgs);
     a->h_area.resize(n_imgs);
@@ -517,9 +531,9 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
     v.depth_grad = g_depth; v.d_edge = a->d_edge; v.d_img = a->d_img; v.part_edge = a->part_edge; v.part_img = a->part_img;
     v.inv_area[0] = a->inv_area[0]; v.inv_area[1] = a->inv_area[1]; v.l2 = a->l2; v.update = update ? 1 : 0;
     v.use_dpp = a->use_dpp; v.adam = s.adam;
-    hipLaunchKernelGGL(aligner_main_kernel, dim3(a->n * (a->nslot / 4)), dim3(256), 0, st, v);
-    hipLaunchKernelGGL(aligner_reduce_kernel, dim3(2 * a->E), dim3(256), 0, st, a->part_edge, a->red_edge, a->nslot);
-    hipLaunchKernelGGL(aligner_reduce_kernel, dim3(a->n), dim3(256), 0, st, a->part_img, a->red_img, a->nslot);
+    hipLaunchKernelGGL(aligner_main_kernel, dim3(a->n * a->nslot), dim3(256), 0, st, v);
+    // part_edge | part_img and red_edge | red_img are contiguous: one launch reduces the 2E + n entries
+    hipLaunchKernelGGL(aligner_reduce_kernel, dim3(2 * a->E + a->n), dim3(256), 0, st, a->part_edge, a->red_edge, a->nslot);
     s.update = update ? 1 : 0;
     s.g_pw = g_pw; s.g_imp = g_imp; s.g_foc = g_foc;
     hipLaunchKernelGGL(aligner_small_kernel, dim3(1), dim3(256), 0, st, s);
