@@ -49,6 +49,11 @@ typedef GemmCfg<1, 8, 8, 4, 2> Cfg512x128;  // M 512 x N 128, 512 threads, 160 K
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Region lookups written as selects (a dynamically indexed member array of the by-value kernel argument can make hipcc
+// copy the whole struct to scratch).
+D3R_DEV int head_kind_of(const GemmParams& p, int region) { return region == 0 ? p.head_kind[0] : (region == 1 ? p.head_kind[1] : p.head_kind[2]); }
+D3R_DEV void* head_dst_of(const GemmParams& p, int region) { return region == 0 ? p.head_dst[0] : (region == 1 ? p.head_dst[1] : p.head_dst[2]); }
+
 template <int DT, class CF>
 __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,21 +63,16 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     constexpr int BM = CF::BM, BN = CF::BN, FI = CF::FI, FJ = CF::FJ, STAGE_BYTES = CF::STAGE_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // ---- tile walk: persistent blocks. Tile ids are XCD-contiguous (block b runs on XCD b % 8 and only ever takes ids
-    // congruent to b mod 8), then 8-wide column panels walked row by row, so the tiles an XCD works on at any moment share
-    // A rows and W rows inside its L2.
+    // ---- block -> tile: XCD-contiguous ids, then 8-wide column panels walked row by row ------------------
     const int tiles_n = (p.n_store + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int ntiles = tiles_m * tiles_n;
-    auto tile_origin = [&](int t, int& m0_, int& n0_) __attribute__((always_inline)) {
-        const int lid = xcd_remap(t, ntiles);
-        constexpr int PANEL = 8;
-        const int per_panel = PANEL * tiles_m;
-        const int panel = lid / per_panel, rem_p = lid - panel * per_panel;
-        const int width = min(PANEL, tiles_n - panel * PANEL);
-        const int tm = rem_p / width, tn = panel * PANEL + (rem_p - tm * width);
-        m0_ = tm * BM;
-        n0_ = tn * BN;
-    };
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    constexpr int PANEL = 8;
+    const int per_panel = PANEL * tiles_m;
+    const int panel = lid / per_panel, rem_p = lid - panel * per_panel;
+    const int width = min(PANEL, tiles_n - panel * PANEL);
+    const int tm = rem_p / width, tn = panel * PANEL + (rem_p - tm * width);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bool swap = (BM == BN) && (p.epi == EPI_HEADS) && (p.head_kind[n0 / p.head_c] == HEAD_VT);
 
     // ---- staging addresses (per lane: one 16-byte chunk of APASS activation rows and WPASS weight rows) ---
     const int lrow = wave * 8 + (lane >> 3);                         // row inside a PASS_ROWS slab
@@ -81,38 +81,32 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     // per activation row of a pass: linear operand -> the row's source address; implicit-GEMM operand -> the packed
     // (image base pixel | top-left input y << 16 | top-left input x) of the output pixel. One 64-bit slot either way.
     unsigned long long arow[CF::APASS];
-    auto setup_stage = [&](int m0_, int n0_) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < CF::WPASS; ++q) {
-            const int r = q * CF::PASS_ROWS + lrow;
-            wsrc[q] = reinterpret_cast<const char*>(p.wgt) + ((size_t)(n0_ + r) * p.K) * EB + lchunk * 16;
-        }
+    for (int q = 0; q < CF::WPASS; ++q) {
+        const int r = q * CF::PASS_ROWS + lrow;
+        wsrc[q] = reinterpret_cast<const char*>(p.wgt) + ((size_t)(n0 + r) * p.K) * EB + lchunk * 16;
+    }
 #pragma unroll
-        for (int q = 0; q < CF::APASS; ++q) {
-            const int r = q * CF::PASS_ROWS + lrow;
-            int m = m0_ + r;
-            m = m < p.M ? m : p.M - 1;
-            if (p.amode == AMODE_LINEAR) {
-                arow[q] = (unsigned long long)(size_t)(reinterpret_cast<const char*>(p.act) + ((size_t)m * p.lda) * EB + lchunk * 16);
-            } else {
-                const int hw = p.Hout * p.Wout;
-                const int b = m / hw, rem = m - b * hw;
-                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;   // |.| < 32768
-                const unsigned pk = ((unsigned)iy0 << 16) | ((unsigned)ix0 & 0xFFFFu);
-                arow[q] = ((unsigned long long)pk << 32) | (unsigned)(b * p.Hin * p.Win);
-            }
+    for (int q = 0; q < CF::APASS; ++q) {
+        const int r = q * CF::PASS_ROWS + lrow;
+        int m = m0 + r;
+        m = m < p.M ? m : p.M - 1;
+        if (p.amode == AMODE_LINEAR) {
+            arow[q] = (unsigned long long)(size_t)(reinterpret_cast<const char*>(p.act) + ((size_t)m * p.lda) * EB + lchunk * 16);
+        } else {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;   // |.| < 32768
+            const unsigned pk = ((unsigned)iy0 << 16) | ((unsigned)ix0 & 0xFFFFu);
+            arow[q] = ((unsigned long long)pk << 32) | (unsigned)(b * p.Hin * p.Win);
         }
-    };
-    int tile = blockIdx.x;
-    int m0, n0;
-    tile_origin(tile, m0, n0);
-    setup_stage(m0, n0);
+    }
     const char* zsrc = reinterpret_cast<const char*>(p.zero_page) + lchunk * 16;
 
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
     const uint32_t lds0 = lds_addr(smem) + wave_u * 1024;   // wave-uniform: one 1 KiB DMA piece per wave and pass
-    auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+    auto stage = [&](int kt, int buf) {
         const uint32_t sb = lds0 + buf * STAGE_BYTES;
         const size_t koff = (size_t)kt * KTB;
         if (p.amode == AMODE_LINEAR) {
@@ -140,78 +134,218 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     // ---- fragment read addresses ---------------------------------------------------------------
     const int wi = wave / CF::NWJ, wj = wave - wi * CF::NWJ;
     const int frow = lane & 15, fsw = (lane >> 1) & 7, fgrp = lane >> 4;
+    // P tile supplies i (4 consecutive per lane), Q tile supplies j
+    const int p_off = swap ? 0 : BM * KTB;  // activations live at 0, weights at BM*KTB
+    const int q_off = swap ? BM * KTB : 0;
     const int p_row0 = wi * (FI * 16) + frow, q_row0 = wj * (FJ * 16) + frow;
-    const int i4 = (lane >> 4) * 4;  // first of this lane's 4 consecutive i inside a fragment
-    const int jl = lane & 15;
 
     f32x4_t acc[FI][FJ];
+#pragma unroll
+    for (int a = 0; a < FI; ++a)
+#pragma unroll
+        for (int b = 0; b < FJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // K loop, two LDS stages: [wait own DMA of tile kt] -> barrier (tile kt visible to every wave, every wave is done
+    // reading the other stage) -> issue the DMA of tile kt+1 into the other stage -> math on tile kt. The DMA of tile
+    // kt+1 is in flight during the whole math of tile kt.
     const int nk = p.K / KT;
-    int it = 0;  // K steps done by this block over all its tiles: LDS stage = it & 1
     stage(0, 0);
-    for (;;) {
-        const bool swap = (BM == BN) && (p.epi == EPI_HEADS) && (p.head_kind[n0 / p.head_c] == HEAD_VT);
-        // P tile supplies i (4 consecutive per lane), Q tile supplies j
-        const int p_off = swap ? 0 : BM * KTB;  // activations live at 0, weights at BM*KTB
-        const int q_off = swap ? BM * KTB : 0;
-        const int next_tile = tile + (int)gridDim.x;
-        int nm0 = 0, nn0 = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        d3r_wait_vm0();
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const char* sb = smem + buf * STAGE_BYTES;
+        if constexpr (DT == D3R_F16X3) {
+            // 128 bytes of a row = 32 logical k = 4 groups [hi x8][lo x8]; lane group fgrp owns group fgrp
+            const int chi = ((2 * fgrp) ^ fsw) * 16, clo = ((2 * fgrp + 1) ^ fsw) * 16;
+            uint4 qf[FJ], ql[FJ];
+#pragma unroll
+            for (int f = 0; f < FJ; ++f) {
+                const char* qr = sb + q_off + (q_row0 + f * 16) * KTB;
+                qf[f] = *reinterpret_cast<const uint4*>(qr + chi);
+                ql[f] = *reinterpret_cast<const uint4*>(qr + clo);
+            }
+#pragma unroll
+            for (int fi = 0; fi < FI; ++fi) {
+                const char* pr = sb + p_off + (p_row0 + fi * 16) * KTB;
+                const uint4 pf = *reinterpret_cast<const uint4*>(pr + chi), pl = *reinterpret_cast<const uint4*>(pr + clo);
+#pragma unroll
+                for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], pf, pl, qf[fj], ql[fj]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
+                uint4 pf[FI], qf[FJ];
+#pragma unroll
+                for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (q_row0 + f * 16) * KTB + coff);
+#pragma unroll
+                for (int f = 0; f < FI; ++f) pf[f] = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + f * 16) * KTB + coff);
+#pragma unroll
+                for (int fi = 0; fi < FI; ++fi)
+#pragma unroll
+                    for (int fj = 0; fj < FJ; ++fj) TR::mma16(acc[fi][fj], pf[fi], qf[fj]);
+            }
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    if (p.flags & GF_NOSTORE) {   // measurement aid (D3R_GEMM_NOSTORE=1): keep the math, skip the epilogue's memory traffic
+        float t = 0.f;
 #pragma unroll
         for (int a = 0; a < FI; ++a)
 #pragma unroll
-            for (int b = 0; b < FJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < FJ; ++b) t += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+        if (t == 123.456f) reinterpret_cast<float*>(p.out)[0] = t;
+        return;
+    }
+    const int i4 = (lane >> 4) * 4;  // first of this lane's 4 consecutive i inside a fragment
+    const int jl = lane & 15;
 
-        // K loop, two LDS stages: [wait own DMA of step it] -> barrier (the step's tile is visible to every wave, every
-        // wave is done reading the other stage) -> issue the DMA of the next step into the other stage -> math. The next
-        // step is K-tile kt+1 of this output tile or, on the last K-tile, K-tile 0 of the block's NEXT output tile, whose
-        // load latency is thereby hidden behind this tile's last math step and its epilogue.
-        for (int kt = 0; kt < nk; ++kt, ++it) {
-            const int buf = it & 1;
-            d3r_wait_vm0();
-            __syncthreads();
-            if (kt + 1 < nk) {
-                stage(kt + 1, buf ^ 1);
-            } else if (next_tile < ntiles) {
-                tile_origin(next_tile, nm0, nn0);
-                setup_stage(nm0, nn0);
-                stage(0, buf ^ 1);
-            }
-            const char* sb = smem + buf * STAGE_BYTES;
-            if constexpr (DT == D3R_F16X3) {
-                // 128 bytes of a row = 32 logical k = 4 groups [hi x8][lo x8]; lane group fgrp owns group fgrp
-                const int chi = ((2 * fgrp) ^ fsw) * 16, clo = ((2 * fgrp + 1) ^ fsw) * 16;
-                uint4 qf[FJ], ql[FJ];
+    // ---- wide epilogues: accumulators -> wave-private LDS tile -> whole 128-byte rows ---------------------------------
+    // An MFMA accumulator fragment gives a lane 4 consecutive columns of ONE row and 16 different rows per wave
+    // instruction: stored directly that is 32 B (16-bit types) or 64 B (fp32) per row per instruction, and the store
+    // tail costs as much as the whole K loop at K = 1024 (measured with D3R_GEMM_NOSTORE: 750 -> 1270 TF/s,
+    // profiles/r01_call5). Staging a [64 rows j][64 x 16-bit or 32 x fp32 columns i] tile per wave in the (now idle) LDS
+    // stages turns every global access into 8 lanes x 16 B = one full 128-byte line per row, 8 rows per instruction.
+    constexpr int WROW = 144;   // 128 payload bytes + 16: keeps ds_write_b64/b128 and ds_read_b128 (nearly) conflict free
+    constexpr bool DT16 = (DT == D3R_BF16 || DT == D3R_F16);
+    const bool heads_wide = p.epi == EPI_HEADS && (!swap || (p.ntok & 63) == 0);
+    const bool wide16 = DT16 && !(p.flags & GF_NOWIDE) &&
+                        (((p.epi == EPI_GELU || (p.epi == EPI_T && !p.res1 && !p.res2 && !p.out2)) && (p.ldo & 7) == 0) || heads_wide);
+    const bool wide32 = p.epi == EPI_F32 && !(p.flags & GF_NOWIDE);
+    if (wide16 || wide32) {
+        __syncthreads();   // every wave is done with the K loop's LDS stages
+        char* wreg = smem + wave * (64 * WROW);
+        // P side (i, 4 consecutive per lane) base / Q side (j) base in global coordinates
+        const int ib = (swap ? m0 : n0) + wi * (FI * 16), jb = (swap ? n0 : m0) + wj * (FJ * 16);
+        const int rrow = lane >> 3, rch = lane & 7;   // read phase: 8 lanes cover one 128-byte row
+        if constexpr (DT16) {
+            if (wide16) {
 #pragma unroll
-                for (int f = 0; f < FJ; ++f) {
-                    const char* qr = sb + q_off + (q_row0 + f * 16) * KTB;
-                    qf[f] = *reinterpret_cast<const uint4*>(qr + chi);
-                    ql[f] = *reinterpret_cast<const uint4*>(qr + clo);
+                for (int g = 0; g < FI / 4; ++g) {
+                    // ---- registers -> LDS (bias, activation / RoPE applied here, rounded once to the 16-bit type)
+                    const int ig = ib + g * 64;                 // first i (column n, or token m when swapped) of this group
+                    int region = 0, h = 0;
+                    bool rope = false;
+                    if (p.epi == EPI_HEADS) {
+                        const int nh = swap ? jb : ig;          // 64-aligned n of this (wave, group): one head
+                        region = nh / p.head_c;
+                        h = (nh - region * p.head_c) >> 6;
+                        rope = !swap && head_kind_of(p, region) == HEAD_ROPE;
+                    }
+#pragma unroll
+                    for (int fj = 0; fj < FJ; ++fj) {
+                        const int j = jb + fj * 16 + jl;        // row m (or feature n when swapped)
+                        float bj = 0.f;
+                        if (swap && p.bias && j < p.n_store) bj = p.bias[j];
+                        float cc[4] = {1.f, 1.f, 1.f, 1.f}, ss[4] = {0.f, 0.f, 0.f, 0.f}, cc2[4] = {1.f, 1.f, 1.f, 1.f}, ss2[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (rope) {
+                            const int mm = j < p.M ? j : p.M - 1;
+                            const int b = mm / p.ntok, t = mm - b * p.ntok;
+                            const int ty = t / p.tok_w, tx = t - ty * p.tok_w;
+                            const float4* cy = reinterpret_cast<const float4*>(p.rope_table + ((size_t)ty * 16 + i4) * 2);
+                            const float4* cx = reinterpret_cast<const float4*>(p.rope_table + ((size_t)tx * 16 + i4) * 2);
+                            const float4 a0 = cy[0], a1 = cy[1], b0 = cx[0], b1 = cx[1];  // (cos0,sin0,cos1,sin1), (cos2,sin2,cos3,sin3)
+                            cc[0] = a0.x; ss[0] = a0.y; cc[1] = a0.z; ss[1] = a0.w; cc[2] = a1.x; ss[2] = a1.y; cc[3] = a1.z; ss[3] = a1.w;
+                            cc2[0] = b0.x; ss2[0] = b0.y; cc2[1] = b0.z; ss2[1] = b0.w; cc2[2] = b1.x; ss2[2] = b1.y; cc2[3] = b1.z; ss2[3] = b1.w;
+                        }
+                        float vals[4][4];
+#pragma unroll
+                        for (int fl = 0; fl < 4; ++fl) {
+                            const int i = ig + fl * 16 + i4;
+                            float4 bi = make_float4(bj, bj, bj, bj);
+                            if (!swap && p.bias && i < p.n_store) bi = *reinterpret_cast<const float4*>(p.bias + i);
+                            const f32x4_t a = acc[g * 4 + fl][fj];
+                            vals[fl][0] = a[0] + bi.x; vals[fl][1] = a[1] + bi.y; vals[fl][2] = a[2] + bi.z; vals[fl][3] = a[3] + bi.w;
+                        }
+                        if (rope) {   // pairs (fl 0, fl 1) rotate with y, (fl 2, fl 3) with x
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float u = vals[0][r], v = vals[1][r], u2 = vals[2][r], v2 = vals[3][r];
+                                vals[0][r] = u * cc[r] - v * ss[r];
+                                vals[1][r] = v * cc[r] + u * ss[r];
+                                vals[2][r] = u2 * cc2[r] - v2 * ss2[r];
+                                vals[3][r] = v2 * cc2[r] + u2 * ss2[r];
+                            }
+                        }
+#pragma unroll
+                        for (int fl = 0; fl < 4; ++fl) {
+                            float v0 = vals[fl][0], v1 = vals[fl][1], v2 = vals[fl][2], v3 = vals[fl][3];
+                            if (p.epi == EPI_GELU) { v0 = gelu<DT>(v0); v1 = gelu<DT>(v1); v2 = gelu<DT>(v2); v3 = gelu<DT>(v3); }
+                            if (p.flags & GF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                            uint2 pk;
+                            pk.x = TR::pack2(v0, v1);
+                            pk.y = TR::pack2(v2, v3);
+                            *reinterpret_cast<uint2*>(wreg + (fj * 16 + jl) * WROW + (fl * 16 + i4) * 2) = pk;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS ops are in order; this only fences the compiler
+                    // ---- LDS -> global: row = j, 8 lanes x 16 B = 64 consecutive i
+#pragma unroll
+                    for (int pass = 0; pass < 8; ++pass) {
+                        const int row = pass * 8 + rrow;
+                        const uint4 v = *reinterpret_cast<const uint4*>(wreg + row * WROW + rch * 16);
+                        const int j = jb + row, i = ig + rch * 8;
+                        if (p.epi == EPI_HEADS) {
+                            char* dst = reinterpret_cast<char*>(head_dst_of(p, region));
+                            if (!swap) {            // q / k: [b][h][token][64]
+                                if (j < p.M) {
+                                    const int b = j / p.ntok, t = j - b * p.ntok;
+                                    *reinterpret_cast<uint4*>(dst + ((((size_t)(b * p.heads + h) * p.ntok + t) * 64) + rch * 8) * 2) = v;
+                                }
+                            } else if (i < p.M && j < p.n_store) {   // v^T: [b][h][feature][ldv], 8 consecutive tokens (ntok % 64 == 0)
+                                const int b = i / p.ntok, t = i - b * p.ntok;
+                                const int dd = j - (j / 64) * 64;
+                                *reinterpret_cast<uint4*>(dst + ((((size_t)(b * p.heads + h) * 64 + dd) * p.ldv) + t) * 2) = v;
+                            }
+                        } else if (j < p.M && i < p.n_store) {
+                            char* o = reinterpret_cast<char*>(p.out) + ((size_t)j * p.ldo + i) * 2;
+                            if (i + 8 <= p.n_store) *reinterpret_cast<uint4*>(o) = v;
+                            else *reinterpret_cast<uint2*>(o) = make_uint2(v.x, v.y);   // n_store % 4 == 0
+                        }
+                    }
+                    asm volatile("" ::: "memory");
                 }
-#pragma unroll
-                for (int fi = 0; fi < FI; ++fi) {
-                    const char* pr = sb + p_off + (p_row0 + fi * 16) * KTB;
-                    const uint4 pf = *reinterpret_cast<const uint4*>(pr + chi), pl = *reinterpret_cast<const uint4*>(pr + clo);
-#pragma unroll
-                    for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], pf, pl, qf[fj], ql[fj]);
-                }
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
-                    uint4 pf[FI], qf[FJ];
-#pragma unroll
-                    for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (q_row0 + f * 16) * KTB + coff);
-#pragma unroll
-                    for (int f = 0; f < FI; ++f) pf[f] = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + f * 16) * KTB + coff);
-#pragma unroll
-                    for (int fi = 0; fi < FI; ++fi)
-#pragma unroll
-                        for (int fj = 0; fj < FJ; ++fj) TR::mma16(acc[fi][fj], pf[fi], qf[fj]);
-                }
+                return;
             }
         }
+        if (wide32) {
+#pragma unroll
+            for (int g = 0; g < FI / 2; ++g) {
+                const int ig = ib + g * 32;
+#pragma unroll
+                for (int fl = 0; fl < 2; ++fl) {
+                    const int i = ig + fl * 16 + i4;
+                    const float4 bi = (p.bias && i < p.n_store) ? *reinterpret_cast<const float4*>(p.bias + i) : make_float4(0, 0, 0, 0);
+#pragma unroll
+                    for (int fj = 0; fj < FJ; ++fj) {
+                        const f32x4_t a = acc[g * 2 + fl][fj];
+                        *reinterpret_cast<float4*>(wreg + (fj * 16 + jl) * WROW + (fl * 16 + i4) * 4) = make_float4(a[0] + bi.x, a[1] + bi.y, a[2] + bi.z, a[3] + bi.w);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int pass = 0; pass < 8; ++pass) {
+                    const int row = pass * 8 + rrow;
+                    float4 v = *reinterpret_cast<const float4*>(wreg + row * WROW + rch * 16);
+                    const int m = jb + row, n = ig + rch * 4;
+                    if (m < p.M && n < p.n_store) {
+                        if (p.res1) {
+                            const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res1) + (size_t)m * p.ldr + n);
+                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        }
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n) = v;
+                        if (p.out2) store4<DT>(p.out2, (size_t)m * p.ldo2 + n, v.x, v.y, v.z, v.w);
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+            return;
+        }
+    }
 
-        auto epilogue = [&]() __attribute__((always_inline)) {
-    // ---- epilogue (of the tile at m0, n0) -------------------------------------------------------
     if (!swap) {
         const int nb = n0 + wi * (FI * 16), mb = m0 + wj * (FJ * 16);
         if (p.epi == EPI_HEADS) {
@@ -342,11 +476,6 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             }
         }
     }
-        };  // epilogue
-        epilogue();
-        if (next_tile >= ntiles) break;
-        tile = next_tile; m0 = nm0; n0 = nn0;
-    }
 }
 
 // ---- host side: configuration choice + launch ------------------------------------------------------------------
@@ -356,15 +485,14 @@ template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hi
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<DT, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
         attr_set = true;
     }
-    // persistent grid: one resident block per CU slot (256 CUs x blocks that fit in 160 KiB of LDS); a multiple of 8
-    // so that a block's tile ids stay on its own XCD's range
-    const int ntiles = cdiv(p.M, CF::BM) * cdiv(p.n_store, CF::BN);
-    const int slots = 256 * (CF::LDS * 2 <= 160 * 1024 ? 2 : 1);
-    const int grid = ntiles < slots ? ntiles : slots;
+    const int grid = cdiv(p.M, CF::BM) * cdiv(p.n_store, CF::BN);
     hipLaunchKernelGGL((gemm_kernel<DT, CF>), dim3(grid), dim3(CF::NT), CF::LDS, s, p);
     return hipGetLastError();
 }
 
+// (A persistent variant -- resident blocks walking several tiles and prefetching the next tile's first K step across the
+// epilogue -- was measured 5-10 % slower on MI355X, profiles/r01_call4: on gfx9 vmcnt also counts the epilogue's stores, so
+// the next tile's first wait drains them, which a fresh block never does. One block per tile it is.)
 // Tile configuration choice, from measurements on MI355X (tools/gpu_probe.py gemm, profiles/): the 256x256 tile wins
 // once there are at least ~3 full rounds of 256 resident blocks (M = 49152: 760-1070 vs 640-830 TF/s), the 128x128 tile
 // (2 blocks per CU: one block's prologue / epilogue hides behind the other's K loop) wins below that; N <= 128 problems
@@ -399,7 +527,10 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
     }
 }
 
-hipError_t launch_gemm(int dt, const GemmParams& p, hipStream_t s) {
+hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    if (const char* e = getenv("D3R_GEMM_NOSTORE")) if (e[0] == '1') p.flags |= GF_NOSTORE;
+    if (const char* e = getenv("D3R_GEMM_NOWIDE")) if (e[0] == '1') p.flags |= GF_NOWIDE;   // A/B: direct (narrow) epilogue stores
     const int kt = KTB / (int)dt_bytes(dt);
     if (p.M <= 0 || p.n_pad % 128 != 0 || p.n_store > p.n_pad || p.K % kt != 0 || p.K <= 0) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV && (p.Cin % kt != 0 || p.zero_page == nullptr)) return hipErrorInvalidValue;

@@ -115,6 +115,24 @@ def test_forward_batch_position_independence(gpu):
         assert torch.equal(o1['pts3d'][0], full1['pts3d'][b]) and torch.equal(o2['conf'][0], full2['conf'][b])
 
 
+def test_wide_epilogue_network_is_bit_identical(gpu, monkeypatch):
+    """Whole network with the wide (LDS-staged) epilogues vs the direct stores, including the q/k RoPE scatter and the V^T
+    scatter of the attention projections (tiny_dpt at 128x192 has 96 tokens: ragged V^T falls back; 256x256 has 256 = 4 x 64)."""
+    from oracle.dust3r_ref import build_ref_model
+    oracle = build_ref_model('tiny_dpt')
+    for (H, W) in ((128, 192), (256, 256)):
+        v1, v2 = synthetic_views(2, H, W, seed=31)
+        outs = []
+        for mode in ('0', '1'):
+            monkeypatch.setenv('D3R_GEMM_NOWIDE', mode)
+            eng = engine_from_oracle(oracle, 'tiny_dpt', 'bf16', gpu)
+            r1, r2 = eng(v1, v2)
+            torch.cuda.synchronize()
+            outs.append((r1['pts3d'].clone(), r2['pts3d_in_other_view'].clone(), r1['conf'].clone()))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)
+
+
 def test_two_stream_decoder_is_bit_identical(gpu):
     """The second-stream schedule of decoder side 2 / head 2 only reorders independent launches: outputs are bit-identical
     to the single-stream schedule, repeatedly (a missing cross-stream dependency would show as run-to-run differences)."""

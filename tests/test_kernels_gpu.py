@@ -98,6 +98,24 @@ def test_gemm_tile_configurations(gpu, cfg, monkeypatch):
         assert relerr(ops.conv2d_nhwc(x, w, b, stride=1, pad=1), ref) < OUT_TOL[dtype]
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_wide_and_direct_epilogues_agree(gpu, dtype, monkeypatch):
+    """The LDS-staged wide-row epilogue and the direct fragment stores are two routes for the same values: bit-identical."""
+    from dust3r_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(23)
+    M, N, K = 1111, 840, 512
+    a = torch.randn((M, K), generator=g).to(gpu).to(dtype)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(gpu).to(dtype)
+    b = torch.randn(N, generator=g).to(gpu)
+    res = torch.randn((M, N), generator=g).to(gpu)
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('D3R_GEMM_NOWIDE', mode)
+        outs[mode] = (ops.linear(a, w, b, 'store'), ops.linear(a, w, b, 'gelu'), ops.linear(a, w, b, 'f32', residual=res))
+    for x, y in zip(outs['0'], outs['1']):
+        assert torch.equal(x, y)
+
+
 def _attention_ref(q, k, v, scale):
     a = (q.float() @ k.float().transpose(-1, -2)) * scale
     return (a.softmax(-1) @ v.float()).transpose(1, 2).flatten(2)

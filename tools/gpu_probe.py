@@ -52,6 +52,14 @@ def gemm_probe():
                 line += f' | cfg {cfg or "auto"}: {ms:7.3f} ms {2 * M * N * K / ms / 1e9:7.1f} TF/s'
             os.environ.pop('D3R_GEMM_CFG', None)
             if dt == torch.bfloat16:
+                os.environ['D3R_GEMM_NOSTORE'] = '1'     # same launch without the epilogue's memory traffic
+                ms = timeit(run)
+                os.environ.pop('D3R_GEMM_NOSTORE', None)
+                line += f' | auto/no-store: {ms:7.3f} ms {2 * M * N * K / ms / 1e9:7.1f} TF/s'
+                os.environ['D3R_GEMM_NOWIDE'] = '1'      # A/B: direct fragment stores instead of the LDS-staged wide rows
+                ms = timeit(run)
+                os.environ.pop('D3R_GEMM_NOWIDE', None)
+                line += f' | auto/narrow-store: {ms:7.3f} ms {2 * M * N * K / ms / 1e9:7.1f} TF/s'
                 ms2 = timeit(lambda: torch.nn.functional.linear(a, w[:N], None))
                 line += f' | hipBLASLt {ms2:7.3f} ms {2 * M * N * K / ms2 / 1e9:7.1f} TF/s'
             print(line)
