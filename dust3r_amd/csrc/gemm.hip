@@ -27,24 +27,31 @@
 
 namespace d3r {
 
-static constexpr int KTB = 128;  // bytes of K per tile row
-
 // NWI x NWJ waves; a wave owns FI x FJ 16x16 fragments. The "i" side (4 consecutive per lane) is n (weights) unless
-// the block works on a V^T region (roles swapped; square configurations only).
-template <int NWI_, int NWJ_, int FI_, int FJ_, int MINW_> struct GemmCfg {
-    static constexpr int NWI = NWI_, NWJ = NWJ_, FI = FI_, FJ = FJ_, MINW = MINW_;
+// the block works on a V^T region (roles swapped; square configurations only). KTB: bytes of K per LDS row and K step
+// (128 = 64 bf16: two MFMA k-steps per barrier; 64 = 32 bf16: one k-step, half the LDS, so two blocks fit on a CU).
+template <int NWI_, int NWJ_, int FI_, int FJ_, int MINW_, int KTB_ = 128> struct GemmCfg {
+    static constexpr int NWI = NWI_, NWJ = NWJ_, FI = FI_, FJ = FJ_, MINW = MINW_, KTB = KTB_;
     static constexpr int NW = NWI * NWJ, NT = NW * 64;
     static constexpr int BN = NWI * FI * 16, BM = NWJ * FJ * 16;
-    static constexpr int PASS_ROWS = NW * 8;                 // rows staged by one global_load_lds per wave
+    static constexpr int CPR = KTB / 16;                     // 16-byte chunks per row
+    static constexpr int RPI = 64 / CPR;                     // rows covered by one 1 KiB wave DMA instruction
+    static constexpr int PASS_ROWS = NW * RPI;               // rows staged by one global_load_lds per wave
     static constexpr int APASS = BM / PASS_ROWS, WPASS = BN / PASS_ROWS;
     static constexpr int STAGE_BYTES = (BM + BN) * KTB;
     static constexpr int LDS = 2 * STAGE_BYTES;
+    // bank swizzle of the lane-linear LDS image: slot = chunk ^ key(row). Checked against the ds_read_b128 service groups
+    // of gfx950 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32): a fragment read (lane -> row lane & 15, chunk group lane >> 4)
+    // touches 16 distinct 16-byte slots of the 256-byte bank row in every group, for both row widths.
+    __host__ __device__ static constexpr int key(int row) { return KTB == 128 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); }
 };
 typedef GemmCfg<2, 4, 8, 4, 2> Cfg256;      // 256 x 256, 512 threads, 128 KiB LDS, 1 block / CU
 typedef GemmCfg<2, 4, 4, 4, 2> Cfg256x128;  // M 256 x N 128, 512 threads, 96 KiB LDS, 1 block / CU
 typedef GemmCfg<2, 2, 4, 4, 2> Cfg128;      // 128 x 128, 256 threads, 64 KiB LDS, 2 blocks / CU
 typedef GemmCfg<1, 8, 8, 4, 2> Cfg512x128;  // M 512 x N 128, 512 threads, 160 KiB LDS (all of it): N <= 128 convolutions with the
                                             // 128 x 64 per-wave tile of Cfg256 (12 ds_read_b128 per 32 MFMAs instead of 8 per 16)
+typedef GemmCfg<1, 4, 8, 4, 2, 64> Cfg256x128w4;  // M 256 x N 128, 4 waves of 128 (n) x 64 (m), 64-byte K rows: 48 KiB LDS, TWO
+                                                  // blocks per CU -- one block's epilogue (an HBM write burst) runs under the other's K loop
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -59,6 +66,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TR = Traits<DT>;
     constexpr int EB = TR::EB;
+    constexpr int KTB = CF::KTB;
     constexpr int KT = KTB / EB;  // elements of K per tile
     constexpr int BM = CF::BM, BN = CF::BN, FI = CF::FI, FJ = CF::FJ, STAGE_BYTES = CF::STAGE_BYTES;
 
@@ -72,11 +80,15 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     const int width = min(PANEL, tiles_n - panel * PANEL);
     const int tm = rem_p / width, tn = panel * PANEL + (rem_p - tm * width);
     const int m0 = tm * BM, n0 = tn * BN;
-    const bool swap = (BM == BN) && (p.epi == EPI_HEADS) && (p.head_kind[n0 / p.head_c] == HEAD_VT);
+    // V^T regions of the attention projections: with the wide epilogue (16-bit types, token count a multiple of 64) the
+    // transposition happens in the LDS staging tile and any tile shape works; otherwise the MFMA operand roles are
+    // swapped for that block (square tiles only) so that a lane owns 4 consecutive tokens.
+    const bool vt_wide = (DT == D3R_BF16 || DT == D3R_F16) && p.epi == EPI_HEADS && (p.ntok & 63) == 0 && !(p.flags & GF_NOWIDE);
+    const bool swap = !vt_wide && (BM == BN) && (p.epi == EPI_HEADS) && (head_kind_of(p, n0 / p.head_c) == HEAD_VT);
 
     // ---- staging addresses (per lane: one 16-byte chunk of APASS activation rows and WPASS weight rows) ---
-    const int lrow = wave * 8 + (lane >> 3);                         // row inside a PASS_ROWS slab
-    const int lchunk = (lane & 7) ^ (((lane >> 4) + wave * 4) & 7);  // logical chunk fetched by this lane
+    const int lrow = wave * CF::RPI + lane / CF::CPR;                // row inside a PASS_ROWS slab
+    const int lchunk = (lane % CF::CPR) ^ CF::key(lrow);             // logical chunk fetched by this lane (slot = chunk ^ key(row))
     const char* wsrc[CF::WPASS];
     // per activation row of a pass: linear operand -> the row's source address; implicit-GEMM operand -> the packed
     // (image base pixel | top-left input y << 16 | top-left input x) of the output pixel. One 64-bit slot either way.
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
 
     // ---- fragment read addresses ---------------------------------------------------------------
     const int wi = wave / CF::NWJ, wj = wave - wi * CF::NWJ;
-    const int frow = lane & 15, fsw = (lane >> 1) & 7, fgrp = lane >> 4;
+    const int frow = lane & 15, fsw = CF::key(frow), fgrp = lane >> 4;   // fragment rows start at multiples of 16: key(row) == key(frow)
     // P tile supplies i (4 consecutive per lane), Q tile supplies j
     const int p_off = swap ? 0 : BM * KTB;  // activations live at 0, weights at BM*KTB
     const int q_off = swap ? BM * KTB : 0;
@@ -157,6 +169,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
         const char* sb = smem + buf * STAGE_BYTES;
         if constexpr (DT == D3R_F16X3) {
+            static_assert(DT != D3R_F16X3 || KTB == 128, "split-fp16 rows are [hi x8][lo x8] groups: 128-byte K rows only");
             // 128 bytes of a row = 32 logical k = 4 groups [hi x8][lo x8]; lane group fgrp owns group fgrp
             const int chi = ((2 * fgrp) ^ fsw) * 16, clo = ((2 * fgrp + 1) ^ fsw) * 16;
             uint4 qf[FJ], ql[FJ];
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             }
         } else {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < KTB / 64; ++ks) {
                 const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
                 uint4 pf[FI], qf[FJ];
 #pragma unroll
@@ -228,12 +241,13 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                     // ---- registers -> LDS (bias, activation / RoPE applied here, rounded once to the 16-bit type)
                     const int ig = ib + g * 64;                 // first i (column n, or token m when swapped) of this group
                     int region = 0, h = 0;
-                    bool rope = false;
+                    bool rope = false, vt = false;
                     if (p.epi == EPI_HEADS) {
                         const int nh = swap ? jb : ig;          // 64-aligned n of this (wave, group): one head
                         region = nh / p.head_c;
                         h = (nh - region * p.head_c) >> 6;
                         rope = !swap && head_kind_of(p, region) == HEAD_ROPE;
+                        vt = !swap && head_kind_of(p, region) == HEAD_VT;   // transposed through the staging tile
                     }
 #pragma unroll
                     for (int fj = 0; fj < FJ; ++fj) {
@@ -278,7 +292,15 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                             uint2 pk;
                             pk.x = TR::pack2(v0, v1);
                             pk.y = TR::pack2(v2, v3);
-                            *reinterpret_cast<uint2*>(wreg + (fj * 16 + jl) * WROW + (fl * 16 + i4) * 2) = pk;
+                            if (!vt) {
+                                *reinterpret_cast<uint2*>(wreg + (fj * 16 + jl) * WROW + (fl * 16 + i4) * 2) = pk;
+                            } else {   // tile[feature][token]: this lane's 4 features of token fj*16+jl
+                                char* tcol = wreg + (fl * 16 + i4) * WROW + (fj * 16 + jl) * 2;
+                                *reinterpret_cast<uint16_t*>(tcol) = (uint16_t)(pk.x & 0xFFFFu);
+                                *reinterpret_cast<uint16_t*>(tcol + WROW) = (uint16_t)(pk.x >> 16);
+                                *reinterpret_cast<uint16_t*>(tcol + 2 * WROW) = (uint16_t)(pk.y & 0xFFFFu);
+                                *reinterpret_cast<uint16_t*>(tcol + 3 * WROW) = (uint16_t)(pk.y >> 16);
+                            }
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS ops are in order; this only fences the compiler
@@ -290,7 +312,13 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                         const int j = jb + row, i = ig + rch * 8;
                         if (p.epi == EPI_HEADS) {
                             char* dst = reinterpret_cast<char*>(head_dst_of(p, region));
-                            if (!swap) {            // q / k: [b][h][token][64]
+                            if (vt) {               // v^T from the transposed tile: row = feature, 8 consecutive tokens per lane
+                                const int tok = jb + rch * 8;
+                                if (tok < p.M) {
+                                    const int b = tok / p.ntok, t = tok - b * p.ntok;
+                                    *reinterpret_cast<uint4*>(dst + ((((size_t)(b * p.heads + h) * 64 + row) * p.ldv) + t) * 2) = v;
+                                }
+                            } else if (!swap) {     // q / k: [b][h][token][64]
                                 if (j < p.M) {
                                     const int b = j / p.ntok, t = j - b * p.ntok;
                                     *reinterpret_cast<uint4*>(dst + ((((size_t)(b * p.heads + h) * p.ntok + t) * 64) + rch * 8) * 2) = v;
@@ -497,16 +525,18 @@ template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hi
 // once there are at least ~3 full rounds of 256 resident blocks (M = 49152: 760-1070 vs 640-830 TF/s), the 128x128 tile
 // (2 blocks per CU: one block's prologue / epilogue hides behind the other's K loop) wins below that; N <= 128 problems
 // (DPT head convolutions) take the 512x128 / 256x128 tiles so that no half-empty 256-wide tile is computed.
-int gemm_pick_config(const GemmParams& p) {
+int gemm_pick_config(const GemmParams& p, int dt) {
     const int n_rows = p.n_rows > 0 ? p.n_rows : p.n_pad;
-    const bool heads = p.epi == EPI_HEADS;
-    const bool ok256 = cdiv(p.n_store, 256) * 256 <= n_rows && (!heads || p.head_c % 256 == 0);
+    const bool wide_vt = (dt == D3R_BF16 || dt == D3R_F16) && (p.ntok & 63) == 0 && !(p.flags & GF_NOWIDE);
+    const bool heads = p.epi == EPI_HEADS && !wide_vt;   // "heads" = needs a square tile (operand-role swap for V^T)
+    const bool ok256 = cdiv(p.n_store, 256) * 256 <= n_rows && (p.epi != EPI_HEADS || p.head_c % 256 == 0);
     int forced = p.force_cfg;
     if (forced < 0) {   // D3R_GEMM_CFG=0|1|2|3 pins the tile configuration (parity tests, probes); infeasible choices are ignored
         const char* e = getenv("D3R_GEMM_CFG");
-        if (e && e[0] >= '0' && e[0] <= '3' && e[1] == 0) forced = e[0] - '0';
+        if (e && e[0] >= '0' && e[0] <= '4' && e[1] == 0) forced = e[0] - '0';
     }
-    if (forced == GEMM_CFG_128 || (forced == GEMM_CFG_256 && ok256) || ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128) && !heads))
+    if (forced == GEMM_CFG_128 || (forced == GEMM_CFG_256 && ok256) ||
+        ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128 || forced == GEMM_CFG_256x128W4) && !heads))
         return forced;
     if (!heads && p.n_store <= 128) {
         if (cdiv(p.M, 512) >= 512) return GEMM_CFG_512x128;
@@ -519,7 +549,12 @@ int gemm_pick_config(const GemmParams& p) {
 }
 
 template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
-    switch (gemm_pick_config(p)) {
+    int cfg = gemm_pick_config(p, DT);
+    if (cfg == GEMM_CFG_256x128W4 && (DT == D3R_F16X3 || p.K % (64 / (int)dt_bytes(DT)) != 0)) cfg = GEMM_CFG_256x128;
+    if constexpr (DT != D3R_F16X3) {
+        if (cfg == GEMM_CFG_256x128W4) return launch_cfg<DT, Cfg256x128w4>(p, s);
+    }
+    switch (cfg) {
         case GEMM_CFG_256: return launch_cfg<DT, Cfg256>(p, s);
         case GEMM_CFG_256x128: return launch_cfg<DT, Cfg256x128>(p, s);
         case GEMM_CFG_512x128: return launch_cfg<DT, Cfg512x128>(p, s);
@@ -531,7 +566,7 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     if (const char* e = getenv("D3R_GEMM_NOSTORE")) if (e[0] == '1') p.flags |= GF_NOSTORE;
     if (const char* e = getenv("D3R_GEMM_NOWIDE")) if (e[0] == '1') p.flags |= GF_NOWIDE;   // A/B: direct (narrow) epilogue stores
-    const int kt = KTB / (int)dt_bytes(dt);
+    const int kt = 128 / (int)dt_bytes(dt);
     if (p.M <= 0 || p.n_pad % 128 != 0 || p.n_store > p.n_pad || p.K % kt != 0 || p.K <= 0) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV && (p.Cin % kt != 0 || p.zero_page == nullptr)) return hipErrorInvalidValue;
     if (p.epi == EPI_HEADS && p.head_c % 128 != 0 && p.head_c < (1 << 29)) return hipErrorInvalidValue;

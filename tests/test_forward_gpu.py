@@ -74,7 +74,7 @@ def test_forward_matches_oracle(gpu, precision, config, B, H, W):
     compare(eng, oracle, v1, v2, *TOLS[precision], tag=f'{config} {precision} {B}x{H}x{W}')
 
 
-@pytest.mark.parametrize('cfg', ['0', '1', '2', '3'])
+@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '4'])
 @pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
 def test_forward_with_pinned_gemm_tile(gpu, precision, cfg, monkeypatch):
     """The whole network with the GEMM tile configuration pinned (D3R_GEMM_CFG): the 256-wide tiles' q/k RoPE scatter,
@@ -85,6 +85,17 @@ def test_forward_with_pinned_gemm_tile(gpu, precision, cfg, monkeypatch):
     eng = engine_from_oracle(oracle, 'tiny_dpt', precision, gpu)
     v1, v2 = synthetic_views(3, 64, 96, seed=5)
     compare(eng, oracle, v1, v2, *TOLS[precision], tag=f'tiny_dpt {precision} cfg{cfg}')
+
+
+@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '4'])
+def test_forward_16bit_with_pinned_gemm_tile(gpu, cfg, monkeypatch):
+    """fp16 engine, 128x128 images = 64 tokens: the wide epilogues incl. the LDS-transposed V^T scatter on every tile shape."""
+    from oracle.dust3r_ref import build_ref_model
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg)
+    oracle = build_ref_model('tiny_dpt')
+    eng = engine_from_oracle(oracle, 'tiny_dpt', 'fp16', gpu)
+    v1, v2 = synthetic_views(2, 128, 128, seed=6)
+    compare(eng, oracle, v1, v2, *TOLS['fp16'], tag=f'tiny_dpt fp16 128x128 cfg{cfg}')
 
 
 @pytest.mark.parametrize('name', ['forward_tiny_dpt.pt', 'forward_tiny_linear.pt'])
@@ -115,22 +126,33 @@ def test_forward_batch_position_independence(gpu):
         assert torch.equal(o1['pts3d'][0], full1['pts3d'][b]) and torch.equal(o2['conf'][0], full2['conf'][b])
 
 
-def test_wide_epilogue_network_is_bit_identical(gpu, monkeypatch):
-    """Whole network with the wide (LDS-staged) epilogues vs the direct stores, including the q/k RoPE scatter and the V^T
-    scatter of the attention projections (tiny_dpt at 128x192 has 96 tokens: ragged V^T falls back; 256x256 has 256 = 4 x 64)."""
+def test_wide_epilogue_network_matches_direct_stores(gpu, monkeypatch):
+    """Whole network with the wide (LDS-staged) epilogues vs the direct fragment stores, including the q/k RoPE scatter and
+    the V^T scatter of the attention projections (tiny_dpt at 128x192 has 96 tokens: the ragged V^T falls back to direct
+    stores; 256x256 has 256 = 4 x 64 tokens: wide V^T). fp32 mode (only the fp32-residual epilogue changes route, same
+    arithmetic): bit-identical. fp16 mode (RoPE / GELU are re-associated between the two routes, so single-ulp differences
+    are legitimate and get amplified by the depth): both within the mode's tolerance of the oracle and close to each other."""
     from oracle.dust3r_ref import build_ref_model
     oracle = build_ref_model('tiny_dpt')
     for (H, W) in ((128, 192), (256, 256)):
         v1, v2 = synthetic_views(2, H, W, seed=31)
-        outs = []
-        for mode in ('0', '1'):
-            monkeypatch.setenv('D3R_GEMM_NOWIDE', mode)
-            eng = engine_from_oracle(oracle, 'tiny_dpt', 'bf16', gpu)
-            r1, r2 = eng(v1, v2)
-            torch.cuda.synchronize()
-            outs.append((r1['pts3d'].clone(), r2['pts3d_in_other_view'].clone(), r1['conf'].clone()))
-        for x, y in zip(*outs):
-            assert torch.equal(x, y)
+        with torch.no_grad():
+            r1, _ = oracle(v1, v2)
+        for precision in ('fp32', 'fp16'):
+            outs = []
+            for mode in ('0', '1'):
+                monkeypatch.setenv('D3R_GEMM_NOWIDE', mode)
+                eng = engine_from_oracle(oracle, 'tiny_dpt', precision, gpu)
+                e1, e2 = eng(v1, v2)
+                torch.cuda.synchronize()
+                outs.append((e1['pts3d'].clone(), e2['pts3d_in_other_view'].clone(), e1['conf'].clone()))
+            if precision == 'fp32':
+                for x, y in zip(*outs):
+                    assert torch.equal(x, y)
+            else:
+                for o in outs:
+                    assert pix_rel_p99(o[0], r1['pts3d']) < TOLS['fp16'][0] and pix_rel(o[0], r1['pts3d'])[1] < TOLS['fp16'][1]
+                assert pix_rel(outs[0][0], outs[1][0].cpu())[1] < 5e-3
 
 
 def test_two_stream_decoder_is_bit_identical(gpu):
