@@ -30,8 +30,8 @@ namespace d3r {
 // NWI x NWJ waves; a wave owns FI x FJ 16x16 fragments. The "i" side (4 consecutive per lane) is n (weights) unless
 // the block works on a V^T region (roles swapped; square configurations only). KTB: bytes of K per LDS row and K step
 // (128 = 64 bf16: two MFMA k-steps per barrier; 64 = 32 bf16: one k-step, half the LDS, so two blocks fit on a CU).
-template <int NWI_, int NWJ_, int FI_, int FJ_, int MINW_, int KTB_ = 128> struct GemmCfg {
-    static constexpr int NWI = NWI_, NWJ = NWJ_, FI = FI_, FJ = FJ_, MINW = MINW_, KTB = KTB_;
+template <int NWI_, int NWJ_, int FI_, int FJ_, int MINW_, int KTB_ = 128, int NSTAGE_ = 2> struct GemmCfg {
+    static constexpr int NWI = NWI_, NWJ = NWJ_, FI = FI_, FJ = FJ_, MINW = MINW_, KTB = KTB_, NSTAGE = NSTAGE_;
     static constexpr int NW = NWI * NWJ, NT = NW * 64;
     static constexpr int BN = NWI * FI * 16, BM = NWJ * FJ * 16;
     static constexpr int CPR = KTB / 16;                     // 16-byte chunks per row
@@ -39,7 +39,8 @@ template <int NWI_, int NWJ_, int FI_, int FJ_, int MINW_, int KTB_ = 128> struc
     static constexpr int PASS_ROWS = NW * RPI;               // rows staged by one global_load_lds per wave
     static constexpr int APASS = BM / PASS_ROWS, WPASS = BN / PASS_ROWS;
     static constexpr int STAGE_BYTES = (BM + BN) * KTB;
-    static constexpr int LDS = 2 * STAGE_BYTES;
+    static constexpr int LDS = NSTAGE * STAGE_BYTES;
+    static constexpr int LPS = APASS + WPASS;                // DMA instructions per lane per K step
     // bank swizzle of the lane-linear LDS image: slot = chunk ^ key(row). Checked against the ds_read_b128 service groups
     // of gfx950 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32): a fragment read (lane -> row lane & 15, chunk group lane >> 4)
     // touches 16 distinct 16-byte slots of the 256-byte bank row in every group, for both row widths.
@@ -50,8 +51,9 @@ typedef GemmCfg<2, 4, 4, 4, 2> Cfg256x128;  // M 256 x N 128, 512 threads, 96 Ki
 typedef GemmCfg<2, 2, 4, 4, 2> Cfg128;      // 128 x 128, 256 threads, 64 KiB LDS, 2 blocks / CU
 typedef GemmCfg<1, 8, 8, 4, 2> Cfg512x128;  // M 512 x N 128, 512 threads, 160 KiB LDS (all of it): N <= 128 convolutions with the
                                             // 128 x 64 per-wave tile of Cfg256 (12 ds_read_b128 per 32 MFMAs instead of 8 per 16)
-typedef GemmCfg<1, 4, 8, 4, 2, 64> Cfg256x128w4;  // M 256 x N 128, 4 waves of 128 (n) x 64 (m), 64-byte K rows: 48 KiB LDS, TWO
-                                                  // blocks per CU -- one block's epilogue (an HBM write burst) runs under the other's K loop
+typedef GemmCfg<2, 4, 8, 4, 2, 64, 4> Cfg256s4;   // 256 x 256, 8 waves, 64-byte K rows, FOUR LDS stages (128 KiB): three K steps of DMA in flight
+typedef GemmCfg<1, 4, 8, 4, 2, 64, 3> Cfg256x128w4;  // M 256 x N 128, 4 waves of 128 (n) x 64 (m), 64-byte K rows: 48 KiB LDS, TWO
+                                                  // blocks per CU, three stages (72 KiB)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -151,22 +153,34 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     const int q_off = swap ? BM * KTB : 0;
     const int p_row0 = wi * (FI * 16) + frow, q_row0 = wj * (FJ * 16) + frow;
 
+    static_assert(CF::NSTAGE >= 2 && CF::NSTAGE <= 4, "vmcnt ladder below covers up to 2 younger steps in flight");
     f32x4_t acc[FI][FJ];
 #pragma unroll
     for (int a = 0; a < FI; ++a)
 #pragma unroll
         for (int b = 0; b < FJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // K loop, two LDS stages: [wait own DMA of tile kt] -> barrier (tile kt visible to every wave, every wave is done
-    // reading the other stage) -> issue the DMA of tile kt+1 into the other stage -> math on tile kt. The DMA of tile
-    // kt+1 is in flight during the whole math of tile kt.
+    // K loop over an NSTAGE-deep LDS ring. Step kt: [wait until this wave's DMA of step kt has landed, leaving the younger
+    // steps' loads in flight: a counted vmcnt -- the asm-issued loads are the only VMEM ops of the loop] -> barrier (step
+    // kt is visible to every wave; every wave is done reading the stage of step kt-1) -> issue the DMA of step
+    // kt+NSTAGE-1 into that freed stage -> math on step kt. NSTAGE-1 steps of HBM/L2 latency are covered.
+    constexpr int NS = CF::NSTAGE, LPS = CF::LPS;
     const int nk = p.K / KT;
-    stage(0, 0);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s, s);
+    int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        d3r_wait_vm0();
+        const int ahead = min(NS - 2, nk - 1 - kt);   // younger steps already issued
+        if (NS == 2 || ahead <= 0) d3r_wait_vm0();
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        if (kt + NS - 1 < nk) {
+            int nb = buf + NS - 1;
+            nb = nb >= NS ? nb - NS : nb;
+            stage(kt + NS - 1, nb);
+        }
         const char* sb = smem + buf * STAGE_BYTES;
         if constexpr (DT == D3R_F16X3) {
             static_assert(DT != D3R_F16X3 || KTB == 128, "split-fp16 rows are [hi x8][lo x8] groups: 128-byte K rows only");
@@ -201,6 +215,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                     for (int fj = 0; fj < FJ; ++fj) TR::mma16(acc[fi][fj], pf[fi], qf[fj]);
             }
         }
+        buf = buf + 1 >= NS ? 0 : buf + 1;
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
@@ -533,10 +548,10 @@ int gemm_pick_config(const GemmParams& p, int dt) {
     int forced = p.force_cfg;
     if (forced < 0) {   // D3R_GEMM_CFG=0|1|2|3 pins the tile configuration (parity tests, probes); infeasible choices are ignored
         const char* e = getenv("D3R_GEMM_CFG");
-        if (e && e[0] >= '0' && e[0] <= '4' && e[1] == 0) forced = e[0] - '0';
+        if (e && e[0] >= '0' && e[0] <= '5' && e[1] == 0) forced = e[0] - '0';
     }
     if (forced == GEMM_CFG_128 || (forced == GEMM_CFG_256 && ok256) ||
-        ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128 || forced == GEMM_CFG_256x128W4) && !heads))
+        ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128 || forced == GEMM_CFG_256x128W4) && !heads) || (forced == GEMM_CFG_256S4 && ok256))
         return forced;
     if (!heads && p.n_store <= 128) {
         if (cdiv(p.M, 512) >= 512) return GEMM_CFG_512x128;
@@ -550,9 +565,11 @@ int gemm_pick_config(const GemmParams& p, int dt) {
 
 template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     int cfg = gemm_pick_config(p, DT);
-    if (cfg == GEMM_CFG_256x128W4 && (DT == D3R_F16X3 || p.K % (64 / (int)dt_bytes(DT)) != 0)) cfg = GEMM_CFG_256x128;
+    if (cfg == GEMM_CFG_256x128W4 && DT == D3R_F16X3) cfg = GEMM_CFG_256x128;   // split-fp16 rows need 128-byte K rows
+    if (cfg == GEMM_CFG_256S4 && DT == D3R_F16X3) cfg = GEMM_CFG_256;
     if constexpr (DT != D3R_F16X3) {
         if (cfg == GEMM_CFG_256x128W4) return launch_cfg<DT, Cfg256x128w4>(p, s);
+        if (cfg == GEMM_CFG_256S4) return launch_cfg<DT, Cfg256s4>(p, s);
     }
     switch (cfg) {
         case GEMM_CFG_256: return launch_cfg<DT, Cfg256>(p, s);

@@ -9,7 +9,7 @@ enum { AMODE_LINEAR = 0, AMODE_CONV = 1 };
 enum { EPI_T = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_HEADS = 3, EPI_CONVT = 4 };
 enum { HEAD_ROPE = 1, HEAD_VT = 2, HEAD_PLAIN = 3 };
 enum { GF_RELU = 1, GF_NOSTORE = 2, GF_NOWIDE = 4 };
-enum { GEMM_CFG_128 = 0, GEMM_CFG_256 = 1, GEMM_CFG_256x128 = 2, GEMM_CFG_512x128 = 3, GEMM_CFG_256x128W4 = 4 };
+enum { GEMM_CFG_128 = 0, GEMM_CFG_256 = 1, GEMM_CFG_256x128 = 2, GEMM_CFG_512x128 = 3, GEMM_CFG_256x128W4 = 4, GEMM_CFG_256S4 = 5 };
 
 struct GemmParams {
     const void* act = nullptr;   // [M][lda] (linear) or NHWC image batch (conv), element type DT
@@ -18,6 +18,7 @@ struct GemmParams {
     int M = 0, K = 0, n_pad = 0; // K in elements, multiple of 128/sizeof(DT); n_pad: multiple of 128, >= n_store
     int n_rows = 0;              // weight rows actually allocated (>= n_pad; 0 = n_pad): bounds the tile width choice
     int force_cfg = -1;          // GEMM_CFG_* to override the heuristic (tests / probes)
+    int stagger_cycles = 0, stagger_blocks = 0;   // set by the launcher: start delay of half of the first round's blocks
     int n_store = 0;             // columns written (multiple of 4, <= n_pad)
     int lda = 0;
     int amode = AMODE_LINEAR;

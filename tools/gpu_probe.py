@@ -43,7 +43,7 @@ def gemm_probe():
             def run():
                 check(lib.d3r_linear(ptr(a), ptr(w), ptr(b), ptr(out), None, M, N, K, 0, ops._dt(a), current_stream()))
             line = f'  M={M} N={N} K={K} {str(dt)[6:]:9s}'
-            for cfg in (('0', '1', '2', '4', None) if dt == torch.bfloat16 else (None,)):
+            for cfg in (('0', '1', '4', '5', None) if dt == torch.bfloat16 else (None,)):
                 if cfg is None:
                     os.environ.pop('D3R_GEMM_CFG', None)
                 else:
@@ -77,7 +77,7 @@ def conv_probe():
         b = torch.randn(Cout, device=dev)
         fl = 2 * B * H * W * Cout * 9 * Cin
         line = f'  {H}x{W} {Cin}->{Cout}'
-        for cfg in ('0', '1', '2', '3', '4', None):
+        for cfg in ('1', '3', '4', '5', None):
             if cfg is None:
                 os.environ.pop('D3R_GEMM_CFG', None)
             else:
