@@ -30,7 +30,7 @@ struct AlignerView {
     const int* img_area;    // [n]
     const int* adj_off;     // [n+1]
     const int* adj_es;      // [2E] entries e*2+side, grouped by projecting image
-    const float* pred[2];   // [E][maxA][3]
+    const float* pred[2];   // PLANAR copies owned by the handle: [E][3][maxA] (x, y, z planes: unit-stride float4 loads)
     const float* wgt[2];    // [E][maxA]
     float* depth;           // [n][maxA] log-depth
     float* depth_m;
@@ -119,8 +119,10 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
         float4 nq0, nq1, nq2, nww;
         {
             const int es = sh_es[0];
-            const float4* pp = reinterpret_cast<const float4*>(a.pred[es & 1] + ((size_t)(es >> 1) * a.maxA + pl) * 3);
-            nq0 = pp[0]; nq1 = pp[1]; nq2 = pp[2];
+            const float* pp = a.pred[es & 1] + (size_t)(es >> 1) * 3 * a.maxA + pl;
+            nq0 = *reinterpret_cast<const float4*>(pp);
+            nq1 = *reinterpret_cast<const float4*>(pp + a.maxA);
+            nq2 = *reinterpret_cast<const float4*>(pp + 2 * (size_t)a.maxA);
             nww = *reinterpret_cast<const float4*>(a.wgt[es & 1] + (size_t)(es >> 1) * a.maxA + pl);
         }
         for (int j = 0; j < nb; ++j) {
@@ -129,8 +131,10 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
             const float4 q0 = nq0, q1 = nq1, q2 = nq2, ww = nww;
             {   // unconditional (index clamped): a branch here would make the compiler wait for the loads at its join
                 const int es2 = sh_es[j + 1 < nb ? j + 1 : j];
-                const float4* pp = reinterpret_cast<const float4*>(a.pred[es2 & 1] + ((size_t)(es2 >> 1) * a.maxA + pl) * 3);
-                nq0 = pp[0]; nq1 = pp[1]; nq2 = pp[2];
+                const float* pp = a.pred[es2 & 1] + (size_t)(es2 >> 1) * 3 * a.maxA + pl;
+                nq0 = *reinterpret_cast<const float4*>(pp);
+                nq1 = *reinterpret_cast<const float4*>(pp + a.maxA);
+                nq2 = *reinterpret_cast<const float4*>(pp + 2 * (size_t)a.maxA);
                 nww = *reinterpret_cast<const float4*>(a.wgt[es2 & 1] + (size_t)(es2 >> 1) * a.maxA + pl);
             }
             float M[12];
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) gm[k] = 0.f;
             {
-                const float pr[PPT][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, {q1.z, q1.w, q2.x}, {q2.y, q2.z, q2.w}};
+                const float pr[PPT][3] = {{q0.x, q1.x, q2.x}, {q0.y, q1.y, q2.y}, {q0.z, q1.z, q2.z}, {q0.w, q1.w, q2.w}};   // q0 = x, q1 = y, q2 = z planes
                 const float ia = active ? a.inv_area[side] : 0.f;   // zero weight: inactive lanes contribute nothing
                 const float wv[PPT] = {ww.x * ia, ww.y * ia, ww.z * ia, ww.w * ia};
 #pragma unroll
@@ -225,6 +229,16 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
     if (threadIdx.x < PW) {
         const int v = threadIdx.x;
         a.part_img[((size_t)img * a.nslot + slot) * PW + v] = (sh_part[0][0][v] + sh_part[1][0][v]) + (sh_part[2][0][v] + sh_part[3][0][v]);
+    }
+}
+
+// one-time re-layout at create: [E][maxA][3] (the reference's stacked pointmaps) -> [E][3][maxA]
+__global__ __launch_bounds__(256) void aligner_planarize_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n_pix_total, int maxA) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_pix_total; i += (size_t)gridDim.x * 256) {
+        const size_t e = i / maxA, p = i - e * maxA;
+        const float x = in[i * 3], y = in[i * 3 + 1], z = in[i * 3 + 2];
+        float* o = out + e * 3 * (size_t)maxA + p;
+        o[0] = x; o[maxA] = y; o[2 * (size_t)maxA] = z;
     }
 }
 
@@ -404,6 +418,7 @@ struct d3r_aligner {
     std::vector<int> h_w, h_h, h_area;
     int *d_w = nullptr, *d_h = nullptr, *d_area = nullptr, *d_adj_off = nullptr, *d_adj_es = nullptr;
     const float *pred[2] = {nullptr, nullptr}, *wgt[2] = {nullptr, nullptr};
+    float* planar = nullptr;  // [2][E][3][maxA] re-laid-out copies of pred_i / pred_j
     float *pw_poses = nullptr, *pw_adaptors = nullptr, *im_poses = nullptr, *im_depth = nullptr, *im_focals = nullptr, *im_pp = nullptr;
     float* state = nullptr;  // one arena: Adam moments, derived matrices, partials
     float *depth_m, *depth_v, *pw_m, *pw_v, *imp_m, *imp_v, *foc_m, *foc_v, *d_edge, *d_img, *part_edge, *part_img, *loss_hist, *g_scratch;
@@ -453,7 +468,7 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     }
     a->inv_area[0] = (float)(1.0 / ta[0]);
     a->inv_area[1] = (float)(1.0 / ta[1]);
-    a->pred[0] = pred_i; a->pred[1] = pred_j; a->wgt[0] = w_i; a->wgt[1] = w_j;
+    a->wgt[0] = w_i; a->wgt[1] = w_j;   // (pred_i / pred_j are copied into a planar layout below)
     a->pw_poses = pw_poses; a->pw_adaptors = pw_adaptors; a->im_poses = im_poses; a->im_depth = im_depth;
     a->im_focals = im_focals; a->im_pp = im_pp;
     a->base_scale = base_scale; a->pw_break = pw_break; a->focal_break = focal_break;
@@ -487,12 +502,22 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     (void)hipMemcpy(a->d_area, a->h_area.data(), n_imgs * sizeof(int), hipMemcpyHostToDevice);
     (void)hipMemcpy(a->d_adj_off, off.data(), (n_imgs + 1) * sizeof(int), hipMemcpyHostToDevice);
     (void)hipMemcpy(a->d_adj_es, es.data(), 2 * (size_t)n_edges * sizeof(int), hipMemcpyHostToDevice);
+    {
+        const size_t npix = (size_t)n_edges * max_area;
+        if (hipMalloc((void**)&a->planar, 2 * npix * 3 * sizeof(float)) != hipSuccess) { (void)hipFree(a->state); (void)hipFree(a->d_w); delete a; return D3R_ERR_ALLOC; }
+        const int grid = (int)((npix + 255) / 256 < 65536 ? (npix + 255) / 256 : 65536);
+        hipLaunchKernelGGL(aligner_planarize_kernel, dim3(grid), dim3(256), 0, nullptr, pred_i, a->planar, npix, max_area);
+        hipLaunchKernelGGL(aligner_planarize_kernel, dim3(grid), dim3(256), 0, nullptr, pred_j, a->planar + npix * 3, npix, max_area);
+        if (hipDeviceSynchronize() != hipSuccess) { (void)hipFree(a->planar); (void)hipFree(a->state); (void)hipFree(a->d_w); delete a; return D3R_ERR_LAUNCH; }
+        a->pred[0] = a->planar; a->pred[1] = a->planar + npix * 3;
+    }
     *out = a;
     return D3R_OK;
 }
 
 extern "C" int d3r_aligner_destroy(d3r_aligner* a) {
     if (!a) return D3R_OK;
+    (void)hipFree(a->planar);
     (void)hipFree(a->state);
     (void)hipFree(a->d_w);
     delete a;

@@ -138,8 +138,9 @@ int d3r_model_debug_read(d3r_model* m, int what, float* out_f32, size_t max_elem
  * Parameter tensors use the reference's own parameterisation and names (state_dict(trainable=True)):
  *   pw_poses [E][8] = quat XYZW, signed-log translation, log scale;  pw_adaptors [E][2] (frozen);
  *   im_poses [n][7];  im_depthmaps [n][max_area] log-depth;  im_focals [n] = focal_break*log(f);  im_pp [n][2] (frozen)
- * They live in caller-owned device memory and are updated IN PLACE; the handle borrows them and the
- * pred/weight tensors until destroy. pred_* [E][max_area][3], w_* [E][max_area] = conf_trf(conf)
+ * They live in caller-owned device memory and are updated IN PLACE; the handle borrows them and the weight
+ * tensors until destroy. pred_* [E][max_area][3] (read ONCE at create: the handle keeps its own planar
+ * [E][3][max_area] copy so that the hot loop streams unit-stride float4s), w_* [E][max_area] = conf_trf(conf)
  * (zero in padding), fp32. ei/ej/img_h/img_w are HOST arrays.
  */
 typedef struct d3r_aligner d3r_aligner;
