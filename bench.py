@@ -52,16 +52,43 @@ def build_model(precision, device):
     return m
 
 
+GEMM_CFG_NAMES = {0: 'GemmCfg<2,2,4,4,2,128,2> (128x128 tile)', 1: 'GemmCfg<2,4,8,4,2,128,2> (256x256 tile)', 2: 'GemmCfg<2,4,4,4,2,128,2> (256x128 tile)',
+                  3: 'GemmCfg<1,8,8,4,2,128,2> (512x128 tile)', 4: 'GemmCfg<1,4,8,4,2,64,3> (256x128, 4 waves)', 5: 'GemmCfg<2,4,8,4,2,64,4> (256x256, 4 stages)'}
+
+
 def read_profile(model):
+    """Per kernel symbol: gemm_kernel<dtype, cfg> (linear + implicit-GEMM conv launches together), attention, other."""
     from dust3r_amd._lib import lib
-    out = {}
-    for kind, name in enumerate(('gemm', 'conv', 'attention', 'other')):
+
+    def rd(kind):
         n, ms, work = C.c_int(), C.c_double(), C.c_double()
-        rc = lib.d3r_model_profile_read(model._engine, kind, C.byref(n), C.byref(ms), C.byref(work))
-        if rc != 0:
+        if lib.d3r_model_profile_read(model._engine, kind, C.byref(n), C.byref(ms), C.byref(work)) != 0:
             return None
-        out[name] = dict(launches=n.value, ms=ms.value, gflop=work.value / 1e9)
+        return dict(launches=n.value, ms=ms.value, gflop=work.value / 1e9)
+    out = {'gemm_cfg': {}, 'linear': dict(launches=0, ms=0.0, gflop=0.0), 'conv': dict(launches=0, ms=0.0, gflop=0.0)}
+    for cfg in range(8):
+        lin, cv = rd(cfg), rd(8 + cfg)
+        if lin is None or cv is None:
+            return None
+        for k in ('launches', 'ms', 'gflop'):
+            out['linear'][k] += lin[k]
+            out['conv'][k] += cv[k]
+        if lin['launches'] + cv['launches']:
+            out['gemm_cfg'][cfg] = {k: lin[k] + cv[k] for k in ('launches', 'ms', 'gflop')}
+    out['attention'], out['other'] = rd(16), rd(17)
     return out
+
+
+def pmc_traffic_gb(cfg):
+    """HBM bytes per launch of the dominant kernel from the last committed rocprofv3 PMC passes (profiles/pmc_latest.json,
+    written by tools/summarize_prof.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950). None when no such file travels with the repository."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')) as f:
+            d = json.load(f)
+        return d.get('gemm_cfg', {}).get(str(cfg), {}).get('hbm_gb_per_launch')
+    except Exception:
+        return None
 
 
 def bench_aligner(device, niter=300, n_views=20):
@@ -84,10 +111,16 @@ def bench_aligner(device, niter=300, n_views=20):
     ms = e0.elapsed_time(e1)
     bytes_iter = E * A * 32 + n * A * 4 * 6                    # preds + weights once, depth param/Adam r/w
     gbs = bytes_iter * niter / (ms * 1e-3) / 1e9
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')) as f:
+            traffic = json.load(f).get('aligner_main_kernel', {}).get('hbm_gb_per_launch')
+    except Exception:
+        pass
     res = dict(metric='global_aligner_iters_per_sec', value=niter / (ms * 1e-3), unit='iters/s', n_views=n, n_edges=E, niter=niter,
                ms_total=ms, final_loss=loss,
-               roofline=dict(bound='hbm', kernel='aligner_main_kernel', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS,
-                             bytes_per_iter=bytes_iter, traffic=None))
+               roofline=dict(bound='hbm', kernel='d3r::aligner_main_kernel (+ reduce + small kernels: whole iteration timed)', achieved=gbs,
+                             peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, bytes_per_iter=bytes_iter, traffic=traffic))
     return res, (out, init)
 
 
@@ -253,19 +286,25 @@ def main():
         prof = read_profile(model)
         lib.d3r_model_set_option(model._engine, 1, 0)
         if prof:
-            g = prof['gemm']
-            cv = prof['conv']
-            launches = g['launches'] + cv['launches']
-            ms = g['ms'] + cv['ms']
-            gflop = g['gflop'] + cv['gflop']
-            ach = gflop / ms                                     # GFLOP / ms == TFLOP/s
+            # dominant kernel = the gemm_kernel instantiation with the largest total time (one kernel symbol in rocprofv3)
+            dom = max(prof['gemm_cfg'], key=lambda c: prof['gemm_cfg'][c]['ms'])
+            d = prof['gemm_cfg'][dom]
+            total_ms = prof['linear']['ms'] + prof['conv']['ms'] + prof['attention']['ms'] + prof['other']['ms']
+            ach = d['gflop'] / d['ms']                              # GFLOP / ms == TFLOP/s
             result['roofline'] = {
-                'bound': 'mfma', 'kernel': f'gemm_kernel<{args.precision}> (nn.Linear GEMMs + implicit-GEMM convolutions: one kernel)',
-                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
-                'launches_per_step': launches, 'avg_launch_ms': ms / launches, 'gflop_per_launch': gflop / launches,
-                'share_of_step_time': ms / sum(v['ms'] for v in prof.values())}
-            result['kernels'] = {k: dict(v, tflops=(v['gflop'] / v['ms'] if v['ms'] > 0 else 0.0)) for k, v in prof.items()}
-            log('[bench] per-class: ' + ', '.join(f"{k} {v['ms']:.1f} ms / {v['launches']} launches / {v['gflop'] / max(v['ms'], 1e-9):.0f} TF/s" for k, v in prof.items()))
+                'bound': 'mfma', 'kernel': f'd3r::gemm_kernel<{args.precision}, {GEMM_CFG_NAMES.get(dom, dom)}>',
+                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
+                'traffic': pmc_traffic_gb(dom), 'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
+                'gflop_per_launch': d['gflop'] / d['launches'], 'share_of_step_time': d['ms'] / total_ms,
+                'timing': 'HIP events around every launch on the launch stream, single-stream schedule, one extra forward after the timed region'}
+            kern = {f'gemm_kernel cfg{c}': dict(v, tflops=v['gflop'] / v['ms']) for c, v in prof['gemm_cfg'].items()}
+            for k in ('attention', 'other'):
+                v = prof[k]
+                kern[k] = dict(v, tflops=(v['gflop'] / v['ms'] if v['ms'] > 0 else 0.0))
+            kern['all_gemm_linear'] = dict(prof['linear'], tflops=prof['linear']['gflop'] / max(prof['linear']['ms'], 1e-9))
+            kern['all_gemm_conv'] = dict(prof['conv'], tflops=prof['conv']['gflop'] / max(prof['conv']['ms'], 1e-9))
+            result['kernels'] = kern
+            log('[bench] per-kernel: ' + ', '.join(f"{k} {v['ms']:.1f} ms / {v['launches']} launches / {v['tflops']:.0f} TF/s" for k, v in kern.items()))
 
     if world > 1:
         dist.barrier()

@@ -44,3 +44,47 @@ for tag in ('pmc_fetch', 'pmc_write'):
         print('== pmc', f)
         for (k, c), (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
             print(f'  {c:12s} sum {v:16.1f} over {n:7d} dispatches, mean {v / n:14.2f}  {k}')
+
+# ---- machine-readable digest for bench.py's roofline.traffic (copied by hand to profiles/pmc_latest.json) ------------------
+import json  # noqa: E402
+
+CFG_OF = {(2, 2, 4, 4, 2, 128, 2): 0, (2, 4, 8, 4, 2, 128, 2): 1, (2, 4, 4, 4, 2, 128, 2): 2, (1, 8, 8, 4, 2, 128, 2): 3,
+          (1, 4, 8, 4, 2, 64, 3): 4, (2, 4, 8, 4, 2, 64, 4): 5}
+
+
+def pmc_means(tag, counter):
+    res = {}
+    for f in sorted(glob.glob(os.path.join(out, tag, '**', '*counter_collection.csv'), recursive=True)):
+        agg = defaultdict(lambda: [0, 0.0])
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get('Counter_Name') != counter:
+                    continue
+                agg[row.get('Kernel_Name', '?')][0] += 1
+                agg[row.get('Kernel_Name', '?')][1] += float(row.get('Counter_Value', 0))
+        for k, (n, v) in agg.items():
+            res[k] = (n, v / n)
+    return res
+
+
+fetch, write = pmc_means('pmc_fetch', 'FETCH_SIZE'), pmc_means('pmc_write', 'WRITE_SIZE')
+digest = {'note': 'per-launch means from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --single-stream`; counters in KiB; '
+                  'hbm_gb_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / 1e9 (FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950, '
+                  'MI355X_MICROARCH.md section HBM; WRITE_SIZE uncalibrated)', 'gemm_cfg': {}}
+for name in set(fetch) | set(write):
+    fk = fetch.get(name, (0, 0.0))[1]
+    wk = write.get(name, (0, 0.0))[1]
+    entry = dict(kernel=name[:120], dispatches=fetch.get(name, write.get(name))[0], fetch_size_kib=fk, write_size_kib=wk,
+                 hbm_gb_per_launch=(2 * fk + wk) * 1024 / 1e9)
+    mm = re.search(r'gemm_kernel<0, d3r::GemmCfg<([0-9, ]+)>', name)
+    if mm:
+        cfg = CFG_OF.get(tuple(int(x) for x in mm.group(1).split(',')))
+        if cfg is not None:
+            digest['gemm_cfg'][str(cfg)] = entry
+    elif 'aligner_main_kernel' in name:
+        digest['aligner_main_kernel'] = entry
+    elif 'attention_kernel<0>' in name:
+        digest['attention_kernel'] = entry
+if fetch or write:
+    with open(os.path.join(out, 'pmc_latest.json'), 'w') as f:
+        json.dump(digest, f, indent=1)
