@@ -584,34 +584,44 @@ size_t dpt_arena_bytes(const d3r_model* m, const DptHead& D, int bc, int th, int
 }
 
 // returns bytes needed when ws == nullptr (dry run), else runs
-size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1,
-                    float* pts2, float* conf2, hipStream_t st, int* rc_out) {
+// Phases: the encoder runs over `nimg` images (img1 holds the first nimg1 of them, img2 the rest: forward passes B + B,
+// d3r_model_encode passes everything in img1) and leaves the normalised features [nimg][N][Ce] in `feat`; the decoder +
+// heads run over B pairs whose features are feat[0..B) (view 1) and feat[B..2B) (view 2). forward = both phases with
+// feat inside the workspace; encode / decode run one phase with a caller-owned feature buffer.
+enum { PH_ENCODE = 1, PH_DECODE = 2 };
+size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const float* img1, const float* img2, int nimg1, int nimg, void* feat_ext,
+                    int B, int H, int W, float* pts1, float* conf1, float* pts2, float* conf2, hipStream_t st, int* rc_out) {
     const d3r_model_config& cf = m->cfg;
     const int ps = cf.patch_size, th = H / ps, tw = W / ps, N = th * tw;
     const int Ce = cf.enc_embed_dim, Cd = cf.dec_embed_dim, He = cf.enc_num_heads, Hd = cf.dec_num_heads;
-    const int M2 = 2 * B * N, M1 = B * N, ldv = rup(N, 64);
+    const bool do_enc = (phases & PH_ENCODE) != 0, do_dec = (phases & PH_DECODE) != 0;
+    const int Me = do_enc ? nimg * N : 0;                    // encoder rows
+    const int M1 = do_dec ? B * N : 0, M2d = 2 * M1;         // decoder rows per side / both sides
+    const int M2 = Me > M2d ? Me : M2d;                      // rows of the shared scratch buffers
+    const int nvt = (do_enc ? nimg : 0) > 2 * (do_dec ? B : 0) ? nimg : 2 * B;   // images the v^T buffer must hold
+    const int ldv = rup(N, 64);
     const size_t eb = dt_bytes(m->dt);
     const bool dry = ws == nullptr;
     Arena ar(ws, ws_cap);
     Ctx c{m, st};
 
-    float* x = (float*)ar.take((size_t)M2 * Ce * 4);
+    float* x = (float*)ar.take((size_t)Me * Ce * 4);
     void* xn = ar.take((size_t)M2 * Ce * eb);
     void* q = ar.take((size_t)M2 * Ce * eb);
     void* k = ar.take((size_t)M2 * Ce * eb);
-    void* vt = ar.take((size_t)2 * B * He * 64 * ldv * eb);
+    void* vt = ar.take((size_t)nvt * He * 64 * ldv * eb);
     void* ao = ar.take((size_t)M2 * Ce * eb);
     void* hb = ar.take((size_t)M2 * 4 * Ce * eb);   // MLP hidden; also holds the gathered patches
-    void* encn = ar.take((size_t)M2 * Ce * eb);
-    float* f[2] = {(float*)ar.take((size_t)M2 * Cd * 4), (float*)ar.take((size_t)M2 * Cd * 4)};
-    void* yn = ar.take((size_t)M2 * Cd * eb);
+    void* encn = feat_ext ? feat_ext : ar.take((size_t)(Me > M2d ? Me : M2d) * Ce * eb);
+    float* f[2] = {(float*)ar.take((size_t)M2d * Cd * 4), (float*)ar.take((size_t)M2d * Cd * 4)};
+    void* yn = ar.take((size_t)M2d * Cd * eb);
     void* hook[2][3];
     for (int s = 0; s < 2; ++s)
         for (int j = 0; j < 3; ++j) hook[s][j] = ar.take((size_t)M1 * Cd * eb);
-    float* lin_out = cf.head_type == 0 ? (float*)ar.take((size_t)M2 * 4 * ps * ps * 4) : nullptr;
+    float* lin_out = cf.head_type == 0 ? (float*)ar.take((size_t)M2d * 4 * ps * ps * 4) : nullptr;
     const size_t common_end = (ar.off + 255) & ~(size_t)255;
     const int chunk = B < 32 ? B : 32;   // 288 GB of HBM: batch the head as wide as the encoder (low-resolution stages need the rows)
-    const size_t head_arena = cf.head_type == 1 ? dpt_arena_bytes(m, m->dpt[0], chunk, th, tw) : 0;
+    const size_t head_arena = (cf.head_type == 1 && do_dec) ? dpt_arena_bytes(m, m->dpt[0], chunk, th, tw) : 0;
 
     if (!dry) {
         // stream plan: encoder on the caller's stream; then side 0 stays there and side 1 runs on the model's second
@@ -626,25 +636,28 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
             c.chk(hipStreamWaitEvent(S[0], m->ev_side, 0));
             c.chk(hipStreamWaitEvent(S[1], m->ev_main, 0));
         };
-        if (ldv != N) D3R_OTHER(hipMemsetAsync(vt, 0, (size_t)2 * B * He * 64 * ldv * eb, st));
-        // ---- encoder: both image batches in one pass (model.py:142-151) ----------------------------------
-        const size_t pk = 3 * (size_t)ps * ps;
-        D3R_OTHER(launch_patchify(m->dt, img1, hb, B, H, W, ps, st));
-        D3R_OTHER(launch_patchify(m->dt, img2, (char*)hb + (size_t)M1 * pk * eb, B, H, W, ps, st));
-        gemm_linear(c, hb, (int)pk, m->patch, M2, EPI_F32, x, Ce);
-        for (int l = 0; l < cf.enc_depth; ++l) {
-            const EncBlk& b = m->enc[l];
-            D3R_OTHER(launch_layernorm(m->dt, x, b.n1.g, b.n1.b, xn, M2, Ce, 1e-6f, st));
-            self_attention(c, xn, b.qkv, M2, Ce, He, 2 * B, N, tw, ldv, q, k, vt, ao);
-            gemm_linear(c, ao, Ce, b.proj, M2, EPI_F32, x, Ce, x);
-            D3R_OTHER(launch_layernorm(m->dt, x, b.n2.g, b.n2.b, xn, M2, Ce, 1e-6f, st));
-            gemm_linear(c, xn, Ce, b.fc1, M2, EPI_GELU, hb, 4 * Ce);
-            gemm_linear(c, hb, 4 * Ce, b.fc2, M2, EPI_F32, x, Ce, x);
+        if (ldv != N) D3R_OTHER(hipMemsetAsync(vt, 0, (size_t)nvt * He * 64 * ldv * eb, st));
+        if (do_enc) {
+            // ---- encoder: all images of the call in one pass (model.py:142-151 concatenates the two views) --------
+            const size_t pk = 3 * (size_t)ps * ps;
+            if (nimg1 > 0) D3R_OTHER(launch_patchify(m->dt, img1, hb, nimg1, H, W, ps, st));
+            if (nimg > nimg1) D3R_OTHER(launch_patchify(m->dt, img2, (char*)hb + (size_t)nimg1 * N * pk * eb, nimg - nimg1, H, W, ps, st));
+            gemm_linear(c, hb, (int)pk, m->patch, Me, EPI_F32, x, Ce);
+            for (int l = 0; l < cf.enc_depth; ++l) {
+                const EncBlk& b = m->enc[l];
+                D3R_OTHER(launch_layernorm(m->dt, x, b.n1.g, b.n1.b, xn, Me, Ce, 1e-6f, st));
+                self_attention(c, xn, b.qkv, Me, Ce, He, nimg, N, tw, ldv, q, k, vt, ao);
+                gemm_linear(c, ao, Ce, b.proj, Me, EPI_F32, x, Ce, x);
+                D3R_OTHER(launch_layernorm(m->dt, x, b.n2.g, b.n2.b, xn, Me, Ce, 1e-6f, st));
+                gemm_linear(c, xn, Ce, b.fc1, Me, EPI_GELU, hb, 4 * Ce);
+                gemm_linear(c, hb, 4 * Ce, b.fc2, Me, EPI_F32, x, Ce, x);
+            }
+            D3R_OTHER(launch_layernorm(m->dt, x, m->enc_norm.g, m->enc_norm.b, encn, Me, Ce, 1e-6f, st));
+            m->last_encn = encn; m->last_encn_elems = (size_t)Me * Ce;
         }
-        D3R_OTHER(launch_layernorm(m->dt, x, m->enc_norm.g, m->enc_norm.b, encn, M2, Ce, 1e-6f, st));
-        m->last_encn = encn; m->last_encn_elems = (size_t)M2 * Ce;
+        if (do_dec) {
         // ---- decoder (model.py:172-191): side s reads the PREVIOUS layer's (f_s, f_other) ---------------------
-        gemm_linear(c, encn, Ce, m->dec_embed, M2, EPI_F32, f[0], Cd);
+        gemm_linear(c, encn, Ce, m->dec_embed, M2d, EPI_F32, f[0], Cd);
         if (two) {
             c.chk(hipEventRecord(m->ev_main, S[0]));
             c.chk(hipStreamWaitEvent(S[1], m->ev_main, 0));
@@ -720,6 +733,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
             c.chk(hipEventRecord(m->ev_side, S[1]));
             c.chk(hipStreamWaitEvent(S[0], m->ev_side, 0));
         }
+        }  // do_dec
         c.mark(PRF_END, 0.0);
     }
     if (rc_out) *rc_out = c.rc;
@@ -728,16 +742,15 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, const float* img1, co
 
 }  // namespace
 
-extern "C" int d3r_model_forward(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1,
-                                 float* pts2, float* conf2, void* stream) {
-    if (!m || !img1 || !img2 || B <= 0 || !pts1 || !conf1 || !pts2 || !conf2) return D3R_ERR_INVALID;
+static int run_phases(d3r_model* m, int phases, const float* img1, const float* img2, int nimg1, int nimg, void* feat, int B, int H, int W,
+                      float* pts1, float* conf1, float* pts2, float* conf2, hipStream_t st) {
     const int ps = m->cfg.patch_size;
     if (H % ps || W % ps || H <= 0 || W <= 0 || H / ps > 511 || W / ps > 511) return D3R_ERR_SHAPE;
     if (d3r_model_missing(m) != 0) return D3R_ERR_STATE;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t need = forward_impl(m, nullptr, 0, img1, img2, B, H, W, pts1, conf1, pts2, conf2, st, nullptr);
+    const size_t need = forward_impl(m, nullptr, 0, phases, img1, img2, nimg1, nimg, feat, B, H, W, pts1, conf1, pts2, conf2, st, nullptr);
     if (need > m->ws_bytes) {
         (void)hipStreamSynchronize(st);
+        if (m->side) (void)hipStreamSynchronize(m->side);
         if (m->ws) (void)hipFree(m->ws);
         m->ws = nullptr; m->ws_bytes = 0;
         if (hipMalloc(&m->ws, need) != hipSuccess) return D3R_ERR_ALLOC;
@@ -745,6 +758,29 @@ extern "C" int d3r_model_forward(d3r_model* m, const float* img1, const float* i
     }
     int rc = D3R_OK;
     m->prof_rec.clear();
-    forward_impl(m, m->ws, m->ws_bytes, img1, img2, B, H, W, pts1, conf1, pts2, conf2, st, &rc);
+    forward_impl(m, m->ws, m->ws_bytes, phases, img1, img2, nimg1, nimg, feat, B, H, W, pts1, conf1, pts2, conf2, st, &rc);
     return rc;
+}
+
+extern "C" int d3r_model_forward(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1,
+                                 float* pts2, float* conf2, void* stream) {
+    if (!m || !img1 || !img2 || B <= 0 || !pts1 || !conf1 || !pts2 || !conf2) return D3R_ERR_INVALID;
+    return run_phases(m, PH_ENCODE | PH_DECODE, img1, img2, B, 2 * B, nullptr, B, H, W, pts1, conf1, pts2, conf2, (hipStream_t)stream);
+}
+
+extern "C" size_t d3r_model_feature_bytes(const d3r_model* m, int H, int W) {
+    if (!m || H <= 0 || W <= 0) return 0;
+    const int ps = m->cfg.patch_size;
+    return (size_t)(H / ps) * (W / ps) * m->cfg.enc_embed_dim * dt_bytes(m->dt);
+}
+
+extern "C" int d3r_model_encode(d3r_model* m, const float* img, int n, int H, int W, void* feat_out, void* stream) {
+    if (!m || !img || n <= 0 || !feat_out) return D3R_ERR_INVALID;
+    return run_phases(m, PH_ENCODE, img, nullptr, n, n, feat_out, 0, H, W, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int d3r_model_decode(d3r_model* m, const void* feat, int B, int H, int W, float* pts1, float* conf1, float* pts2, float* conf2,
+                                void* stream) {
+    if (!m || !feat || B <= 0 || !pts1 || !conf1 || !pts2 || !conf2) return D3R_ERR_INVALID;
+    return run_phases(m, PH_DECODE, nullptr, nullptr, 0, 0, const_cast<void*>(feat), B, H, W, pts1, conf1, pts2, conf2, (hipStream_t)stream);
 }

@@ -278,6 +278,43 @@ class AsymmetricCroCo3DStereo(nn.Module):
         return res1, res2
 
 
+# ---- encode-once API (an MI355X-side addition: the reference re-encodes a view for every pair it appears in) -------------
+def _encode(self, img):
+    """img (n,3,H,W) fp32 in [-1,1] -> opaque feature tensor (n, feature_bytes) uint8 on the engine's device."""
+    _lib.require_device()
+    if self._engine is None:
+        raise _lib.D3RError('model is not on a GPU: call .to("cuda") first (dust3r_amd has no CPU execution path)')
+    n, _, H, W = img.shape
+    assert H % self.patch_size == 0 and W % self.patch_size == 0
+    dev = self._engine_device
+    with torch.cuda.device(dev):
+        x = img.to(dev, torch.float32).contiguous()
+        fb = int(lib.d3r_model_feature_bytes(self._engine, H, W))
+        feat = torch.empty((n, fb), dtype=torch.uint8, device=dev)
+        check(lib.d3r_model_encode(self._engine, ptr(x), n, H, W, ptr(feat), current_stream()), 'model_encode')
+    return feat
+
+
+def _decode(self, feat, H, W):
+    """feat (2B, feature_bytes): view-1 features of the B pairs, then their view-2 features -> (res1, res2) like forward."""
+    _lib.require_device()
+    B = feat.shape[0] // 2
+    dev = self._engine_device
+    with torch.cuda.device(dev):
+        feat = feat.contiguous()
+        pts1 = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+        pts2 = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+        conf1 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        conf2 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        check(lib.d3r_model_decode(self._engine, ptr(feat), B, H, W, ptr(pts1), ptr(conf1), ptr(pts2), ptr(conf2), current_stream()),
+              'model_decode')
+    return dict(pts3d=pts1, conf=conf1), dict(pts3d_in_other_view=pts2, conf=conf2)
+
+
+AsymmetricCroCo3DStereo.encode_images = _encode
+AsymmetricCroCo3DStereo.decode_pairs = _decode
+
+
 def parse_model_string(args):
     """Parse the constructor string stored in a checkpoint (`ckpt['args'].model`), e.g.
     "AsymmetricCroCo3DStereo(pos_embed='RoPE100', img_size=(512, 512), head_type='dpt', ...)",

@@ -114,6 +114,17 @@ int d3r_model_missing(const d3r_model* m);
  * pts2 (= pred2['pts3d_in_other_view']) and conf2. Workspace is owned by the model and grown on demand. */
 int d3r_model_forward(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1, float* pts2,
                       float* conf2, void* stream);
+/* The same forward in two calls, so that a view shared by several pairs is encoded ONCE (the reference re-encodes it for every
+ * pair, dust3r/model.py:142-151; make_pairs' complete graph over n views has n(n-1) pair slots but only n images):
+ *   d3r_model_encode: patch-embed + encoder + enc_norm (model.py:128-140) over n images fp32 [n][3][H][W] -> feat_out, an
+ *                     opaque device buffer of n * d3r_model_feature_bytes(m, H, W) bytes (engine dtype, [n][tokens][enc_dim]);
+ *   d3r_model_decode: decoder + heads (model.py:172-211) over B pairs whose features the caller gathered into feat =
+ *                     [view-1 features of the B pairs | view-2 features of the B pairs] (2 B feature blocks).
+ * encode + gather + decode gives bit-identical outputs to d3r_model_forward on the same pairs. */
+size_t d3r_model_feature_bytes(const d3r_model* m, int H, int W);
+int d3r_model_encode(d3r_model* m, const float* img, int n, int H, int W, void* feat_out, void* stream);
+int d3r_model_decode(d3r_model* m, const void* feat, int B, int H, int W, float* pts1, float* conf1, float* pts2, float* conf2,
+                     void* stream);
 /* bytes of device memory currently held (weights + workspace) */
 size_t d3r_model_device_bytes(const d3r_model* m);
 /* Measurement hook (bench.py): with D3R_MODEL_OPT_PROFILE = 1 the next forwards record one HIP event before every

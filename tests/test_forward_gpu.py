@@ -244,3 +244,22 @@ def test_config1_pairviewer_pipeline(gpu):
     assert poses.shape == (2, 4, 4) and focals.shape[0] == 2 and torch.isfinite(poses).all() and torch.isfinite(focals).all()
     pts = scene.get_pts3d()
     assert len(pts) == 2 and pts[0].shape == (224, 224, 3) and len(scene.get_masks()) == 2
+
+
+def test_encode_once_inference_is_bit_identical(gpu):
+    """inference() with each distinct image encoded once (d3r_model_encode / d3r_model_decode) returns exactly what the
+    pair-by-pair path returns: same structure, same view order, bit-identical predictions (complete symmetrised graph)."""
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.inference import inference
+    from dust3r_amd.synthetic import synthetic_image_list
+    from oracle.dust3r_ref import build_ref_model
+    eng = engine_from_oracle(build_ref_model('tiny_dpt'), 'tiny_dpt', 'bf16', gpu)
+    imgs = synthetic_image_list(4, 64, 96, seed=13)
+    pairs = make_pairs(imgs, 'complete', None, True)
+    a = inference(pairs, eng, gpu, batch_size=3, verbose=False, encode_once=False)
+    b = inference(pairs, eng, gpu, batch_size=3, verbose=False, encode_once=True)
+    assert a['view1']['idx'] == b['view1']['idx'] and a['view2']['idx'] == b['view2']['idx'] and b['loss'] is None
+    assert torch.equal(a['view1']['img'], b['view1']['img']) and b['pred1']['pts3d'].device.type == 'cpu'
+    for k in ('pts3d', 'conf'):
+        assert torch.equal(a['pred1'][k], b['pred1'][k])
+    assert torch.equal(a['pred2']['pts3d_in_other_view'], b['pred2']['pts3d_in_other_view']) and torch.equal(a['pred2']['conf'], b['pred2']['conf'])

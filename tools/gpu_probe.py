@@ -134,6 +134,35 @@ def forward_probe():
             print(f'  {prec} B={B:3d}: {ms:9.2f} ms/forward  {B / ms * 1e3:8.2f} pairs/s  {B * 1856.8 / ms:8.1f} TF/s eff  mem {m.device_bytes() / 2**30:.1f} GiB')
 
 
+def cache_probe():
+    """BASELINE configs[2] on one GPU: 20 views -> 190 pairs (complete graph), forward only, device-resident tensors:
+    pair-by-pair (every pair re-encodes both views, as the reference does) vs encode-once (20 encoder passes + 190 decodes)."""
+    from dust3r_amd.model import AsymmetricCroCo3DStereo
+    from dust3r_amd.synthetic import MODEL_CONFIGS, OUT_GAIN, scene_edges, synthetic_state_dict
+    cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
+    print('== 20 views -> 190 pairs, forward only', cfg)
+    m = AsymmetricCroCo3DStereo(precision='bf16', landscape_only=False, **MODEL_CONFIGS[cfg])
+    m.load_state_dict(synthetic_state_dict({k: torch.empty(v, device='meta') for k, v in m._spec.items()}, 0, OUT_GAIN[cfg], device=dev))
+    m.to(dev)
+    n, H, W, bs = 20, 384, 512, 32
+    imgs = torch.rand((n, 3, H, W), device=dev) * 2 - 1
+    edges = scene_edges(n, 'complete', False)
+    i1 = torch.tensor([i for i, j in edges], device=dev)
+    i2 = torch.tensor([j for i, j in edges], device=dev)
+
+    def plain():
+        for s in range(0, len(edges), bs):
+            m(dict(img=imgs[i1[s:s + bs]]), dict(img=imgs[i2[s:s + bs]]))
+
+    def cached():
+        feats = m.encode_images(imgs)
+        for s in range(0, len(edges), bs):
+            m.decode_pairs(feats.index_select(0, torch.cat((i1[s:s + bs], i2[s:s + bs]))), H, W)
+    for name, fn in (('pair-by-pair', plain), ('encode-once', cached)):
+        ms = timeit(fn, warm=1, reps=3)
+        print(f'  {name:13s}: {ms:8.1f} ms for {len(edges)} pairs = {len(edges) / ms * 1e3:7.1f} pairs/s')
+
+
 def aligner_probe():
     from dust3r_amd.cloud_opt import global_aligner
     from dust3r_amd.cloud_opt.base_opt import global_alignment_loop
@@ -160,7 +189,7 @@ if __name__ == '__main__':
     print(torch.cuda.get_device_name(0))
     for w in which:
         try:
-            {'gemm': gemm_probe, 'conv': conv_probe, 'attn': attn_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
+            {'gemm': gemm_probe, 'cache': cache_probe, 'conv': conv_probe, 'attn': attn_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
         except Exception as e:  # keep going: this is a probe
             import traceback
             traceback.print_exc()
