@@ -30,8 +30,8 @@ namespace d3r {
 // NWI x NWJ waves; a wave owns FI x FJ 16x16 fragments. The "i" side (4 consecutive per lane) is n (weights) unless
 // the block works on a V^T region (roles swapped; square configurations only). KTB: bytes of K per LDS row and K step
 // (128 = 64 bf16: two MFMA k-steps per barrier; 64 = 32 bf16: one k-step, half the LDS, so two blocks fit on a CU).
-template <int NWI_, int NWJ_, int FI_, int FJ_, int MINW_, int KTB_ = 128, int NSTAGE_ = 2> struct GemmCfg {
-    static constexpr int NWI = NWI_, NWJ = NWJ_, FI = FI_, FJ = FJ_, MINW = MINW_, KTB = KTB_, NSTAGE = NSTAGE_;
+template <int NWI_, int NWJ_, int FI_, int FJ_, int MINW_, int KTB_ = 128, int NSTAGE_ = 2, int PP_ = 0> struct GemmCfg {
+    static constexpr int NWI = NWI_, NWJ = NWJ_, FI = FI_, FJ = FJ_, MINW = MINW_, KTB = KTB_, NSTAGE = NSTAGE_, PP = PP_;
     static constexpr int NW = NWI * NWJ, NT = NW * 64;
     static constexpr int BN = NWI * FI * 16, BM = NWJ * FJ * 16;
     static constexpr int CPR = KTB / 16;                     // 16-byte chunks per row
@@ -52,6 +52,8 @@ typedef GemmCfg<2, 2, 4, 4, 2> Cfg128;      // 128 x 128, 256 threads, 64 KiB LD
 typedef GemmCfg<1, 8, 8, 4, 2> Cfg512x128;  // M 512 x N 128, 512 threads, 160 KiB LDS (all of it): N <= 128 convolutions with the
                                             // 128 x 64 per-wave tile of Cfg256 (12 ds_read_b128 per 32 MFMAs instead of 8 per 16)
 typedef GemmCfg<2, 4, 8, 4, 2, 64, 4> Cfg256s4;   // 256 x 256, 8 waves, 64-byte K rows, FOUR LDS stages (128 KiB): three K steps of DMA in flight
+typedef GemmCfg<2, 4, 8, 4, 2, 64, 4, 1> Cfg256pp;   // 256 x 256, 64-byte K rows, 4-stage ring, PING-PONG schedule: waves 0-3 and 4-7 (one of each per
+                                                     // SIMD) run half a phase apart, so one group's 16-MFMA burst covers the other's ds_reads + DMA issue
 typedef GemmCfg<1, 4, 8, 4, 2, 64, 3> Cfg256x128w4;  // M 256 x N 128, 4 waves of 128 (n) x 64 (m), 64-byte K rows: 48 KiB LDS, TWO
                                                   // blocks per CU, three stages (72 KiB)
 
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
 
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
     const uint32_t lds0 = lds_addr(smem) + wave_u * 1024;   // wave-uniform: one 1 KiB DMA piece per wave and pass
-    auto stage = [&](int kt, int buf) {
+    auto stage_a = [&](int kt, int buf) __attribute__((always_inline)) {   // activation rows of K step kt -> stage buf
         const uint32_t sb = lds0 + buf * STAGE_BYTES;
         const size_t koff = (size_t)kt * KTB;
         if (p.amode == AMODE_LINEAR) {
@@ -141,8 +143,16 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                 glds16(src, sb + q * (CF::NW * 1024));
             }
         }
+    };
+    auto stage_w = [&](int kt, int buf) __attribute__((always_inline)) {   // weight rows of K step kt -> stage buf
+        const uint32_t sb = lds0 + buf * STAGE_BYTES;
+        const size_t koff = (size_t)kt * KTB;
 #pragma unroll
         for (int q = 0; q < CF::WPASS; ++q) glds16(wsrc[q] + koff, sb + BM * KTB + q * (CF::NW * 1024));
+    };
+    auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+        stage_a(kt, buf);
+        stage_w(kt, buf);
     };
 
     // ---- fragment read addresses ---------------------------------------------------------------
@@ -166,6 +176,73 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     // kt+NSTAGE-1 into that freed stage -> math on step kt. NSTAGE-1 steps of HBM/L2 latency are covered.
     constexpr int NS = CF::NSTAGE, LPS = CF::LPS;
     const int nk = p.K / KT;
+    if constexpr (CF::PP) {
+        // ---- ping-pong schedule (non-swapped 16-bit / fp32 operands; KTB = 64: one MFMA k-step per K step) -----------------
+        // A K step is two phases, each [L: issue half of the DMA of step kt+2, ds_read this phase's fragments] | s_barrier |
+        // [C: 16 MFMAs] | s_barrier. Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in C while its
+        // partner is in L. Data flow (ring of 4 stages, loads two steps ahead): every wave waits for ITS loads of step kt+1
+        // (counted vmcnt: the 4 loads of step kt+2 stay in flight) in the segment that ends at the barrier in front of the
+        // first read of step kt+1 -- C_b for the leading group, L_b for the trailing one; the stage written by step kt+2's
+        // DMA was last read in step kt-2, four phases back.
+        static_assert(CF::KTB == 64 && CF::NSTAGE == 4 && CF::NW == 8 && FI == 8 && FJ == 4, "ping-pong schedule is written for the 256x256 / 64-byte-row tile");
+        const bool trailing = wave_u >= 4;
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else d3r_wait_vm0();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (trailing) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sb = smem + (kt & 3) * STAGE_BYTES;
+            const int coff = (fgrp ^ fsw) * 16;
+            const bool more = kt + 2 < nk;
+            auto wait_next = [&]() __attribute__((always_inline)) {   // this wave's loads of step kt+1 have landed
+                if (kt + 1 < nk) {
+                    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                    else d3r_wait_vm0();
+                }
+            };
+            uint4 qf[FJ], pf[4];
+            // ---- phase a: P fragments 0-3 x all Q fragments
+            if (more) stage_a(kt + 2, (kt + 2) & 3);
+#pragma unroll
+            for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (q_row0 + f * 16) * KTB + coff);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) pf[f] = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + f * 16) * KTB + coff);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < FJ; ++fj) TR::mma16(acc[fi][fj], pf[fi], qf[fj]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phase b: P fragments 4-7 x all Q fragments
+            if (more) stage_w(kt + 2, (kt + 2) & 3);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) pf[f] = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + (4 + f) * 16) * KTB + coff);
+            if (trailing) wait_next();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < FJ; ++fj) TR::mma16(acc[4 + fi][fj], pf[fi], qf[fj]);
+            __builtin_amdgcn_s_setprio(0);
+            if (!trailing) wait_next();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!trailing) __builtin_amdgcn_s_barrier();
+    } else {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) stage(s, s);
@@ -217,6 +294,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         }
         buf = buf + 1 >= NS ? 0 : buf + 1;
     }
+    }  // !PP
 
     // ---- epilogue ------------------------------------------------------------------------------
     if (p.flags & GF_NOSTORE) {   // measurement aid (D3R_GEMM_NOSTORE=1): keep the math, skip the epilogue's memory traffic
@@ -548,10 +626,10 @@ int gemm_pick_config(const GemmParams& p, int dt) {
     int forced = p.force_cfg;
     if (forced < 0) {   // D3R_GEMM_CFG=0|1|2|3 pins the tile configuration (parity tests, probes); infeasible choices are ignored
         const char* e = getenv("D3R_GEMM_CFG");
-        if (e && e[0] >= '0' && e[0] <= '5' && e[1] == 0) forced = e[0] - '0';
+        if (e && e[0] >= '0' && e[0] <= '6' && e[1] == 0) forced = e[0] - '0';
     }
     if (forced == GEMM_CFG_128 || (forced == GEMM_CFG_256 && ok256) ||
-        ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128 || forced == GEMM_CFG_256x128W4) && !heads) || (forced == GEMM_CFG_256S4 && ok256))
+        ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128 || forced == GEMM_CFG_256x128W4) && !heads) || ((forced == GEMM_CFG_256S4 || forced == GEMM_CFG_256PP) && ok256))
         return forced;
     if (!heads && p.n_store <= 128) {
         if (cdiv(p.M, 512) >= 512) return GEMM_CFG_512x128;
@@ -566,10 +644,13 @@ int gemm_pick_config(const GemmParams& p, int dt) {
 template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     int cfg = gemm_pick_config(p, DT);
     if (cfg == GEMM_CFG_256x128W4 && DT == D3R_F16X3) cfg = GEMM_CFG_256x128;   // split-fp16 rows need 128-byte K rows
-    if (cfg == GEMM_CFG_256S4 && DT == D3R_F16X3) cfg = GEMM_CFG_256;
+    if ((cfg == GEMM_CFG_256S4 || cfg == GEMM_CFG_256PP) && DT == D3R_F16X3) cfg = GEMM_CFG_256;
+    // the ping-pong schedule has no operand-role swap: attention projections only through the wide V^T route
+    if (cfg == GEMM_CFG_256PP && p.epi == EPI_HEADS && !((DT == D3R_BF16 || DT == D3R_F16) && (p.ntok & 63) == 0 && !(p.flags & GF_NOWIDE))) cfg = GEMM_CFG_256;
     if constexpr (DT != D3R_F16X3) {
         if (cfg == GEMM_CFG_256x128W4) return launch_cfg<DT, Cfg256x128w4>(p, s);
         if (cfg == GEMM_CFG_256S4) return launch_cfg<DT, Cfg256s4>(p, s);
+        if (cfg == GEMM_CFG_256PP) return launch_cfg<DT, Cfg256pp>(p, s);
     }
     switch (cfg) {
         case GEMM_CFG_256: return launch_cfg<DT, Cfg256>(p, s);

@@ -74,7 +74,7 @@ def test_forward_matches_oracle(gpu, precision, config, B, H, W):
     compare(eng, oracle, v1, v2, *TOLS[precision], tag=f'{config} {precision} {B}x{H}x{W}')
 
 
-@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '4', '5'])
+@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '4', '5', '6'])
 @pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
 def test_forward_with_pinned_gemm_tile(gpu, precision, cfg, monkeypatch):
     """The whole network with the GEMM tile configuration pinned (D3R_GEMM_CFG): the 256-wide tiles' q/k RoPE scatter,
@@ -87,7 +87,7 @@ def test_forward_with_pinned_gemm_tile(gpu, precision, cfg, monkeypatch):
     compare(eng, oracle, v1, v2, *TOLS[precision], tag=f'tiny_dpt {precision} cfg{cfg}')
 
 
-@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '4', '5'])
+@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '4', '5', '6'])
 def test_forward_16bit_with_pinned_gemm_tile(gpu, cfg, monkeypatch):
     """fp16 engine, 128x128 images = 64 tokens: the wide epilogues incl. the LDS-transposed V^T scatter on every tile shape."""
     from oracle.dust3r_ref import build_ref_model

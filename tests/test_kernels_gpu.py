@@ -74,7 +74,7 @@ def test_conv2d_nhwc(gpu, dtype, B, H, W, Cin, Cout, k, stride, pad):
     assert relerr(out, (ref - b).clamp_min(0)) < OUT_TOL[dtype]
 
 
-@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '4', '5'])
+@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '4', '5', '6'])
 def test_gemm_tile_configurations(gpu, cfg, monkeypatch):
     """Every tile configuration of the GEMM template (128x128, 256x256, 256x128) on shapes with ragged M / N edges,
     K long enough to cycle both LDS stages many times, linear and implicit-GEMM convolution operands."""

@@ -27,7 +27,7 @@ def timeit(fn, warm=3, reps=10):
 
 def gemm_probe():
     import os
-    print('== GEMM: ms and TFLOP/s per tile configuration (D3R_GEMM_CFG: 0 = 128x128, 1 = 256x256, 2 = 256x128, 3 = 512x128, 4 = 256x128 4-wave 2 blocks/CU, auto = heuristic)')
+    print('== GEMM: ms and TFLOP/s per tile configuration (D3R_GEMM_CFG: 0 = 128x128, 1 = 256x256, 2 = 256x128, 3 = 512x128, 4 = 256x128 4-wave 2 blocks/CU, 5 = 256x256 4-stage, 6 = 256x256 ping-pong, auto = heuristic)')
     from dust3r_amd._lib import lib, ptr, current_stream, check
     shapes = [(49152, 3072, 1024), (49152, 1024, 1024), (49152, 4096, 1024), (49152, 1024, 4096), (24576, 2304, 768), (24576, 768, 768),
               (24576, 3072, 768), (24576, 768, 3072), (4096, 4096, 4096), (8192, 8192, 8192)]
@@ -43,7 +43,7 @@ def gemm_probe():
             def run():
                 check(lib.d3r_linear(ptr(a), ptr(w), ptr(b), ptr(out), None, M, N, K, 0, ops._dt(a), current_stream()))
             line = f'  M={M} N={N} K={K} {str(dt)[6:]:9s}'
-            for cfg in (('0', '1', '4', '5', None) if dt == torch.bfloat16 else (None,)):
+            for cfg in (('0', '1', '5', '6', None) if dt == torch.bfloat16 else (None,)):
                 if cfg is None:
                     os.environ.pop('D3R_GEMM_CFG', None)
                 else:
@@ -77,7 +77,7 @@ def conv_probe():
         b = torch.randn(Cout, device=dev)
         fl = 2 * B * H * W * Cout * 9 * Cin
         line = f'  {H}x{W} {Cin}->{Cout}'
-        for cfg in ('1', '3', '4', '5', None):
+        for cfg in ('1', '3', '6', None):
             if cfg is None:
                 os.environ.pop('D3R_GEMM_CFG', None)
             else:
