@@ -637,7 +637,12 @@ int gemm_pick_config(const GemmParams& p, int dt) {
         return GEMM_CFG_128;
     }
     const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.n_store, 256);
-    if (ok256 && tiles256 >= 700) return GEMM_CFG_256;
+    if (ok256 && tiles256 >= 700) {
+        // nn.Linear operands: the ping-pong schedule measured 1-8 % ahead of the plain 2-stage loop (profiles/r01_call13);
+        // implicit-GEMM operands: behind it (the per-tap address arithmetic sits in the load segment) -> plain loop
+        static const bool pp = [] { const char* e = getenv("D3R_GEMM_PP"); return e ? e[0] == '1' : false; }();
+        return (pp && p.amode == AMODE_LINEAR) ? GEMM_CFG_256PP : GEMM_CFG_256;
+    }
     return GEMM_CFG_128;
 }
 

@@ -18,7 +18,6 @@ struct GemmParams {
     int M = 0, K = 0, n_pad = 0; // K in elements, multiple of 128/sizeof(DT); n_pad: multiple of 128, >= n_store
     int n_rows = 0;              // weight rows actually allocated (>= n_pad; 0 = n_pad): bounds the tile width choice
     int force_cfg = -1;          // GEMM_CFG_* to override the heuristic (tests / probes)
-    int stagger_cycles = 0, stagger_blocks = 0;   // set by the launcher: start delay of half of the first round's blocks
     int n_store = 0;             // columns written (multiple of 4, <= n_pad)
     int lda = 0;
     int amode = AMODE_LINEAR;

@@ -48,8 +48,10 @@ for tag in ('pmc_fetch', 'pmc_write'):
 # ---- machine-readable digest for bench.py's roofline.traffic (copied by hand to profiles/pmc_latest.json) ------------------
 import json  # noqa: E402
 
-CFG_OF = {(2, 2, 4, 4, 2, 128, 2): 0, (2, 4, 8, 4, 2, 128, 2): 1, (2, 4, 4, 4, 2, 128, 2): 2, (1, 8, 8, 4, 2, 128, 2): 3,
-          (1, 4, 8, 4, 2, 64, 3): 4, (2, 4, 8, 4, 2, 64, 4): 5}
+CFG_OF = {(2, 2, 4, 4, 2, 128, 2, 0): 0, (2, 4, 8, 4, 2, 128, 2, 0): 1, (2, 4, 4, 4, 2, 128, 2, 0): 2, (1, 8, 8, 4, 2, 128, 2, 0): 3,
+          (1, 4, 8, 4, 2, 64, 3, 0): 4, (2, 4, 8, 4, 2, 64, 4, 0): 5,
+          (2, 2, 4, 4, 2, 128, 2): 0, (2, 4, 8, 4, 2, 128, 2): 1, (2, 4, 4, 4, 2, 128, 2): 2, (1, 8, 8, 4, 2, 128, 2): 3,
+          (1, 4, 8, 4, 2, 64, 3): 4, (2, 4, 8, 4, 2, 64, 4): 5, (2, 4, 8, 4, 2, 64, 4, 1): 6}
 
 
 def pmc_means(tag, counter):
