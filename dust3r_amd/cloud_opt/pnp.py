@@ -47,10 +47,12 @@ def _dlt_pose(X, xn):
     A[1::2, 4:8] = -Xh
     A[1::2, 8:12] = xn[:, 1:2] * Xh
     try:
-        _, _, Vt = np.linalg.svd(A)
+        # null vector of A = eigenvector of the 12x12 normal matrix for its smallest eigenvalue. (A full SVD of A builds the
+        # 2n x 2n left factor: 43 s per call on a 20 000-point consensus set, 700 s of a 100-view MST initialisation.)
+        _, V = np.linalg.eigh(A.T @ A)
     except np.linalg.LinAlgError:
         return None
-    P = Vt[-1].reshape(3, 4)
+    P = V[:, 0].reshape(3, 4)
     U, S, Vt2 = np.linalg.svd(P[:, :3])
     if S.mean() < 1e-12:
         return None

@@ -69,11 +69,24 @@ def _encode_once_ok(pairs, model):
         return False
 
 
+def _alloc_outputs(P, H, W, out_device):
+    kw = dict(dtype=torch.float32, device=out_device)
+    return (dict(pts3d=torch.empty((P, H, W, 3), **kw), conf=torch.empty((P, H, W), **kw)),
+            dict(pts3d_in_other_view=torch.empty((P, H, W, 3), **kw), conf=torch.empty((P, H, W), **kw)))
+
+
+def _collate_views(pairs):
+    """view1 / view2 dicts of the whole pair list in the reference's collated format (tensors cat'ed on the host, lists chained)."""
+    view1, view2 = collate_with_cat(list(pairs))
+    return view1, view2
+
+
 @torch.no_grad()
-def inference_encode_once(pairs, model, device, batch_size=8, verbose=True):
+def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, output_device='cpu'):
     """Same return value as `inference` (bit-identical: every engine kernel is batch-position independent), but every distinct
     image goes through the ViT-L encoder ONCE: n encoder passes instead of 2 x len(pairs) -- 20 instead of 380 for the demo's
-    complete symmetrised graph over 20 views, i.e. ~53 % fewer FLOPs end to end."""
+    complete symmetrised graph over 20 views, i.e. ~53 % fewer FLOPs end to end. Predictions are written
+    straight into preallocated outputs (one allocation per tensor, no per-batch host tensors, no final concatenation)."""
     imgs, order = {}, []
     for v1, v2 in pairs:
         for v in (v1, v2):
@@ -88,31 +101,50 @@ def inference_encode_once(pairs, model, device, batch_size=8, verbose=True):
     for i in tqdm.trange(0, len(order), enc_bs, disable=not verbose, desc='encode'):
         feats.append(model.encode_images(torch.cat([imgs[k] for k in order[i:i + enc_bs]], dim=0).to(device, non_blocking=True)))
     feats = torch.cat(feats, dim=0)
-    result = []
+    pred1, pred2 = _alloc_outputs(len(pairs), H, W, output_device)
+    i1 = torch.tensor([pos[int(a['idx'])] for a, _ in pairs], device=feats.device)
+    i2 = torch.tensor([pos[int(b['idx'])] for _, b in pairs], device=feats.device)
     for i in tqdm.trange(0, len(pairs), batch_size, disable=not verbose, desc='decode'):
-        chunk = pairs[i:i + batch_size]
-        view1, view2 = collate_with_cat(chunk)
-        sel = torch.tensor([pos[int(a['idx'])] for a, _ in chunk] + [pos[int(b['idx'])] for _, b in chunk], device=feats.device)
-        pred1, pred2 = model.decode_pairs(feats.index_select(0, sel), H, W)
-        for view in (view1, view2):      # the reference moves the images to the device and back (loss_of_one_batch / to_cpu)
-            view['img'] = view['img'].cpu()
-        result.append(to_cpu(dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)))
-    return collate_with_cat(result, lists=False)
+        j = min(i + batch_size, len(pairs))
+        p1, p2 = model.decode_pairs(feats.index_select(0, torch.cat((i1[i:j], i2[i:j]))), H, W)
+        pred1['pts3d'][i:j].copy_(p1['pts3d'], non_blocking=True)
+        pred1['conf'][i:j].copy_(p1['conf'], non_blocking=True)
+        pred2['pts3d_in_other_view'][i:j].copy_(p2['pts3d_in_other_view'], non_blocking=True)
+        pred2['conf'][i:j].copy_(p2['conf'], non_blocking=True)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    view1, view2 = _collate_views(pairs)
+    return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)
 
 
 @torch.no_grad()
-def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None):
+def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None, output_device='cpu'):
+    """Mirror of dust3r/inference.py:55-72. Extras (defaults keep the reference's behaviour): `encode_once` (None = automatic:
+    encode every distinct image once when the pair list shares images) and `output_device` ('cpu' like the reference's
+    to_cpu; a CUDA device keeps the predictions in HBM for `global_aligner(output, device)`, which would upload them again)."""
     if verbose:
         print(f'>> Inference with model on {len(pairs)} image pairs')
-    result = []
     multiple_shapes = not check_if_same_size(pairs)
     if encode_once is None:
         encode_once = True
     if encode_once and not multiple_shapes and _encode_once_ok(pairs, model):
-        return inference_encode_once(pairs, model, device, batch_size=batch_size, verbose=verbose)
+        return inference_encode_once(pairs, model, device, batch_size=batch_size, verbose=verbose, output_device=output_device)
     if multiple_shapes:
-        batch_size = 1
+        result = []
+        for i in tqdm.trange(0, len(pairs), 1, disable=not verbose):
+            res = loss_of_one_batch(collate_with_cat(pairs[i:i + 1]), model, None, device)
+            result.append(to_cpu(res) if str(output_device) == 'cpu' else res)
+        return collate_with_cat(result, lists=True)
+    H, W = pairs[0][0]['img'].shape[-2:]
+    pred1, pred2 = _alloc_outputs(len(pairs), H, W, output_device)
     for i in tqdm.trange(0, len(pairs), batch_size, disable=not verbose):
-        res = loss_of_one_batch(collate_with_cat(pairs[i:i + batch_size]), model, None, device)
-        result.append(to_cpu(res))
-    return collate_with_cat(result, lists=multiple_shapes)
+        j = min(i + batch_size, len(pairs))
+        res = loss_of_one_batch(collate_with_cat(pairs[i:j]), model, None, device)
+        pred1['pts3d'][i:j].copy_(res['pred1']['pts3d'], non_blocking=True)
+        pred1['conf'][i:j].copy_(res['pred1']['conf'], non_blocking=True)
+        pred2['pts3d_in_other_view'][i:j].copy_(res['pred2']['pts3d_in_other_view'], non_blocking=True)
+        pred2['conf'][i:j].copy_(res['pred2']['conf'], non_blocking=True)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    view1, view2 = _collate_views(pairs)
+    return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)
