@@ -210,7 +210,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from dust3r_amd import _lib
-    from dust3r_amd.parallel import all_gather_packed, pack_predictions
+    from dust3r_amd.parallel import all_gather_packed
     from dust3r_amd.synthetic import synthetic_views
     _lib.require_device()
     model = build_model(args.precision, device)
@@ -225,19 +225,19 @@ def main():
     pending = []
 
     def step(i):
-        r1, r2 = model(v1, v2)
-        if do_gather:
-            packed = pack_predictions(r1, r2)
-            ev = torch.cuda.Event()
-            ev.record()
-            gather_stream.wait_event(ev)
-            with torch.cuda.stream(gather_stream):
-                packed.record_stream(gather_stream)
-                _, work = all_gather_packed(packed, async_op=True, out=gather_out[i & 1])
-            pending.append(work)
-            if len(pending) > 1:                                        # at most one all-gather in flight behind the compute
-                pending.pop(0).wait()
-        return r1, r2
+        if not do_gather:
+            return model(v1, v2)
+        packed = model.forward_packed(v1, v2)                # the heads write the (B,H,W,8) all-gather payload directly
+        ev = torch.cuda.Event()
+        ev.record()
+        gather_stream.wait_event(ev)
+        with torch.cuda.stream(gather_stream):
+            packed.record_stream(gather_stream)
+            _, work = all_gather_packed(packed, async_op=True, out=gather_out[i & 1])
+        pending.append(work)
+        if len(pending) > 1:                                 # at most one all-gather in flight behind the compute
+            pending.pop(0).wait()
+        return packed
 
     def drain():
         while pending:

@@ -52,6 +52,7 @@ def _load():
         'd3r_model_load_tensor_device': (i, [vp, C.c_char_p, fp, i, C.POINTER(C.c_int64)]),
         'd3r_model_missing': (i, [vp]),
         'd3r_model_forward': (i, [vp, fp, fp, i, i, i, fp, fp, fp, fp, vp]),
+        'd3r_model_forward_packed': (i, [vp, fp, fp, i, i, i, fp, vp]),
         'd3r_model_device_bytes': (C.c_size_t, [vp]),
         'd3r_model_feature_bytes': (C.c_size_t, [vp, i, i]),
         'd3r_model_encode': (i, [vp, fp, i, i, i, vp, vp]),

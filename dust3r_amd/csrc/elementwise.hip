@@ -234,13 +234,15 @@ hipError_t launch_upsample2x(int dt, const void* in, void* out, void* out_relu, 
 // ------------------------------------------------------------------------------ head epilogues
 // postprocess (dust3r/heads/postprocess.py:10-58) with depth_mode ('exp', -inf, inf) and
 // conf_mode ('exp', 1, inf): pts = xyz / max(|xyz|, 1e-8) * expm1(|xyz|); conf = 1 + exp(x).
-D3R_DEV void postprocess_store(float x, float y, float z, float cl, float* pts, float* conf, size_t pix) {
+// pts / conf element strides between pixels: (3, 1) = the reference's separate pts3d / conf tensors; (8, 8) = the packed
+// [pixel][pts1 conf1 pts2 conf2] record that the multi-GPU path all-gathers as one payload.
+D3R_DEV void postprocess_store(float x, float y, float z, float cl, float* pts, float* conf, size_t pix, int ps, int cs) {
     const float d = sqrtf(x * x + y * y + z * z);
     const float sc = expm1f(d) / fmaxf(d, 1e-8f);
-    pts[3 * pix + 0] = x * sc;
-    pts[3 * pix + 1] = y * sc;
-    pts[3 * pix + 2] = z * sc;
-    conf[pix] = 1.0f + expf(cl);
+    pts[ps * pix + 0] = x * sc;
+    pts[ps * pix + 1] = y * sc;
+    pts[ps * pix + 2] = z * sc;
+    conf[cs * pix] = 1.0f + expf(cl);
 }
 
 // DPT head tail: Conv2d(last_dim, 4, 1) on the ReLU'd features + postprocess (dpt_head.py:63,
@@ -248,7 +250,7 @@ D3R_DEV void postprocess_store(float x, float y, float z, float cl, float* pts, 
 template <int DT>
 __global__ __launch_bounds__(256) void head_final_kernel(const void* __restrict__ feat, int C, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ pts, float* __restrict__ conf,
-                                                         size_t npix) {
+                                                         size_t npix, int pstride, int cstride) {
     const int sub = threadIdx.x & 15;
     for (size_t pix = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (size_t)gridDim.x * 16) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -270,18 +272,18 @@ __global__ __launch_bounds__(256) void head_final_kernel(const void* __restrict_
             a2 += __shfl_xor(a2, o);
             a3 += __shfl_xor(a3, o);
         }
-        if (sub == 0) postprocess_store(a0 + bias[0], a1 + bias[1], a2 + bias[2], a3 + bias[3], pts, conf, pix);
+        if (sub == 0) postprocess_store(a0 + bias[0], a1 + bias[1], a2 + bias[2], a3 + bias[3], pts, conf, pix, pstride, cstride);
     }
 }
 hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, const float* b, float* pts, float* conf,
-                             size_t npix, hipStream_t s) {
+                             size_t npix, int pstride, int cstride, hipStream_t s) {
     if (C % 8 != 0) return hipErrorInvalidValue;
     const int grid = (int)((npix + 15) / 16 < 65536 ? (npix + 15) / 16 : 65536);
     switch (dt) {
-        case D3R_BF16: hipLaunchKernelGGL(head_final_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix); break;
-        case D3R_F16: hipLaunchKernelGGL(head_final_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix); break;
-        case D3R_F32: hipLaunchKernelGGL(head_final_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix); break;
-        case D3R_F16X3: hipLaunchKernelGGL(head_final_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix); break;
+        case D3R_BF16: hipLaunchKernelGGL(head_final_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride); break;
+        case D3R_F16: hipLaunchKernelGGL(head_final_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride); break;
+        case D3R_F32: hipLaunchKernelGGL(head_final_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride); break;
+        case D3R_F16X3: hipLaunchKernelGGL(head_final_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -290,7 +292,7 @@ hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, co
 // LinearPts3d tail (dust3r/heads/linear_head.py:36-41): pixel_shuffle(ps) of the token-major
 // projection (channel = c*ps*ps + py*ps + px) followed by postprocess.
 __global__ __launch_bounds__(256) void linear_head_post_kernel(const float* __restrict__ feat, float* __restrict__ pts,
-                                                               float* __restrict__ conf, int B, int th, int tw, int ps) {
+                                                               float* __restrict__ conf, int B, int th, int tw, int ps, int pstride, int cstride) {
     const int H = th * ps, W = tw * ps, pp = ps * ps;
     const size_t total = (size_t)B * H * W;
     for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (size_t)gridDim.x * 256) {
@@ -300,13 +302,14 @@ __global__ __launch_bounds__(256) void linear_head_post_kernel(const float* __re
         const int b = (int)(r / H);
         const int ty = y / ps, py = y - ty * ps, tx = x / ps, px = x - tx * ps;
         const float* f = feat + (((size_t)b * th + ty) * tw + tx) * (size_t)(4 * pp) + py * ps + px;
-        postprocess_store(f[0], f[pp], f[2 * pp], f[3 * pp], pts, conf, pix);
+        postprocess_store(f[0], f[pp], f[2 * pp], f[3 * pp], pts, conf, pix, pstride, cstride);
     }
 }
-hipError_t launch_linear_head_post(const float* feat, float* pts, float* conf, int B, int th, int tw, int ps, hipStream_t s) {
+hipError_t launch_linear_head_post(const float* feat, float* pts, float* conf, int B, int th, int tw, int ps, int pstride, int cstride,
+                                   hipStream_t s) {
     const size_t total = (size_t)B * th * tw * ps * ps;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(linear_head_post_kernel, dim3(grid), dim3(256), 0, s, feat, pts, conf, B, th, tw, ps);
+    hipLaunchKernelGGL(linear_head_post_kernel, dim3(grid), dim3(256), 0, s, feat, pts, conf, B, th, tw, ps, pstride, cstride);
     return hipGetLastError();
 }
 

@@ -81,6 +81,7 @@ struct d3r_model {
     hipStream_t side = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     bool two_streams = true;
+    int out_pstride = 3, out_cstride = 1;   // output element strides between pixels (8, 8 while d3r_model_forward_packed runs)
     // last forward (debug hook)
     const void* last_encn = nullptr; size_t last_encn_elems = 0;
     // optional per-launch HIP-event timing (d3r_model_set_option(D3R_MODEL_OPT_PROFILE)); off in timed runs
@@ -558,7 +559,7 @@ void run_dpt(Ctx& c, const DptHead& D, Arena ar, const void* const hooks[4], con
     D3R_OTHER(launch_upsample2x(m->dt, h0, h1, nullptr, B, H8, W8, 128, 128, 2 * H8, 2 * W8, c.st));
     void* h2 = ar.take((size_t)B * 4 * H8 * W8 * 128 * eb);
     conv(c, h1, B, 2 * H8, 2 * W8, 128, D.head2, 1, 1, h2, 128, GF_RELU);
-    D3R_OTHER(launch_head_final(m->dt, h2, 128, D.head4_w, D.head4_b, pts, conf, (size_t)B * 4 * H8 * W8, c.st));
+    D3R_OTHER(launch_head_final(m->dt, h2, 128, D.head4_w, D.head4_b, pts, conf, (size_t)B * 4 * H8 * W8, m->out_pstride, m->out_cstride, c.st));
     if (ar.base && ar.off > ar.cap) c.rc = D3R_ERR_ALLOC;
 }
 
@@ -716,7 +717,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
             if (cf.head_type == 0) {
                 float* lo = lin_out + (size_t)s * M1 * 4 * ps * ps;
                 gemm_linear(c, hook[s][2], Cd, m->lin_head[s], M1, EPI_F32, lo, 4 * ps * ps);
-                D3R_OTHER(launch_linear_head_post(lo, pts[s], cnf[s], B, th, tw, ps, c.st));
+                D3R_OTHER(launch_linear_head_post(lo, pts[s], cnf[s], B, th, tw, ps, m->out_pstride, m->out_cstride, c.st));
             } else {
                 for (int b0 = 0; b0 < B; b0 += chunk) {
                     const int bc = (B - b0) < chunk ? (B - b0) : chunk;
@@ -724,7 +725,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                     const void* hooks[4] = {(const char*)encn + ((size_t)s * M1 + (size_t)b0 * N) * Ce * eb, (const char*)hook[s][0] + (size_t)b0 * N * Cd * eb,
                                             (const char*)hook[s][1] + (size_t)b0 * N * Cd * eb, (const char*)hook[s][2] + (size_t)b0 * N * Cd * eb};
                     const int hc[4] = {Ce, Cd, Cd, Cd};
-                    run_dpt(c, m->dpt[s], sub, hooks, hc, bc, th, tw, pts[s] + (size_t)b0 * H * W * 3, cnf[s] + (size_t)b0 * H * W);
+                    run_dpt(c, m->dpt[s], sub, hooks, hc, bc, th, tw, pts[s] + (size_t)b0 * H * W * m->out_pstride, cnf[s] + (size_t)b0 * H * W * m->out_cstride);
                 }
             }
         }
@@ -766,6 +767,14 @@ extern "C" int d3r_model_forward(d3r_model* m, const float* img1, const float* i
                                  float* pts2, float* conf2, void* stream) {
     if (!m || !img1 || !img2 || B <= 0 || !pts1 || !conf1 || !pts2 || !conf2) return D3R_ERR_INVALID;
     return run_phases(m, PH_ENCODE | PH_DECODE, img1, img2, B, 2 * B, nullptr, B, H, W, pts1, conf1, pts2, conf2, (hipStream_t)stream);
+}
+
+extern "C" int d3r_model_forward_packed(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* out8, void* stream) {
+    if (!m || !img1 || !img2 || B <= 0 || !out8) return D3R_ERR_INVALID;
+    m->out_pstride = 8; m->out_cstride = 8;
+    const int rc = run_phases(m, PH_ENCODE | PH_DECODE, img1, img2, B, 2 * B, nullptr, B, H, W, out8, out8 + 3, out8 + 4, out8 + 7, (hipStream_t)stream);
+    m->out_pstride = 3; m->out_cstride = 1;
+    return rc;
 }
 
 extern "C" size_t d3r_model_feature_bytes(const d3r_model* m, int H, int W) {

@@ -70,9 +70,10 @@ hipError_t launch_upsample2x(int dt, const void* in, void* out, void* out_relu, 
                              int Ho, int Wo, hipStream_t s);
 // final DPT stage: relu'd NHWC DT [pix][C] x W[4][C] + b -> postprocess -> pts3d [pix][3], conf [pix]
 hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, const float* b, float* pts, float* conf,
-                             size_t npix, hipStream_t s);
+                             size_t npix, int pstride, int cstride, hipStream_t s);
 // linear head: proj output fp32 [B*th*tw][(3+1)*ps*ps] -> pixel_shuffle -> postprocess
-hipError_t launch_linear_head_post(const float* feat, float* pts, float* conf, int B, int th, int tw, int ps, hipStream_t s);
+hipError_t launch_linear_head_post(const float* feat, float* pts, float* conf, int B, int th, int tw, int ps, int pstride, int cstride,
+                                   hipStream_t s);
 hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 
 // load-time weight packing on the device (fp32 PyTorch-layout source -> engine layout in DT)

@@ -311,6 +311,24 @@ def _decode(self, feat, H, W):
     return dict(pts3d=pts1, conf=conf1), dict(pts3d_in_other_view=pts2, conf=conf2)
 
 
+def _forward_packed(self, view1, view2, out=None):
+    """forward() with the four outputs interleaved per pixel: (B,H,W,8) = (pts1 xyz, conf1, pts2 xyz, conf2), the all-gather
+    payload of dust3r_amd.parallel (unpack_predictions gives the reference's dict pair back)."""
+    _lib.require_device()
+    img1, img2 = view1['img'], view2['img']
+    B, _, H, W = img1.shape
+    dev = self._engine_device
+    with torch.cuda.device(dev):
+        i1 = img1.to(dev, torch.float32).contiguous()
+        i2 = img2.to(dev, torch.float32).contiguous()
+        if out is None:
+            out = torch.empty((B, H, W, 8), dtype=torch.float32, device=dev)
+        assert out.shape == (B, H, W, 8) and out.is_contiguous() and out.dtype == torch.float32
+        check(lib.d3r_model_forward_packed(self._engine, ptr(i1), ptr(i2), B, H, W, ptr(out), current_stream()), 'model_forward_packed')
+    return out
+
+
+AsymmetricCroCo3DStereo.forward_packed = _forward_packed
 AsymmetricCroCo3DStereo.encode_images = _encode
 AsymmetricCroCo3DStereo.decode_pairs = _decode
 

@@ -56,9 +56,14 @@ def inference_sharded(pairs, model, device, batch_size=8, verbose=False, group=N
     H, W = pairs[0][0]['img'].shape[-2:]
     local = torch.zeros((per, H, W, 8), dtype=torch.float32, device=gather_device)
     for i in range(lo, hi, batch_size):
-        res = loss_of_one_batch(collate_with_cat(pairs[i:min(i + batch_size, hi)]), model, None, device)
-        n = res['pred1']['pts3d'].shape[0]
-        local[i - lo:i - lo + n] = pack_predictions(res['pred1'], res['pred2']).to(gather_device)
+        batch = collate_with_cat(pairs[i:min(i + batch_size, hi)])
+        n = batch[0]['img'].shape[0]
+        if hasattr(model, 'forward_packed') and local.is_cuda:
+            # the engine's heads write the interleaved payload in place: no pack pass
+            model.forward_packed(dict(img=batch[0]['img'].to(device)), dict(img=batch[1]['img'].to(device)), out=local[i - lo:i - lo + n])
+        else:
+            res = loss_of_one_batch(batch, model, None, device)
+            local[i - lo:i - lo + n] = pack_predictions(res['pred1'], res['pred2']).to(gather_device)
     gathered = all_gather_packed(local, group)
     # drop the padding slots of the short last shards
     keep = torch.cat([torch.arange(r * per, r * per + (shard_bounds(len(pairs), r, world)[1] - shard_bounds(len(pairs), r, world)[0]))

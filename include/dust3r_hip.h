@@ -114,6 +114,9 @@ int d3r_model_missing(const d3r_model* m);
  * pts2 (= pred2['pts3d_in_other_view']) and conf2. Workspace is owned by the model and grown on demand. */
 int d3r_model_forward(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1, float* pts2,
                       float* conf2, void* stream);
+/* same forward, outputs interleaved per pixel: out8 fp32 [B][H][W][8] = (pts1 xyz, conf1, pts2 xyz, conf2) -- the single payload the
+ * pair-sharded multi-GPU path all-gathers (dust3r_amd/parallel.py), written directly by the head epilogues */
+int d3r_model_forward_packed(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* out8, void* stream);
 /* The same forward in two calls, so that a view shared by several pairs is encoded ONCE (the reference re-encodes it for every
  * pair, dust3r/model.py:142-151; make_pairs' complete graph over n views has n(n-1) pair slots but only n images):
  *   d3r_model_encode: patch-embed + encoder + enc_norm (model.py:128-140) over n images fp32 [n][3][H][W] -> feat_out, an

@@ -263,3 +263,16 @@ def test_encode_once_inference_is_bit_identical(gpu):
     for k in ('pts3d', 'conf'):
         assert torch.equal(a['pred1'][k], b['pred1'][k])
     assert torch.equal(a['pred2']['pts3d_in_other_view'], b['pred2']['pts3d_in_other_view']) and torch.equal(a['pred2']['conf'], b['pred2']['conf'])
+
+
+def test_packed_forward_equals_forward(gpu):
+    """d3r_model_forward_packed writes the same numbers as forward, interleaved per pixel (the multi-GPU gather payload)."""
+    from dust3r_amd.parallel import unpack_predictions
+    from oracle.dust3r_ref import build_ref_model
+    for cfg in ('tiny_dpt', 'tiny_linear'):
+        eng = engine_from_oracle(build_ref_model(cfg), cfg, 'bf16', gpu)
+        v1, v2 = synthetic_views(3, 64, 96, seed=17)
+        r1, r2 = eng(v1, v2)
+        p1, p2 = unpack_predictions(eng.forward_packed(v1, v2))
+        assert torch.equal(p1['pts3d'], r1['pts3d']) and torch.equal(p1['conf'], r1['conf'])
+        assert torch.equal(p2['pts3d_in_other_view'], r2['pts3d_in_other_view']) and torch.equal(p2['conf'], r2['conf'])
