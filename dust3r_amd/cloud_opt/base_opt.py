@@ -271,7 +271,11 @@ class BasePCOptimizer(nn.Module):
     @torch.no_grad()
     def clean_pointcloud(self, **kw):
         cams = inv(self.get_im_poses())
-        new_confs = clean_pointcloud(self.im_conf, self.get_intrinsics(), cams, self.get_depthmaps(), self.get_pts3d(), **kw)
+        if self.device.type == 'cuda' and not kw.get('dbg'):
+            new_confs = clean_pointcloud_hip(self.im_conf, self.get_intrinsics(), cams, self.get_depthmaps(), self.get_pts3d(),
+                                             tol=kw.get('tol', 0.001), bad_conf=kw.get('bad_conf', 0))
+        else:
+            new_confs = clean_pointcloud(self.im_conf, self.get_intrinsics(), cams, self.get_depthmaps(), self.get_pts3d(), **kw)
         for i, c in enumerate(new_confs):
             self.im_conf[i][:] = c
         return self
@@ -345,6 +349,33 @@ def global_alignment_loop(net, lr=0.01, niter=300, schedule='cosine', lr_min=1e-
     if bar is not None:
         bar.close()
     return loss
+
+
+@torch.no_grad()
+def clean_pointcloud_hip(im_confs, K, cams, depthmaps, all_pts3d, tol=0.001, bad_conf=0):
+    """Same result as `clean_pointcloud` below (the reference's host loop), computed by d3r_clean_pointcloud: n launches, one
+    thread per pixel walking the other cameras, instead of n (n - 1) rounds of ~15 elementwise torch kernels."""
+    _lib.require_device()
+    n = len(im_confs)
+    dev = im_confs[0].device
+    shapes = [tuple(c.shape) for c in im_confs]
+    maxA = max(h * w for h, w in shapes)
+
+    def stack(ts, tail=()):
+        out = torch.zeros((n, maxA) + tail, dtype=torch.float32, device=dev)
+        for i, t in enumerate(ts):
+            out[i, :t.numel() // max(1, int(np.prod(tail)))] = t.reshape((-1,) + tail).float()
+        return out
+    conf = stack(im_confs)
+    depth = stack(depthmaps)
+    pts = stack(all_pts3d, (3,))
+    Kc = K.float().contiguous().reshape(n, 9)
+    w2c = cams.float().contiguous().reshape(n, 16)
+    arr = lambda v: (C.c_int * len(v))(*v)  # noqa: E731
+    with torch.cuda.device(dev):
+        check(lib.d3r_clean_pointcloud(n, ptr(conf), ptr(depth), ptr(pts), ptr(Kc), ptr(w2c), arr([h for h, w in shapes]),
+                                       arr([w for h, w in shapes]), maxA, float(tol), float(bad_conf), current_stream()), 'clean_pointcloud')
+    return [conf[i, :h * w].view(h, w).to(im_confs[i].dtype) for i, (h, w) in enumerate(shapes)]
 
 
 @torch.no_grad()

@@ -607,6 +607,62 @@ extern "C" int d3r_aligner_loss_grad(d3r_aligner* a, float* loss_device, float* 
     return D3R_OK;
 }
 
+// ---- clean_pointcloud (reference dust3r/cloud_opt/base_opt.py:369-405) ----------------------------------------------
+// A point of image i that projects IN FRONT of image j's depthmap while being less confident than the pixel it lands on
+// gets its confidence clipped to bad_conf. The reference is a host-driven double loop (i outer, j inner) that updates the
+// confidences in place, so image i sees the already-cleaned confidences of images j < i: one launch per i keeps exactly
+// that order; inside a launch a thread owns one pixel of image i and walks the cameras j in order.
+namespace d3r {
+__global__ __launch_bounds__(256) void clean_pointcloud_kernel(int i, int n, float* __restrict__ conf, const float* __restrict__ depth,
+                                                                const float* __restrict__ pts, const float* __restrict__ K,
+                                                                const float* __restrict__ w2c, const int* __restrict__ Hs,
+                                                                const int* __restrict__ Ws, int maxA, float tol, float bad_conf) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= Hs[i] * Ws[i]) return;
+    const float* X = pts + ((size_t)i * maxA + p) * 3;
+    const float x = X[0], y = X[1], z = X[2];
+    float c = conf[(size_t)i * maxA + p];
+    for (int j = 0; j < n; ++j) {
+        if (j == i) continue;
+        const float* M = w2c + j * 16;
+        const float px = M[0] * x + M[1] * y + M[2] * z + M[3];
+        const float py = M[4] * x + M[5] * y + M[6] * z + M[7];
+        const float pz = M[8] * x + M[9] * y + M[10] * z + M[11];
+        if (!(pz > 0.f)) continue;
+        const float* Kj = K + j * 9;
+        const float ku = Kj[0] * px + Kj[1] * py + Kj[2] * pz, kv = Kj[3] * px + Kj[4] * py + Kj[5] * pz, kw = Kj[6] * px + Kj[7] * py + Kj[8] * pz;
+        const float u = rintf(ku / kw), v = rintf(kv / kw);   // torch.round: half to even
+        const int Wj = Ws[j], Hj = Hs[j];
+        if (!(u >= 0.f && u < (float)Wj && v >= 0.f && v < (float)Hj)) continue;
+        const size_t q = (size_t)j * maxA + (size_t)((int)v * Wj + (int)u);
+        if (pz < (1.f - tol) * depth[q] && c < conf[q]) c = fminf(c, bad_conf);
+    }
+    conf[(size_t)i * maxA + p] = c;
+}
+}  // namespace d3r
+
+extern "C" int d3r_clean_pointcloud(int n_imgs, float* conf, const float* depth, const float* pts3d, const float* intrinsics,
+                                    const float* world2cam, const int* img_h, const int* img_w, int max_area, float tol, float bad_conf,
+                                    void* stream) {
+    if (n_imgs <= 0 || !conf || !depth || !pts3d || !intrinsics || !world2cam || !img_h || !img_w || max_area <= 0 || tol < 0.f || tol >= 1.f)
+        return D3R_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    int* d_hw = nullptr;
+    if (hipMalloc((void**)&d_hw, 2 * (size_t)n_imgs * sizeof(int)) != hipSuccess) return D3R_ERR_ALLOC;
+    (void)hipMemcpyAsync(d_hw, img_h, n_imgs * sizeof(int), hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(d_hw + n_imgs, img_w, n_imgs * sizeof(int), hipMemcpyHostToDevice, st);
+    for (int i = 0; i < n_imgs; ++i) {
+        const int area = img_h[i] * img_w[i];
+        if (area <= 0 || area > max_area) { (void)hipStreamSynchronize(st); (void)hipFree(d_hw); return D3R_ERR_SHAPE; }
+        hipLaunchKernelGGL(d3r::clean_pointcloud_kernel, dim3((area + 255) / 256), dim3(256), 0, st, i, n_imgs, conf, depth, pts3d, intrinsics,
+                           world2cam, d_hw, d_hw + n_imgs, max_area, tol, bad_conf);
+    }
+    const hipError_t e = hipGetLastError();
+    (void)hipStreamSynchronize(st);   // d_hw is freed below; the call is one-shot post-processing, not a hot loop
+    (void)hipFree(d_hw);
+    return e == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
+}
+
 // ---- host-only self test of the analytic gradients (no GPU): used by the CPU test-suite to check
 // aligner_math.hpp against autograd before any kernel runs. NOT a compute path of the product.
 extern "C" int d3r_selftest_aligner_math_host(int n_imgs, int n_edges, const int* ei, const int* ej, int H, int W,

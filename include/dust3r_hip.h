@@ -181,6 +181,14 @@ int d3r_aligner_run(d3r_aligner* a, int niter, int iter0, int niter_total, float
 int d3r_aligner_loss_grad(d3r_aligner* a, float* loss, float* g_pw_poses, float* g_im_poses, float* g_im_depthmaps,
                           float* g_im_focals, void* stream);
 
+/* clean_pointcloud -- replaces the host-driven O(n^2 A) double loop of dust3r/cloud_opt/base_opt.py:369-405 (called through
+ * BasePCOptimizer.clean_pointcloud, base_opt.py:234-244, by the demo's post-processing). conf [n][max_area] is updated in place with
+ * the reference's sequential semantics (image i sees the cleaned confidences of images j < i); depth [n][max_area],
+ * pts3d [n][max_area][3] (world points), intrinsics [n][9], world2cam [n][16] are DEVICE fp32; img_h / img_w are HOST arrays.
+ * Synchronises `stream` before returning. */
+int d3r_clean_pointcloud(int n_imgs, float* conf, const float* depth, const float* pts3d, const float* intrinsics, const float* world2cam,
+                         const int* img_h, const int* img_w, int max_area, float tol, float bad_conf, void* stream);
+
 /* Host-only self test of the analytic gradient formulas shared with the kernels (no GPU touched; all pointers HOST).
  * Not a compute path: the product never calls it. */
 int d3r_selftest_aligner_math_host(int n_imgs, int n_edges, const int* ei, const int* ej, int H, int W, const float* pred_i,

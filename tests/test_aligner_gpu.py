@@ -133,3 +133,28 @@ def test_preset_pose_and_focal_freeze_parameters(gpu):
     f0, p0 = scene.im_focals.data.clone(), scene.im_poses.data.clone()
     scene.compute_global_alignment(init=None, niter=10, schedule='cosine', lr=0.01)
     assert torch.equal(scene.im_focals.data, f0) and torch.equal(scene.im_poses.data, p0)
+
+
+def test_clean_pointcloud_kernel_matches_host_loop(gpu):
+    """d3r_clean_pointcloud vs the restated host double loop of base_opt.py:369-405 on the same scene (mixed image sizes
+    exercise the padded layout). fp32 projections computed in a different association order can flip a rounded pixel index at
+    an exact .5 boundary, so a vanishing fraction of differing pixels is tolerated; everything else is bit-equal."""
+    from dust3r_amd.cloud_opt.base_opt import clean_pointcloud, clean_pointcloud_hip
+    from dust3r_amd.utils.geometry import inv
+    scene, out, init, gt = make_scene(gpu, 5, 48, 64, seed=9, noise=0.05)
+    scene.compute_global_alignment(init=None, niter=20, schedule='cosine', lr=0.01)
+    with torch.no_grad():
+        scene.im_depthmaps.data[0] -= 0.25      # pull image 0's points 22 % closer: many now sit in front of the other views' depth
+        scene.im_depthmaps.data[3] -= 0.10
+        confs = [c.clone() for c in scene.im_conf]
+        K, cams = scene.get_intrinsics(), inv(scene.get_im_poses())
+        depth, pts = scene.get_depthmaps(), scene.get_pts3d()
+        ref = clean_pointcloud([c.clone() for c in confs], K, cams, depth, pts, tol=0.001, bad_conf=0)
+        got = clean_pointcloud_hip([c.clone() for c in confs], K, cams, depth, pts, tol=0.001, bad_conf=0)
+    changed = sum(int((r != c).sum()) for r, c in zip(ref, confs))
+    diff = sum(int((r != g).sum()) for r, g in zip(ref, got))
+    total = sum(c.numel() for c in confs)
+    print(f'clean_pointcloud: {changed} of {total} confidences clipped by the host loop, {diff} differ between kernel and host loop')
+    assert changed > 0 and diff <= max(2, total // 5000)
+    scene.clean_pointcloud()            # the method routes to the kernel on a CUDA scene
+    assert all(torch.equal(a, b) for a, b in zip(scene.im_conf, got))
