@@ -66,6 +66,7 @@ def _load():
         'd3r_aligner_set_option': (i, [vp, i, i]),
         'd3r_aligner_run': (i, [vp, i, i, i, f, f, i, fp, vp]),
         'd3r_aligner_loss_grad': (i, [vp, fp, fp, fp, fp, fp, vp]),
+        'd3r_nearest_neighbors': (i, [fp, i, fp, i, ip, vp]),
         'd3r_clean_pointcloud': (i, [i, fp, fp, fp, fp, fp, ip, ip, i, f, f, vp]),
         'd3r_selftest_aligner_math_host': (i, [i, i, ip, ip, i, i, fp, fp, fp, fp, fp, fp, fp, fp, f, f, vp, vp, vp, vp, vp]),
     }

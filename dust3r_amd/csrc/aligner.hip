@@ -663,6 +663,44 @@ extern "C" int d3r_clean_pointcloud(int n_imgs, float* conf, const float* depth,
     return e == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
 }
 
+// ---- brute-force 3-D nearest neighbour (find_reciprocal_matches, reference dust3r/utils/geometry.py:345-361) ---------------
+// The reference builds two SciPy KD-trees on the host; on the GPU an exhaustive scan is simpler and faster at pointmap
+// sizes (196 608^2 distance evaluations = 2 x 10^11 flops): one thread per query, reference points streamed through LDS
+// as (x, y, z, -) float4 tiles. Ties resolve to the lowest index.
+namespace d3r {
+__global__ __launch_bounds__(256) void nearest_neighbor_kernel(const float* __restrict__ Q, int nq, const float* __restrict__ R, int nr,
+                                                                int* __restrict__ out) {
+    __shared__ float4 tile[1024];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const bool live = q < nq;
+    const float qx = live ? Q[(size_t)q * 3] : 0.f, qy = live ? Q[(size_t)q * 3 + 1] : 0.f, qz = live ? Q[(size_t)q * 3 + 2] : 0.f;
+    float best = 3.4e38f;
+    int bi = 0;
+    for (int r0 = 0; r0 < nr; r0 += 1024) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < 1024; t += 256) {
+            const int r = r0 + t;
+            tile[t] = r < nr ? make_float4(R[(size_t)r * 3], R[(size_t)r * 3 + 1], R[(size_t)r * 3 + 2], 0.f) : make_float4(3e18f, 3e18f, 3e18f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int t = 0; t < 1024; ++t) {
+            const float4 p = tile[t];
+            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < best) { best = d; bi = r0 + t; }
+        }
+    }
+    if (live) out[q] = bi;
+}
+}  // namespace d3r
+
+extern "C" int d3r_nearest_neighbors(const float* query, int n_query, const float* ref, int n_ref, int* idx_out, void* stream) {
+    if (!query || !ref || !idx_out || n_query <= 0 || n_ref <= 0) return D3R_ERR_INVALID;
+    hipLaunchKernelGGL(d3r::nearest_neighbor_kernel, dim3((n_query + 255) / 256), dim3(256), 0, (hipStream_t)stream, query, n_query, ref, n_ref, idx_out);
+    return hipGetLastError() == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
+}
+
 // ---- host-only self test of the analytic gradients (no GPU): used by the CPU test-suite to check
 // aligner_math.hpp against autograd before any kernel runs. NOT a compute path of the product.
 extern "C" int d3r_selftest_aligner_math_host(int n_imgs, int n_edges, const int* ei, const int* ej, int H, int W,

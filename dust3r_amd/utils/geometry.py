@@ -108,3 +108,30 @@ def get_med_dist_between_poses(poses):
     from scipy.spatial.distance import pdist
     from .device import to_numpy
     return np.median(pdist([to_numpy(p[:3, 3]) for p in poses]))
+
+
+def find_reciprocal_matches(P1, P2):
+    """Mirror of the reference `find_reciprocal_matches` (dust3r/utils/geometry.py:345-361; caller visloc.py:105): mutual nearest
+    neighbours between two 3-D point sets. Returns (reciprocal_in_P2 bool (len P2), nn2_in_P1 int (len P2), number of matches),
+    numpy arrays for numpy inputs and torch tensors for torch inputs. The two nearest-neighbour queries run as exhaustive scans
+    on the GPU (d3r_nearest_neighbors) instead of SciPy KD-trees; exact distance ties resolve to the lowest index."""
+    import ctypes as C
+
+    from .. import _lib
+    from .._lib import check, current_stream, lib, ptr
+    _lib.require_device()
+    as_numpy = isinstance(P1, np.ndarray)
+    dev = P1.device if (isinstance(P1, torch.Tensor) and P1.is_cuda) else torch.device('cuda', torch.cuda.current_device())
+    a = torch.as_tensor(P1, dtype=torch.float32).reshape(-1, 3).to(dev).contiguous()
+    b = torch.as_tensor(P2, dtype=torch.float32).reshape(-1, 3).to(dev).contiguous()
+    nn1_in_P2 = torch.empty(len(a), dtype=torch.int32, device=dev)
+    nn2_in_P1 = torch.empty(len(b), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.d3r_nearest_neighbors(ptr(a), len(a), ptr(b), len(b), ptr(nn1_in_P2), current_stream()), 'nearest_neighbors')
+        check(lib.d3r_nearest_neighbors(ptr(b), len(b), ptr(a), len(a), ptr(nn2_in_P1), current_stream()), 'nearest_neighbors')
+    nn1, nn2 = nn1_in_P2.long(), nn2_in_P1.long()
+    reciprocal_in_P2 = nn1[nn2] == torch.arange(len(nn2), device=dev)
+    count = int(reciprocal_in_P2.sum())
+    if as_numpy:
+        return reciprocal_in_P2.cpu().numpy(), nn2.cpu().numpy(), count
+    return reciprocal_in_P2, nn2, count

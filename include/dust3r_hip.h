@@ -189,6 +189,11 @@ int d3r_aligner_loss_grad(d3r_aligner* a, float* loss, float* g_pw_poses, float*
 int d3r_clean_pointcloud(int n_imgs, float* conf, const float* depth, const float* pts3d, const float* intrinsics, const float* world2cam,
                          const int* img_h, const int* img_w, int max_area, float tol, float bad_conf, void* stream);
 
+/* exhaustive 3-D nearest neighbour: idx_out[q] = argmin_r |query[q] - ref[r]|^2 (lowest index on ties); query [n_query][3],
+ * ref [n_ref][3] DEVICE fp32, idx_out DEVICE int32. The building block of find_reciprocal_matches (dust3r/utils/geometry.py:345-361,
+ * two SciPy KD-tree queries in the reference; caller: visloc.py:105). */
+int d3r_nearest_neighbors(const float* query, int n_query, const float* ref, int n_ref, int* idx_out, void* stream);
+
 /* Host-only self test of the analytic gradient formulas shared with the kernels (no GPU touched; all pointers HOST).
  * Not a compute path: the product never calls it. */
 int d3r_selftest_aligner_math_host(int n_imgs, int n_edges, const int* ei, const int* ej, int H, int W, const float* pred_i,

@@ -183,3 +183,19 @@ def test_upsample2x(gpu, dtype, B, H, W, C, crop):
         ref = ref[:, :crop[0], :crop[1]]
     out = ops.upsample2x_nhwc(x, crop)
     assert out.shape == ref.shape and relerr(out, ref) < OUT_TOL[dtype]
+
+
+def test_find_reciprocal_matches_matches_kdtree(gpu):
+    """dust3r_amd.utils.geometry.find_reciprocal_matches (exhaustive GPU scan) vs the reference's SciPy KD-tree formulation."""
+    import numpy as np
+    from scipy.spatial import KDTree
+    from dust3r_amd.utils.geometry import find_reciprocal_matches
+    rng = np.random.RandomState(0)
+    P1 = rng.randn(5000, 3).astype(np.float32)
+    P2 = (P1[rng.permutation(5000)[:4000]] + 0.01 * rng.randn(4000, 3)).astype(np.float32)
+    rec, nn2, cnt = find_reciprocal_matches(P1, P2)
+    _, nn1_ref = KDTree(P2).query(P1)
+    _, nn2_ref = KDTree(P1).query(P2)
+    rec_ref = nn1_ref[nn2_ref] == np.arange(len(nn2_ref))
+    assert rec.dtype == bool and rec.shape == (4000,) and cnt == int(rec.sum())
+    assert (nn2 == nn2_ref).mean() > 0.9999 and (rec == rec_ref).mean() > 0.9999 and abs(cnt - int(rec_ref.sum())) <= 2
