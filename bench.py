@@ -79,6 +79,25 @@ def read_profile(model):
     return out
 
 
+def read_launch_table(model):
+    """Every launch of the last profiled forward, aggregated by (kernel class, tile configuration, M, N, K): launches, total ms, TFLOP/s.
+    This is what tells WHICH GEMM shapes of the network run below the dominant kernel's average."""
+    from dust3r_amd._lib import lib
+    agg, idx = {}, 0
+    kind, M, N, K, ms, work = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double(), C.c_double()
+    while lib.d3r_model_profile_launch(model._engine, idx, C.byref(kind), C.byref(M), C.byref(N), C.byref(K), C.byref(ms), C.byref(work)) == 0:
+        idx += 1
+        k = kind.value
+        name = f'linear cfg{k}' if k < 8 else f'conv cfg{k - 8}' if k < 16 else 'attention' if k == 16 else 'other'
+        a = agg.setdefault((name, M.value, N.value, K.value), [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += ms.value
+        a[2] += work.value
+    rows = [dict(kernel=k[0], M=k[1], N=k[2], K=k[3], launches=v[0], ms=round(v[1], 3), tflops=round(v[2] / 1e9 / v[1], 1) if v[1] > 0 else 0.0)
+            for k, v in agg.items()]
+    return sorted(rows, key=lambda r: -r['ms'])
+
+
 def pmc_traffic_gb(cfg):
     """HBM bytes per launch of the dominant kernel from the last committed rocprofv3 PMC passes (profiles/pmc_latest.json,
     written by tools/summarize_prof.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE
@@ -289,7 +308,10 @@ def main():
         model(v1, v2)
         torch.cuda.synchronize()
         prof = read_profile(model)
+        table = read_launch_table(model)
         lib.d3r_model_set_option(model._engine, 1, 0)
+        for r in table[:40]:
+            log(f"[bench]   {r['kernel']:12s} M={r['M']:8d} N={r['N']:5d} K={r['K']:5d}  x{r['launches']:3d}  {r['ms']:8.3f} ms  {r['tflops']:7.1f} TF/s")
         if prof:
             # dominant kernel = the gemm_kernel instantiation with the largest total time (one kernel symbol in rocprofv3)
             dom = max(prof['gemm_cfg'], key=lambda c: prof['gemm_cfg'][c]['ms'])
@@ -309,6 +331,7 @@ def main():
             kern['all_gemm_linear'] = dict(prof['linear'], tflops=prof['linear']['gflop'] / max(prof['linear']['ms'], 1e-9))
             kern['all_gemm_conv'] = dict(prof['conv'], tflops=prof['conv']['gflop'] / max(prof['conv']['ms'], 1e-9))
             result['kernels'] = kern
+            result['launch_table'] = table[:24]
             log('[bench] per-kernel: ' + ', '.join(f"{k} {v['ms']:.1f} ms / {v['launches']} launches / {v['tflops']:.0f} TF/s" for k, v in kern.items()))
 
     # ---- the precision mode that meets the north-star parity bar (1e-3 on pointmaps), same workload ----------------------

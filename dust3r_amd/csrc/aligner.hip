@@ -55,12 +55,37 @@ D3R_DEV float wave_sum_dpp(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));  // row_bcast31 -> rows 2,3
     return v;
 }
+// The 13 per-edge sums (dL/dM 3x4 + loss) at once, results valid in lane 63. Written as ONE asm block of DPP-fused adds:
+// from the builtin form above hipcc emits v_mov 0 / v_mov_dpp / v_pk_add groups (5 VALU per 2 values per step, ~190 per
+// edge), and this kernel is VALU-bound (wave64 VALU = 4 cycles; ~440 VALU per thread-edge x 285 wave-edges per SIMD ~ 210 us
+// of the 269 us launch). Fused: 78. Each value is read 13 instructions after it was written, so only the block's first DPP
+// read needs the 2 wait states the hazard rules ask for after a VALU write (s_nop 1).
+D3R_DEV void wave_sum13_dpp(float (&v)[13]) {
+#define D3R_DPP13(ctrl)                                                                                                    \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl "\n\t"       \
+    "v_add_f32_dpp %3, %3, %3 " ctrl "\n\tv_add_f32_dpp %4, %4, %4 " ctrl "\n\tv_add_f32_dpp %5, %5, %5 " ctrl "\n\t"       \
+    "v_add_f32_dpp %6, %6, %6 " ctrl "\n\tv_add_f32_dpp %7, %7, %7 " ctrl "\n\tv_add_f32_dpp %8, %8, %8 " ctrl "\n\t"       \
+    "v_add_f32_dpp %9, %9, %9 " ctrl "\n\tv_add_f32_dpp %10, %10, %10 " ctrl "\n\tv_add_f32_dpp %11, %11, %11 " ctrl "\n\t" \
+    "v_add_f32_dpp %12, %12, %12 " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 D3R_DPP13("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 D3R_DPP13("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 D3R_DPP13("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 D3R_DPP13("row_mirror row_mask:0xf bank_mask:0xf")
+                 D3R_DPP13("row_bcast:15 row_mask:0xa bank_mask:0xf")     // rows 1, 3 += lane 15 of the row before; rows 0, 2 keep their value
+                 D3R_DPP13("row_bcast:31 row_mask:0xc bank_mask:0xf")     // rows 2, 3 += lane 31
+                 "s_nop 1"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                   "+v"(v[10]), "+v"(v[11]), "+v"(v[12]));
+#undef D3R_DPP13
+}
 D3R_DEV float wave_sum_shfl(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
+template <bool L2>
 __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
     const int nchunk = a.nslot;
     const int img = blockIdx.x / nchunk, chunk = blockIdx.x - img * nchunk;
@@ -152,13 +177,14 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
                 const float ia = active ? a.inv_area[side] : 0.f;   // zero weight: inactive lanes contribute nothing
                 const float wv[PPT] = {ww.x * ia, ww.y * ia, ww.z * ia, ww.w * ia};
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) residual_accumulate(X[k], M, pr[k], wv[k], a.l2 != 0, loss, g[k], gm);
+                for (int k = 0; k < PPT; ++k) residual_accumulate(X[k], M, pr[k], wv[k], L2, loss, g[k], gm);
             }
             float red[13];
             if (a.use_dpp) {
 #pragma unroll
-                for (int k = 0; k < 12; ++k) red[k] = wave_sum_dpp(gm[k]);
-                red[12] = wave_sum_dpp(loss);
+                for (int k = 0; k < 12; ++k) red[k] = gm[k];
+                red[12] = loss;
+                wave_sum13_dpp(red);
             } else {
 #pragma unroll
                 for (int k = 0; k < 12; ++k) red[k] = wave_sum_shfl(gm[k]);
@@ -273,7 +299,7 @@ struct SmallView {
     const double* red_img;   // [n][16]
     float* d_edge;           // [E][12]
     float* d_img;            // [n][16]
-    double* scratch;         // [E] gs*s~ ; [1] sum
+    double* scratch;         // [E][8]: gradient wrt P_e[0:7] from pass 1, and gs*s~ in slot 7
     float* loss_hist; int iter;
     float* g_pw; float* g_imp; float* g_foc;  // optional gradient export (tests)
     float base_scale, pw_break, focal_break;
@@ -323,30 +349,20 @@ __global__ __launch_bounds__(256) void aligner_small_kernel(SmallView s) {
             double GM[12], gP[7], gs;
             for (int k = 0; k < 12; ++k) GM[k] = s.red_edge[(size_t)(2 * e) * PW + k] + s.red_edge[(size_t)(2 * e + 1) * PW + k];
             edge_chain(P, R, st, adapt, GM, gP, gs);
-            s.scratch[e] = gs * (double)st;
+            for (int k = 0; k < 7; ++k) s.scratch[(size_t)e * 8 + k] = gP[k];   // reused by pass 2 (same thread, same e)
+            s.scratch[(size_t)e * 8 + 7] = gs * (double)st;
             gsum += gs * (double)st;
             lsum += s.red_edge[(size_t)(2 * e) * PW + 12] + s.red_edge[(size_t)(2 * e + 1) * PW + 12];
         }
         const double sum_gs = block_sum_f64(gsum, sh4);
         const double loss = block_sum_f64(lsum, sh4);
         if (tid == 0 && s.loss_hist) s.loss_hist[s.iter] = (float)loss;
-        // pass 2: gradients + Adam on pairwise poses
+        // pass 2: the scale gradient needs the sum over ALL edges (norm_pw_scale couples them); then Adam on pairwise poses
         for (int e = tid; e < s.E; e += 256) {
             float* P = s.pw_poses + e * 8;
-            float R[9];
-            quat_to_rotmat(P, R);
-            const float st = expf(P[7]) * nf;
-            float adapt[3];
-            {
-                const float a0 = s.pw_adaptors[e * 2], a1 = s.pw_adaptors[e * 2 + 1];
-                const float mean = s.norm_pw_scale ? (2.f * a0 + a1) / 3.f : 0.f;
-                adapt[0] = adapt[1] = expf((a0 - mean) / s.pw_break);
-                adapt[2] = expf((a1 - mean) / s.pw_break);
-            }
-            double GM[12], gP[8], gs;
-            for (int k = 0; k < 12; ++k) GM[k] = s.red_edge[(size_t)(2 * e) * PW + k] + s.red_edge[(size_t)(2 * e + 1) * PW + k];
-            edge_chain(P, R, st, adapt, GM, gP, gs);
-            gP[7] = s.scratch[e] - (s.norm_pw_scale ? sum_gs / (double)s.E : 0.0);
+            double gP[8];
+            for (int k = 0; k < 7; ++k) gP[k] = s.scratch[(size_t)e * 8 + k];
+            gP[7] = s.scratch[(size_t)e * 8 + 7] - (s.norm_pw_scale ? sum_gs / (double)s.E : 0.0);
             if (s.g_pw)
                 for (int k = 0; k < 8; ++k) s.g_pw[e * 8 + k] = (float)gP[k];
             if (s.update)
@@ -483,7 +499,7 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
                  o_de = take((size_t)n_edges * 12), o_di = take((size_t)n_imgs * 16),
                  o_pe = take((size_t)2 * n_edges * a->nslot * PW), o_pi = take((size_t)n_imgs * a->nslot * PW),
                  o_lh = take(a->loss_cap), o_gs = take((size_t)n_edges * 8);
-    const size_t dbl = ((size_t)2 * n_edges * PW + (size_t)n_imgs * PW + n_edges + 8);
+    const size_t dbl = ((size_t)2 * n_edges * PW + (size_t)n_imgs * PW + (size_t)n_edges * 8 + 8);
     a->state_bytes = fl * sizeof(float) + dbl * sizeof(double) + 64;
     if (hipMalloc((void**)&a->state, a->state_bytes) != hipSuccess) { delete a; return D3R_ERR_ALLOC; }
     (void)hipMemset(a->state, 0, a->state_bytes);
@@ -556,7 +572,8 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
     v.depth_grad = g_depth; v.d_edge = a->d_edge; v.d_img = a->d_img; v.part_edge = a->part_edge; v.part_img = a->part_img;
     v.inv_area[0] = a->inv_area[0]; v.inv_area[1] = a->inv_area[1]; v.l2 = a->l2; v.update = update ? 1 : 0;
     v.use_dpp = a->use_dpp; v.adam = s.adam;
-    hipLaunchKernelGGL(aligner_main_kernel, dim3(a->n * a->nslot), dim3(256), 0, st, v);
+    if (a->l2) hipLaunchKernelGGL(aligner_main_kernel<true>, dim3(a->n * a->nslot), dim3(256), 0, st, v);
+    else hipLaunchKernelGGL(aligner_main_kernel<false>, dim3(a->n * a->nslot), dim3(256), 0, st, v);
     // part_edge | part_img and red_edge | red_img are contiguous: one launch reduces the 2E + n entries
     hipLaunchKernelGGL(aligner_reduce_kernel, dim3(2 * a->E + a->n), dim3(256), 0, st, a->part_edge, a->red_edge, a->nslot);
     s.update = update ? 1 : 0;

@@ -154,6 +154,42 @@ template <int DT> D3R_DEV float4 load4(const void* base, size_t elem_off) {
                            Traits<DT>::unpack_hi(v.y));
     }
 }
+// 8 consecutive elements, elem_off % 8 == 0: ONE 16-byte access for the 16-bit types (two for fp32 and for the split-fp16 rows)
+template <int DT> D3R_DEV void store8(void* base, size_t elem_off, const float (&v)[8]) {
+    if constexpr (DT == D3R_BF16 || DT == D3R_F16) {
+        uint4 u;
+        u.x = Traits<DT>::pack2(v[0], v[1]); u.y = Traits<DT>::pack2(v[2], v[3]);
+        u.z = Traits<DT>::pack2(v[4], v[5]); u.w = Traits<DT>::pack2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + elem_off) = u;
+    } else if constexpr (DT == D3R_F16X3) {
+        using TX = Traits<D3R_F16X3>;
+        uint4 h, l;
+        TX::split2(v[0], v[1], h.x, l.x); TX::split2(v[2], v[3], h.y, l.y);
+        TX::split2(v[4], v[5], h.z, l.z); TX::split2(v[6], v[7], h.w, l.w);
+        char* p = reinterpret_cast<char*>(base) + TX::boff(elem_off);
+        *reinterpret_cast<uint4*>(p) = h;
+        *reinterpret_cast<uint4*>(p + 16) = l;
+    } else {
+        store4<DT>(base, elem_off, v[0], v[1], v[2], v[3]);
+        store4<DT>(base, elem_off + 4, v[4], v[5], v[6], v[7]);
+    }
+}
+template <int DT> D3R_DEV void load8(const void* base, size_t elem_off, float (&v)[8]) {
+    if constexpr (DT == D3R_BF16 || DT == D3R_F16) {
+        const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + elem_off);
+        v[0] = Traits<DT>::unpack_lo(u.x); v[1] = Traits<DT>::unpack_hi(u.x); v[2] = Traits<DT>::unpack_lo(u.y); v[3] = Traits<DT>::unpack_hi(u.y);
+        v[4] = Traits<DT>::unpack_lo(u.z); v[5] = Traits<DT>::unpack_hi(u.z); v[6] = Traits<DT>::unpack_lo(u.w); v[7] = Traits<DT>::unpack_hi(u.w);
+    } else if constexpr (DT == D3R_F16X3) {
+        using TX = Traits<D3R_F16X3>;
+        const char* p = reinterpret_cast<const char*>(base) + TX::boff(elem_off);
+        const uint4 h = *reinterpret_cast<const uint4*>(p), l = *reinterpret_cast<const uint4*>(p + 16);
+        v[0] = TX::join_lo(h.x, l.x); v[1] = TX::join_hi(h.x, l.x); v[2] = TX::join_lo(h.y, l.y); v[3] = TX::join_hi(h.y, l.y);
+        v[4] = TX::join_lo(h.z, l.z); v[5] = TX::join_hi(h.z, l.z); v[6] = TX::join_lo(h.w, l.w); v[7] = TX::join_hi(h.w, l.w);
+    } else {
+        const float4 a = load4<DT>(base, elem_off), b = load4<DT>(base, elem_off + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+}
 template <int DT> D3R_DEV void store1(void* base, size_t elem_off, float a) {
     if constexpr (DT == D3R_F32) reinterpret_cast<float*>(base)[elem_off] = a;
     else if constexpr (DT == D3R_F16X3) {

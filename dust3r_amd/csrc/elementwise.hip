@@ -184,48 +184,69 @@ hipError_t launch_rope_table(float* table, int max_pos, float base, float F0, hi
 // ------------------------------------------------------------------------------ bilinear x2
 // F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) on NHWC, cropped to (Ho, Wo)
 // (dpt_head.py:57 crops refinenet4's output to layer 3's size). ATen's source-index formula.
-template <int DT>
+// One workgroup per output row (b, oy): the row's source lines and vertical weights are wave-uniform, the per-item index
+// math is 32-bit (the first version decomposed a flat 64-bit index with three 64-bit divisions per item and moved 8 B per
+// lane: 2x off the HBM rate at the head's 384x512 maps). NV groups of 4 channels per lane: 16 B accesses for 16-bit types.
+template <int DT, int NV>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const void* __restrict__ in, void* __restrict__ out, void* __restrict__ out_relu,
-                                                         int B, int Hi, int Wi, int C, int cstride, int Ho, int Wo) {
-    const int c4n = C >> 2;
-    const size_t total = (size_t)B * Ho * Wo * c4n;
+                                                         int Hi, int Wi, int C, int cstride, int Ho, int Wo) {
+    const int cn = C / (4 * NV);
+    const int b = blockIdx.x / Ho, oy = blockIdx.x - b * Ho;
     const float sh = Hi > 1 ? (float)(Hi - 1) / (float)(2 * Hi - 1) : 0.f;
     const float sw = Wi > 1 ? (float)(Wi - 1) / (float)(2 * Wi - 1) : 0.f;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        size_t r = idx;
-        const int c4 = (int)(r % c4n); r /= c4n;
-        const int ox = (int)(r % Wo); r /= Wo;
-        const int oy = (int)(r % Ho);
-        const int b = (int)(r / Ho);
-        const float fy = sh * (float)oy, fx = sw * (float)ox;
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
-        const float ly = fy - (float)y0, lx = fx - (float)x0;
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        const size_t rb = (size_t)b * Hi;
-        const float4 v00 = load4<DT>(in, ((rb + y0) * Wi + x0) * (size_t)cstride + 4 * c4);
-        const float4 v01 = load4<DT>(in, ((rb + y0) * Wi + x1) * (size_t)cstride + 4 * c4);
-        const float4 v10 = load4<DT>(in, ((rb + y1) * Wi + x0) * (size_t)cstride + 4 * c4);
-        const float4 v11 = load4<DT>(in, ((rb + y1) * Wi + x1) * (size_t)cstride + 4 * c4);
-        const float o0 = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
-        const float o1 = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
-        const float o2 = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
-        const float o3 = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
-        const size_t oo = (((size_t)b * Ho + oy) * Wo + ox) * (size_t)cstride + 4 * c4;
-        store4<DT>(out, oo, o0, o1, o2, o3);
-        if (out_relu) store4<DT>(out_relu, oo, fmaxf(o0, 0.f), fmaxf(o1, 0.f), fmaxf(o2, 0.f), fmaxf(o3, 0.f));
+    const float fy = sh * (float)oy;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, hy = 1.f - ly;
+    const size_t row0 = ((size_t)b * Hi + y0) * Wi, row1 = ((size_t)b * Hi + y1) * Wi;
+    const size_t orow = ((size_t)b * Ho + oy) * Wo;
+    const int items = Wo * cn;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int ox = i / cn, c = (i - ox * cn) * (4 * NV);
+        const float fx = sw * (float)ox;
+        const int x0 = (int)fx;
+        const int x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+        const float lx = fx - (float)x0, hx = 1.f - lx;
+        const size_t a00 = (row0 + x0) * (size_t)cstride + c, a01 = (row0 + x1) * (size_t)cstride + c;
+        const size_t a10 = (row1 + x0) * (size_t)cstride + c, a11 = (row1 + x1) * (size_t)cstride + c;
+        const size_t oo = (orow + ox) * (size_t)cstride + c;
+        if constexpr (NV == 2) {   // cstride % 8 == 0 and c % 8 == 0: whole 16-byte accesses
+            float v00[8], v01[8], v10[8], v11[8], o[8], orl[8];
+            load8<DT>(in, a00, v00);
+            load8<DT>(in, a01, v01);
+            load8<DT>(in, a10, v10);
+            load8<DT>(in, a11, v11);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                o[k] = hy * (hx * v00[k] + lx * v01[k]) + ly * (hx * v10[k] + lx * v11[k]);
+                orl[k] = fmaxf(o[k], 0.f);
+            }
+            store8<DT>(out, oo, o);
+            if (out_relu) store8<DT>(out_relu, oo, orl);
+        } else {
+            const float4 v00 = load4<DT>(in, a00), v01 = load4<DT>(in, a01), v10 = load4<DT>(in, a10), v11 = load4<DT>(in, a11);
+            const float o0 = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+            const float o1 = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+            const float o2 = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+            const float o3 = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+            store4<DT>(out, oo, o0, o1, o2, o3);
+            if (out_relu) store4<DT>(out_relu, oo, fmaxf(o0, 0.f), fmaxf(o1, 0.f), fmaxf(o2, 0.f), fmaxf(o3, 0.f));
+        }
     }
+}
+template <int DT> static void launch_upsample_t(const void* in, void* out, void* out_relu, int B, int Hi, int Wi, int C, int cstride, int Ho, int Wo,
+                                                hipStream_t s) {
+    if (C % 8 == 0 && cstride % 8 == 0) hipLaunchKernelGGL((upsample2x_kernel<DT, 2>), dim3(B * Ho), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);
+    else hipLaunchKernelGGL((upsample2x_kernel<DT, 1>), dim3(B * Ho), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);
 }
 hipError_t launch_upsample2x(int dt, const void* in, void* out, void* out_relu, int B, int Hi, int Wi, int C, int cstride,
                              int Ho, int Wo, hipStream_t s) {
-    if (C % 4 != 0 || Ho > 2 * Hi || Wo > 2 * Wi) return hipErrorInvalidValue;
-    const size_t total = (size_t)B * Ho * Wo * (C / 4);
-    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (C % 4 != 0 || Ho > 2 * Hi || Wo > 2 * Wi || B <= 0 || Ho <= 0 || Wo <= 0) return hipErrorInvalidValue;
     switch (dt) {
-        case D3R_BF16: hipLaunchKernelGGL(upsample2x_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo); break;
-        case D3R_F16: hipLaunchKernelGGL(upsample2x_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo); break;
-        case D3R_F32: hipLaunchKernelGGL(upsample2x_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo); break;
-        case D3R_F16X3: hipLaunchKernelGGL(upsample2x_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo); break;
+        case D3R_BF16: launch_upsample_t<D3R_BF16>(in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo, s); break;
+        case D3R_F16: launch_upsample_t<D3R_F16>(in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo, s); break;
+        case D3R_F32: launch_upsample_t<D3R_F32>(in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo, s); break;
+        case D3R_F16X3: launch_upsample_t<D3R_F16X3>(in, out, out_relu, B, Hi, Wi, C, cstride, Ho, Wo, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -247,32 +268,72 @@ D3R_DEV void postprocess_store(float x, float y, float z, float cl, float* pts, 
 
 // DPT head tail: Conv2d(last_dim, 4, 1) on the ReLU'd features + postprocess (dpt_head.py:63,
 // croco dpt_block head[3:5]). 16 lanes per pixel, 8 channels per lane per step.
+// Sums over the 16 lanes of a DPP row (= the 16 lanes that share a pixel), 4 values at once, every lane gets the totals. One asm
+// block of DPP-fused adds (the builtin form compiles to mov/mov_dpp/add triples; __shfl_xor goes through the LDS crossbar).
+D3R_DEV void row_sum4_dpp(float& a0, float& a1, float& a2, float& a3) {
+#define D3R_DPP4(ctrl) \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 D3R_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 D3R_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 D3R_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 D3R_DPP4("row_mirror row_mask:0xf bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+#undef D3R_DPP4
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void head_final_kernel(const void* __restrict__ feat, int C, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ pts, float* __restrict__ conf,
                                                          size_t npix, int pstride, int cstride) {
     const int sub = threadIdx.x & 15;
-    for (size_t pix = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (size_t)gridDim.x * 16) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int c = sub * 8; c < C; c += 128) {
-            const float4 f0 = load4<DT>(feat, pix * (size_t)C + c), f1 = load4<DT>(feat, pix * (size_t)C + c + 4);
-            const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+    // this lane's slice of the 4 x C weight matrix stays in registers when C <= 128 (the DPT head: C = 128)
+    float wr[4][8];
+    const bool hoist = C <= 128;
+    const int wbase = sub * 8 < C ? sub * 8 : 0;
+    const float wsel = sub * 8 < C ? 1.f : 0.f;
+    if (hoist) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                a0 += fv[e] * w[0 * C + c + e];
-                a1 += fv[e] * w[1 * C + c + e];
-                a2 += fv[e] * w[2 * C + c + e];
-                a3 += fv[e] * w[3 * C + c + e];
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wr[o][e] = w[o * C + wbase + e] * wsel;   // C % 8 == 0: a lane's 8 channels are in or out together
+    }
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2], b3 = bias[3];
+    // all 16 groups of a workgroup iterate together (the DPP block needs every lane active): round the trip count up
+    const size_t stride = (size_t)gridDim.x * 16;
+    for (size_t base = (size_t)blockIdx.x * 16; base < npix; base += stride) {
+        const size_t pix = base + (threadIdx.x >> 4);
+        const bool live = pix < npix;
+        const size_t lp = live ? pix : npix - 1;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (hoist) {
+            if (sub * 8 < C) {
+                float fv[8];
+                load8<DT>(feat, lp * (size_t)C + sub * 8, fv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    a0 += fv[e] * wr[0][e];
+                    a1 += fv[e] * wr[1][e];
+                    a2 += fv[e] * wr[2][e];
+                    a3 += fv[e] * wr[3][e];
+                }
+            }
+        } else {
+            for (int c = sub * 8; c < C; c += 128) {
+                float fv[8];
+                load8<DT>(feat, lp * (size_t)C + c, fv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    a0 += fv[e] * w[0 * C + c + e];
+                    a1 += fv[e] * w[1 * C + c + e];
+                    a2 += fv[e] * w[2 * C + c + e];
+                    a3 += fv[e] * w[3 * C + c + e];
+                }
             }
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            a0 += __shfl_xor(a0, o);
-            a1 += __shfl_xor(a1, o);
-            a2 += __shfl_xor(a2, o);
-            a3 += __shfl_xor(a3, o);
-        }
-        if (sub == 0) postprocess_store(a0 + bias[0], a1 + bias[1], a2 + bias[2], a3 + bias[3], pts, conf, pix, pstride, cstride);
+        row_sum4_dpp(a0, a1, a2, a3);
+        if (sub == 0 && live) postprocess_store(a0 + b0, a1 + b1, a2 + b2, a3 + b3, pts, conf, pix, pstride, cstride);
     }
 }
 hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, const float* b, float* pts, float* conf,

@@ -87,7 +87,7 @@ struct d3r_model {
     // optional per-launch HIP-event timing (d3r_model_set_option(D3R_MODEL_OPT_PROFILE)); off in timed runs
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
-    struct ProfRec { int kind; double work; };
+    struct ProfRec { int kind; double work; int M, N, K; };
     std::vector<ProfRec> prof_rec;
 
     void* dalloc(size_t bytes) {
@@ -283,7 +283,7 @@ struct Ctx {
     int rc = D3R_OK;
     void chk(hipError_t e) { if (e != hipSuccess && rc == D3R_OK) rc = 1000 + (int)e; }
     // profiling: one event BEFORE every launch; a launch's duration is event[i+1] - event[i]
-    void mark(int kind, double work) {
+    void mark(int kind, double work, int M = 0, int N = 0, int K = 0) {
         if (!m->prof_on) return;
         const size_t i = m->prof_rec.size();
         if (i >= m->prof_ev.size()) {
@@ -292,7 +292,7 @@ struct Ctx {
             m->prof_ev.push_back(e);
         }
         (void)hipEventRecord(m->prof_ev[i], st);
-        m->prof_rec.push_back({kind, work});
+        m->prof_rec.push_back({kind, work, M, N, K});
     }
 };
 // profile record kinds: GEMM-kernel launches carry their tile configuration: kind = cfg (0..7) + 8 for implicit-GEMM convolution
@@ -305,7 +305,7 @@ void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi,
     p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_rows = L.n_rows;
     p.n_store = n_store >= 0 ? n_store : L.N;
     p.epi = epi; p.out = out; p.ldo = ldo; p.res1 = res1; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo2; p.flags = flags;
-    c.mark(PRF_GEMM + gemm_pick_config(p, c.m->dt), 2.0 * M * (double)L.N * L.K);
+    c.mark(PRF_GEMM + gemm_pick_config(p, c.m->dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(c.m->dt, p, c.st));
 }
 
@@ -316,7 +316,7 @@ void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_
     p.epi = EPI_HEADS; p.head_c = head_c;
     for (int i = 0; i < nreg; ++i) { p.head_kind[i] = kinds[i]; p.head_dst[i] = dsts[i]; }
     p.heads = heads; p.ntok = ntok; p.tok_w = tok_w; p.ldv = ldv; p.rope_table = c.m->rope_table;
-    c.mark(PRF_GEMM + gemm_pick_config(p, c.m->dt), 2.0 * M * (double)L.N * L.K);
+    c.mark(PRF_GEMM + gemm_pick_config(p, c.m->dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(c.m->dt, p, c.st));
 }
 
@@ -329,7 +329,7 @@ void conv(Ctx& c, const void* in, int B, int Hin, int Win, int cstride, const Co
     p.M = B * p.Hout * p.Wout; p.K = w.K; p.n_pad = w.n_pad; p.n_rows = w.n_rows; p.n_store = n_store >= 0 ? n_store : w.Cout;
     p.zero_page = c.m->zero_page;
     p.epi = EPI_T; p.flags = flags; p.out = out; p.ldo = ldo; p.res1 = res1; p.res2 = res2; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo;
-    c.mark(PRF_CONV + gemm_pick_config(p, c.m->dt), 2.0 * p.M * (double)w.Cout * w.k * w.k * w.Cin);
+    c.mark(PRF_CONV + gemm_pick_config(p, c.m->dt), 2.0 * p.M * (double)w.Cout * w.k * w.k * w.Cin, p.M, w.Cout, w.k * w.k * w.Cin);
     c.chk(launch_gemm(c.m->dt, p, c.st));
 }
 
@@ -479,6 +479,23 @@ extern "C" int d3r_model_profile_read(d3r_model* m, int kind, int* launches, dou
     return D3R_OK;
 }
 
+// One launch of the LAST profiled forward: its class (as above), GEMM shape (M, N, K; attention: batch*heads, queries, keys; 0 for
+// other kernels), duration and algorithmic work. Returns D3R_ERR_STATE past the last launch.
+extern "C" int d3r_model_profile_launch(d3r_model* m, int index, int* kind, int* M, int* N, int* K, double* ms, double* work) {
+    if (!m || index < 0 || (size_t)index + 1 >= m->prof_rec.size()) return D3R_ERR_STATE;
+    if (hipEventSynchronize(m->prof_ev[m->prof_rec.size() - 1]) != hipSuccess) return D3R_ERR_LAUNCH;
+    float dt = 0.f;
+    if (hipEventElapsedTime(&dt, m->prof_ev[index], m->prof_ev[index + 1]) != hipSuccess) return D3R_ERR_LAUNCH;
+    const auto& r = m->prof_rec[index];
+    if (kind) *kind = r.kind;
+    if (M) *M = r.M;
+    if (N) *N = r.N;
+    if (K) *K = r.K;
+    if (ms) *ms = dt;
+    if (work) *work = r.work;
+    return D3R_OK;
+}
+
 // ---- the forward ---------------------------------------------------------------------------------------------
 namespace {
 
@@ -489,7 +506,7 @@ void self_attention(Ctx& c, const void* xn, const Lin& qkv, int M, int C, int he
     gemm_heads(c, xn, C, qkv, M, C, 3, kinds, dsts, heads, ntok, tok_w, ldv);
     AttnParams a;
     a.q = q; a.k = k; a.vt = vt; a.out = ao; a.B = nimg; a.H = heads; a.Nq = ntok; a.Nk = ntok; a.ldv = ldv; a.scale = 0.125f;
-    c.mark(PRF_ATTN, 4.0 * nimg * heads * (double)ntok * ntok * 64);
+    c.mark(PRF_ATTN, 4.0 * nimg * heads * (double)ntok * ntok * 64, nimg * heads, ntok, ntok);
     c.chk(launch_attention(c.m->dt, a, c.st));
 }
 
@@ -513,7 +530,7 @@ void run_dpt(Ctx& c, const DptHead& D, Arena ar, const void* const hooks[4], con
             p.n_pad = D.convt[i].n_pad; p.n_rows = D.convt[i].n_rows; p.n_store = D.convt[i].N; p.epi = EPI_CONVT; p.ksize = D.convt_k[i]; p.ct_cout = D.convt_coutp[i];
             p.Hin = th; p.Win = tw; p.out = cmap[i]; p.ldo = D.cstride[i];
             const int ldi[2] = {96, 192};
-            c.mark(PRF_CONV + gemm_pick_config(p, m->dt), 2.0 * p.M * (double)(D.convt_k[i] * D.convt_k[i] * ldi[i]) * ldi[i]);
+            c.mark(PRF_CONV + gemm_pick_config(p, m->dt), 2.0 * p.M * (double)(D.convt_k[i] * D.convt_k[i] * ldi[i]) * ldi[i], p.M, D.convt_k[i] * D.convt_k[i] * ldi[i], ldi[i]);
             c.chk(launch_gemm(m->dt, p, c.st));
         } else if (i == 3) {
             conv(c, t1, B, th, tw, D.cstride[3], D.act3conv, 2, 1, cmap[3], D.cstride[3], 0);
@@ -695,7 +712,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                     gemm_heads(c, syn, Cd, b.ckv, M1, Cd, 2, kkv, dkv, Hd, N, tw, ldv);
                     AttnParams a;
                     a.q = sq; a.k = sk; a.vt = svt; a.out = sao; a.B = B; a.H = Hd; a.Nq = N; a.Nk = N; a.ldv = ldv; a.scale = 0.125f;
-                    c.mark(PRF_ATTN, 4.0 * B * Hd * (double)N * N * 64);
+                    c.mark(PRF_ATTN, 4.0 * B * Hd * (double)N * N * 64, B * Hd, N, N);
                     c.chk(launch_attention(m->dt, a, c.st));
                 }
                 gemm_linear(c, sao, Cd, b.cproj, M1, EPI_F32, xw, Cd, xw);

@@ -23,6 +23,8 @@
 // attention projections the roles are swapped (i = m) so 4 consecutive TOKENS land together.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace d3r {
@@ -64,6 +66,24 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // copy the whole struct to scratch).
 D3R_DEV int head_kind_of(const GemmParams& p, int region) { return region == 0 ? p.head_kind[0] : (region == 1 ? p.head_kind[1] : p.head_kind[2]); }
 D3R_DEV void* head_dst_of(const GemmParams& p, int region) { return region == 0 ? p.head_dst[0] : (region == 1 ? p.head_dst[1] : p.head_dst[2]); }
+
+// RoPE table rows of token row jj (clamped to M - 1): (cos0,sin0,cos1,sin1), (cos2,sin2,cos3,sin3) of the y position, then of x
+D3R_DEV void load_rope_rows(const float* table, int ntok, int tok_w, int M, int jj, int i4, float4 (&d)[4]) {
+    const int mm = jj < M ? jj : M - 1;
+    const int b = mm / ntok, t = mm - b * ntok;
+    const int ty = t / tok_w, tx = t - ty * tok_w;
+    const float4* cy = reinterpret_cast<const float4*>(table + ((size_t)ty * 16 + i4) * 2);
+    const float4* cx = reinterpret_cast<const float4*>(table + ((size_t)tx * 16 + i4) * 2);
+    d[0] = cy[0]; d[1] = cy[1]; d[2] = cx[0]; d[3] = cx[1];
+}
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+D3R_DEV void store16(void* dst, uint4 v, bool nt) {
+    const u32x4_t w = {v.x, v.y, v.z, v.w};
+    // inline asm: behind a uniform branch hipcc merges a __builtin_nontemporal_store with the plain store and drops the policy
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
+    else *reinterpret_cast<u32x4_t*>(dst) = w;
+}
 
 template <int DT, class CF>
 __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
@@ -327,47 +347,66 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         // P side (i, 4 consecutive per lane) base / Q side (j) base in global coordinates
         const int ib = (swap ? m0 : n0) + wi * (FI * 16), jb = (swap ? n0 : m0) + wj * (FJ * 16);
         const int rrow = lane >> 3, rch = lane & 7;   // read phase: 8 lanes cover one 128-byte row
+        const bool nt = (p.flags & GF_NTSTORE) != 0;
+        // No global read of the wide epilogues sits behind a run-time condition. A load inside `if (p.bias)` / `if (rope)` /
+        // `if (m < M)` whose value is used after the join is a PHI: hipcc copies it at the end of the block and puts
+        // `s_waitcnt vmcnt(0)` there -- load -> wait -> use once per fragment, and vmcnt also counts the stores issued in
+        // between. Measured on the network: residual-stream projections ran 380-580 TF/s against 620-950 for the same shapes
+        // without a residual (32 serial HBM round trips per tile). So every read is issued unconditionally, ahead of its use,
+        // from a clamped index (columns >= n_store / rows >= M are never stored) or, when the operand is absent, from another
+        // readable buffer of the launch, and what is conditional is a register select on the loaded value.
         if constexpr (DT16) {
             if (wide16) {
+                const bool bias_i = !swap && p.bias != nullptr, bias_j = swap && p.bias != nullptr;
+                const float* bsrc = p.bias ? p.bias : reinterpret_cast<const float*>(p.wgt);          // >= n_pad floats either way
+                const bool has_tab = p.epi == EPI_HEADS && p.rope_table != nullptr;
+                const float* rtab = has_tab ? p.rope_table : reinterpret_cast<const float*>(p.wgt);   // dummy reads stay inside row 0 of the weights
+                const int r_ntok = has_tab ? p.ntok : 1, r_tokw = has_tab ? p.tok_w : 1, r_M = has_tab ? p.M : 1;
 #pragma unroll
                 for (int g = 0; g < FI / 4; ++g) {
                     // ---- registers -> LDS (bias, activation / RoPE applied here, rounded once to the 16-bit type)
                     const int ig = ib + g * 64;                 // first i (column n, or token m when swapped) of this group
                     int region = 0, h = 0;
                     bool rope = false, vt = false;
+                    char* hdst = nullptr;
                     if (p.epi == EPI_HEADS) {
-                        const int nh = swap ? jb : ig;          // 64-aligned n of this (wave, group): one head
+                        // wave-uniform, and told so (readfirstlane): left in a VGPR the destination-pointer select became a vector
+                        // load from the kernel-argument segment inside the store loop, followed by vmcnt(0) -- which also waits
+                        // for the previous row's store, i.e. one HBM round trip per stored row
+                        const int nh = __builtin_amdgcn_readfirstlane(swap ? jb : ig);   // 64-aligned n of this (wave, group): one head
                         region = nh / p.head_c;
                         h = (nh - region * p.head_c) >> 6;
                         rope = !swap && head_kind_of(p, region) == HEAD_ROPE;
                         vt = !swap && head_kind_of(p, region) == HEAD_VT;   // transposed through the staging tile
+                        hdst = reinterpret_cast<char*>(head_dst_of(p, region));
                     }
+                    float4 bq[4];
+#pragma unroll
+                    for (int fl = 0; fl < 4; ++fl) {
+                        const float4 t = *reinterpret_cast<const float4*>(bsrc + max(min(ig + fl * 16 + i4, p.n_store - 4), 0));
+                        bq[fl] = make_float4(bias_i ? t.x : 0.f, bias_i ? t.y : 0.f, bias_i ? t.z : 0.f, bias_i ? t.w : 0.f);
+                    }
+                    float bjv[FJ];     // per-row bias of the operand-swapped (V^T) tiles, requested with the rest
+#pragma unroll
+                    for (int fj = 0; fj < FJ; ++fj) bjv[fj] = bsrc[max(min(jb + fj * 16 + jl, p.n_store - 1), 0)];
+                    float4 rt[2][4];   // RoPE table rows, double buffered: fragment fj + 1 is requested before fragment fj is rotated
+                    load_rope_rows(rtab, r_ntok, r_tokw, r_M, jb + jl, i4, rt[0]);
 #pragma unroll
                     for (int fj = 0; fj < FJ; ++fj) {
                         const int j = jb + fj * 16 + jl;        // row m (or feature n when swapped)
-                        float bj = 0.f;
-                        if (swap && p.bias && j < p.n_store) bj = p.bias[j];
-                        float cc[4] = {1.f, 1.f, 1.f, 1.f}, ss[4] = {0.f, 0.f, 0.f, 0.f}, cc2[4] = {1.f, 1.f, 1.f, 1.f}, ss2[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (rope) {
-                            const int mm = j < p.M ? j : p.M - 1;
-                            const int b = mm / p.ntok, t = mm - b * p.ntok;
-                            const int ty = t / p.tok_w, tx = t - ty * p.tok_w;
-                            const float4* cy = reinterpret_cast<const float4*>(p.rope_table + ((size_t)ty * 16 + i4) * 2);
-                            const float4* cx = reinterpret_cast<const float4*>(p.rope_table + ((size_t)tx * 16 + i4) * 2);
-                            const float4 a0 = cy[0], a1 = cy[1], b0 = cx[0], b1 = cx[1];  // (cos0,sin0,cos1,sin1), (cos2,sin2,cos3,sin3)
-                            cc[0] = a0.x; ss[0] = a0.y; cc[1] = a0.z; ss[1] = a0.w; cc[2] = a1.x; ss[2] = a1.y; cc[3] = a1.z; ss[3] = a1.w;
-                            cc2[0] = b0.x; ss2[0] = b0.y; cc2[1] = b0.z; ss2[1] = b0.w; cc2[2] = b1.x; ss2[2] = b1.y; cc2[3] = b1.z; ss2[3] = b1.w;
-                        }
+                        const float bj = bias_j ? bjv[fj] : 0.f;
+                        if (fj + 1 < FJ) load_rope_rows(rtab, r_ntok, r_tokw, r_M, jb + (fj + 1) * 16 + jl, i4, rt[(fj + 1) & 1]);
+                        const float4 a0 = rt[fj & 1][0], a1 = rt[fj & 1][1], b0 = rt[fj & 1][2], b1 = rt[fj & 1][3];
+                        const float cc[4] = {a0.x, a0.z, a1.x, a1.z}, ss[4] = {a0.y, a0.w, a1.y, a1.w};      // y position: pairs (fl 0, fl 1)
+                        const float cc2[4] = {b0.x, b0.z, b1.x, b1.z}, ss2[4] = {b0.y, b0.w, b1.y, b1.w};    // x position: pairs (fl 2, fl 3)
                         float vals[4][4];
 #pragma unroll
                         for (int fl = 0; fl < 4; ++fl) {
-                            const int i = ig + fl * 16 + i4;
-                            float4 bi = make_float4(bj, bj, bj, bj);
-                            if (!swap && p.bias && i < p.n_store) bi = *reinterpret_cast<const float4*>(p.bias + i);
+                            const float4 bi = swap ? make_float4(bj, bj, bj, bj) : bq[fl];
                             const f32x4_t a = acc[g * 4 + fl][fj];
                             vals[fl][0] = a[0] + bi.x; vals[fl][1] = a[1] + bi.y; vals[fl][2] = a[2] + bi.z; vals[fl][3] = a[3] + bi.w;
                         }
-                        if (rope) {   // pairs (fl 0, fl 1) rotate with y, (fl 2, fl 3) with x
+                        if (rope) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const float u = vals[0][r], v = vals[1][r], u2 = vals[2][r], v2 = vals[3][r];
@@ -404,17 +443,17 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                         const uint4 v = *reinterpret_cast<const uint4*>(wreg + row * WROW + rch * 16);
                         const int j = jb + row, i = ig + rch * 8;
                         if (p.epi == EPI_HEADS) {
-                            char* dst = reinterpret_cast<char*>(head_dst_of(p, region));
+                            char* dst = hdst;
                             if (vt) {               // v^T from the transposed tile: row = feature, 8 consecutive tokens per lane
                                 const int tok = jb + rch * 8;
                                 if (tok < p.M) {
                                     const int b = tok / p.ntok, t = tok - b * p.ntok;
-                                    *reinterpret_cast<uint4*>(dst + ((((size_t)(b * p.heads + h) * 64 + row) * p.ldv) + t) * 2) = v;
+                                    store16(dst + ((((size_t)(b * p.heads + h) * 64 + row) * p.ldv) + t) * 2, v, nt);
                                 }
                             } else if (!swap) {     // q / k: [b][h][token][64]
                                 if (j < p.M) {
                                     const int b = j / p.ntok, t = j - b * p.ntok;
-                                    *reinterpret_cast<uint4*>(dst + ((((size_t)(b * p.heads + h) * p.ntok + t) * 64) + rch * 8) * 2) = v;
+                                    store16(dst + ((((size_t)(b * p.heads + h) * p.ntok + t) * 64) + rch * 8) * 2, v, nt);
                                 }
                             } else if (i < p.M && j < p.n_store) {   // v^T: [b][h][feature][ldv], 8 consecutive tokens (ntok % 64 == 0)
                                 const int b = i / p.ntok, t = i - b * p.ntok;
@@ -423,7 +462,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                             }
                         } else if (j < p.M && i < p.n_store) {
                             char* o = reinterpret_cast<char*>(p.out) + ((size_t)j * p.ldo + i) * 2;
-                            if (i + 8 <= p.n_store) *reinterpret_cast<uint4*>(o) = v;
+                            if (i + 8 <= p.n_store) store16(o, v, nt);
                             else *reinterpret_cast<uint2*>(o) = make_uint2(v.x, v.y);   // n_store % 4 == 0
                         }
                     }
@@ -433,13 +472,31 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             }
         }
         if (wide32) {
+            const bool has_res = p.res1 != nullptr, has_bias = p.bias != nullptr;
+            // without a residual the same addresses of the (fp32, same shape) output are read and discarded: no branch, no PHI
+            const float* rsrc = has_res ? reinterpret_cast<const float*>(p.res1) : reinterpret_cast<const float*>(p.out);
+            const int rld = has_res ? p.ldr : p.ldo;
+            const float* bsrc = has_bias ? p.bias : reinterpret_cast<const float*>(p.wgt);
 #pragma unroll
             for (int g = 0; g < FI / 2; ++g) {
                 const int ig = ib + g * 32;
+                // the residual rows this lane adds in the read phase, all 8 requested now. In place (res1 == out) is fine: a lane
+                // reads exactly the elements it stores later and nobody else touches them.
+                float4 rr[8];
+#pragma unroll
+                for (int pass = 0; pass < 8; ++pass) {
+                    const int m = min(jb + pass * 8 + rrow, p.M - 1), n = max(min(ig + rch * 4, p.n_store - 4), 0);
+                    rr[pass] = *reinterpret_cast<const float4*>(rsrc + (size_t)m * rld + n);
+                }
+                float4 bi2[2];
 #pragma unroll
                 for (int fl = 0; fl < 2; ++fl) {
-                    const int i = ig + fl * 16 + i4;
-                    const float4 bi = (p.bias && i < p.n_store) ? *reinterpret_cast<const float4*>(p.bias + i) : make_float4(0, 0, 0, 0);
+                    const float4 t = *reinterpret_cast<const float4*>(bsrc + max(min(ig + fl * 16 + i4, p.n_store - 4), 0));
+                    bi2[fl] = make_float4(has_bias ? t.x : 0.f, has_bias ? t.y : 0.f, has_bias ? t.z : 0.f, has_bias ? t.w : 0.f);
+                }
+#pragma unroll
+                for (int fl = 0; fl < 2; ++fl) {
+                    const float4 bi = bi2[fl];
 #pragma unroll
                     for (int fj = 0; fj < FJ; ++fj) {
                         const f32x4_t a = acc[g * 2 + fl][fj];
@@ -452,12 +509,10 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                     const int row = pass * 8 + rrow;
                     float4 v = *reinterpret_cast<const float4*>(wreg + row * WROW + rch * 16);
                     const int m = jb + row, n = ig + rch * 4;
+                    v.x += has_res ? rr[pass].x : 0.f; v.y += has_res ? rr[pass].y : 0.f;
+                    v.z += has_res ? rr[pass].z : 0.f; v.w += has_res ? rr[pass].w : 0.f;
                     if (m < p.M && n < p.n_store) {
-                        if (p.res1) {
-                            const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res1) + (size_t)m * p.ldr + n);
-                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                        }
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n) = v;
+                        store16(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), nt);
                         if (p.out2) store4<DT>(p.out2, (size_t)m * p.ldo2 + n, v.x, v.y, v.z, v.w);
                     }
                 }
@@ -637,12 +692,15 @@ int gemm_pick_config(const GemmParams& p, int dt) {
         return GEMM_CFG_128;
     }
     const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.n_store, 256);
-    if (ok256 && tiles256 >= 700) {
+    long t256 = 700;     // probes: D3R_GEMM_T256 moves the 256x256 / 128x128 crossover, D3R_GEMM_MID=2 sends the shapes below it to 256x128
+    if (const char* e = getenv("D3R_GEMM_T256")) t256 = atol(e);
+    if (ok256 && tiles256 >= t256) {
         // nn.Linear operands: the ping-pong schedule measured 1-8 % ahead of the plain 2-stage loop (profiles/r01_call13);
         // implicit-GEMM operands: behind it (the per-tap address arithmetic sits in the load segment) -> plain loop
         static const bool pp = [] { const char* e = getenv("D3R_GEMM_PP"); return e ? e[0] == '1' : false; }();
         return (pp && p.amode == AMODE_LINEAR) ? GEMM_CFG_256PP : GEMM_CFG_256;
     }
+    if (const char* e = getenv("D3R_GEMM_MID")) if (e[0] == '2' && !heads) return GEMM_CFG_256x128;
     return GEMM_CFG_128;
 }
 
@@ -668,7 +726,9 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
 hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     if (const char* e = getenv("D3R_GEMM_NOSTORE")) if (e[0] == '1') p.flags |= GF_NOSTORE;
-    if (const char* e = getenv("D3R_GEMM_NOWIDE")) if (e[0] == '1') p.flags |= GF_NOWIDE;   // A/B: direct (narrow) epilogue stores
+    if (const char* e = getenv("D3R_GEMM_NOWIDE")) if (e[0] == '1') p.flags |= GF_NOWIDE;
+    // wide epilogues store with the non-temporal policy (measured +3..10 % on isolated GEMMs, +1 % on the forward); D3R_GEMM_NT=0: plain stores
+    { const char* e = getenv("D3R_GEMM_NT"); if (!e || e[0] != '0') p.flags |= GF_NTSTORE; }
     const int kt = 128 / (int)dt_bytes(dt);
     if (p.M <= 0 || p.n_pad % 128 != 0 || p.n_store > p.n_pad || p.K % kt != 0 || p.K <= 0) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV && (p.Cin % kt != 0 || p.zero_page == nullptr)) return hipErrorInvalidValue;

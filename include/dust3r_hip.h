@@ -142,6 +142,9 @@ size_t d3r_model_device_bytes(const d3r_model* m);
                                      * into the caller's stream before d3r_model_forward's work completes; 0: everything on the caller's stream */
 int d3r_model_set_option(d3r_model* m, int option, int value);
 int d3r_model_profile_read(d3r_model* m, int kind, int* launches, double* ms, double* work);
+/* launch `index` of the last profiled forward: class, GEMM shape (attention: batch*heads, queries, keys), ms, flops;
+ * D3R_ERR_STATE past the last launch */
+int d3r_model_profile_launch(d3r_model* m, int index, int* kind, int* M, int* N, int* K, double* ms, double* work);
 /* debug/parity hook: copy an internal activation of the last forward to `out_f32` (device fp32).
  * what: 0 = encoder output after enc_norm [2B*N][enc_dim] (img1 batch then img2 batch) */
 int d3r_model_debug_read(d3r_model* m, int what, float* out_f32, size_t max_elems, void* stream);

@@ -184,12 +184,56 @@ def aligner_probe():
         del scene, out
 
 
+def tune_probe():
+    """A/B switches measured on the whole forward (B = 32, bf16, two-stream, as bench.py times it) and on isolated GEMMs with the
+    network's epilogues (bf16 out / fp32 residual stream): D3R_GEMM_NT=0 (plain instead of non-temporal epilogue stores),
+    D3R_GEMM_T256 (256x256 / 128x128 crossover, default 700 tiles)."""
+    import os
+    from dust3r_amd._lib import lib, ptr, current_stream, check
+    from dust3r_amd.model import AsymmetricCroCo3DStereo
+    from dust3r_amd.synthetic import MODEL_CONFIGS, OUT_GAIN, synthetic_state_dict, synthetic_views
+    print('== tune: isolated GEMMs (TF/s): bf16 store | fp32 out + fp32 residual (the residual-stream epilogue) | GELU; nt on / off')
+    for (M, N, K) in ((49152, 1024, 1024), (49152, 1024, 4096), (49152, 4096, 1024), (24576, 768, 768), (24576, 768, 3072)):
+        a = torch.randn((M, K), device=dev).to(torch.bfloat16)
+        w = ops.pad_rows((torch.randn((N, K), device=dev) / math.sqrt(K)).to(torch.bfloat16))
+        b = ops.pad_rows(torch.randn(N, device=dev))
+        out16 = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        out32 = torch.randn((M, N), dtype=torch.float32, device=dev)
+        line = f'  M={M} N={N} K={K}'
+        for name, epi, o, r in (('store', 0, out16, None), ('f32+res', 1, out32, out32), ('gelu', 2, out16, None)):
+            def run():
+                check(lib.d3r_linear(ptr(a), ptr(w), ptr(b), ptr(o), ptr(r), M, N, K, epi, ops._dt(a), current_stream()))
+            for nt in ('1', '0'):
+                os.environ['D3R_GEMM_NT'] = nt
+                ms = timeit(run, warm=2, reps=6)
+                line += f' | {name} nt={nt}: {2 * M * N * K / ms / 1e9:6.1f}'
+            os.environ.pop('D3R_GEMM_NT', None)
+        print(line)
+    cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
+    m = AsymmetricCroCo3DStereo(precision='bf16', landscape_only=False, **MODEL_CONFIGS[cfg])
+    m.load_state_dict(synthetic_state_dict({k: torch.empty(v, device='meta') for k, v in m._spec.items()}, 0, OUT_GAIN[cfg], device=dev))
+    m.to(dev)
+    v1, v2 = synthetic_views(32, 384, 512, seed=0, device=dev)
+    print('== tune: forward B=32 bf16 (two streams)')
+    variants = [('default', {}), ('plain stores', {'D3R_GEMM_NT': '0'}), ('T256=250', {'D3R_GEMM_T256': '250'}), ('default again', {})]
+    for name, env in variants:
+        for k, v in env.items():
+            os.environ[k] = v
+        ms = timeit(lambda: m(v1, v2), warm=2, reps=4)
+        for k in env:
+            os.environ.pop(k, None)
+        print(f'  {name:26s}: {ms:8.2f} ms/forward  {32 / ms * 1e3:7.2f} pairs/s')
+    m.set_two_streams(False)
+    ms = timeit(lambda: m(v1, v2), warm=2, reps=4)
+    print(f'  {"single stream":26s}: {ms:8.2f} ms/forward  {32 / ms * 1e3:7.2f} pairs/s')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['gemm', 'attn', 'forward', 'aligner']
     print(torch.cuda.get_device_name(0))
     for w in which:
         try:
-            {'gemm': gemm_probe, 'cache': cache_probe, 'conv': conv_probe, 'attn': attn_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
+            {'gemm': gemm_probe, 'tune': tune_probe, 'cache': cache_probe, 'conv': conv_probe, 'attn': attn_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
         except Exception as e:  # keep going: this is a probe
             import traceback
             traceback.print_exc()
