@@ -686,6 +686,10 @@ int gemm_pick_config(const GemmParams& p, int dt) {
     if (forced == GEMM_CFG_128 || (forced == GEMM_CFG_256 && ok256) ||
         ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128 || forced == GEMM_CFG_256x128W4) && !heads) || ((forced == GEMM_CFG_256S4 || forced == GEMM_CFG_256PP) && ok256))
         return forced;
+    if (p.epi == EPI_F32 && p.K <= 1024) {   // probe: tile of the HBM-heavy residual-stream epilogues at short K (D3R_GEMM_F32CFG=0|2|4)
+        if (const char* e = getenv("D3R_GEMM_F32CFG"))
+            if ((e[0] == '0' || e[0] == '2' || e[0] == '4') && e[1] == 0) return e[0] - '0';
+    }
     if (!heads && p.n_store <= 128) {
         if (cdiv(p.M, 512) >= 512) return GEMM_CFG_512x128;
         if (cdiv(p.M, 256) >= 512) return GEMM_CFG_256x128;

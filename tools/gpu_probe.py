@@ -193,7 +193,7 @@ def tune_probe():
     from dust3r_amd.model import AsymmetricCroCo3DStereo
     from dust3r_amd.synthetic import MODEL_CONFIGS, OUT_GAIN, synthetic_state_dict, synthetic_views
     print('== tune: isolated GEMMs (TF/s): bf16 store | fp32 out + fp32 residual (the residual-stream epilogue) | GELU; nt on / off')
-    for (M, N, K) in ((49152, 1024, 1024), (49152, 1024, 4096), (49152, 4096, 1024), (24576, 768, 768), (24576, 768, 3072)):
+    for (M, N, K) in ((49152, 1024, 1024), (49152, 1024, 4096), (24576, 768, 768), (24576, 768, 3072)):
         a = torch.randn((M, K), device=dev).to(torch.bfloat16)
         w = ops.pad_rows((torch.randn((N, K), device=dev) / math.sqrt(K)).to(torch.bfloat16))
         b = ops.pad_rows(torch.randn(N, device=dev))
@@ -203,11 +203,14 @@ def tune_probe():
         for name, epi, o, r in (('store', 0, out16, None), ('f32+res', 1, out32, out32), ('gelu', 2, out16, None)):
             def run():
                 check(lib.d3r_linear(ptr(a), ptr(w), ptr(b), ptr(o), ptr(r), M, N, K, epi, ops._dt(a), current_stream()))
-            for nt in ('1', '0'):
-                os.environ['D3R_GEMM_NT'] = nt
+            for c in ((None, '0', '2', '4') if epi == 1 else (None,)):
+                if c is None:
+                    os.environ.pop('D3R_GEMM_CFG', None)
+                else:
+                    os.environ['D3R_GEMM_CFG'] = c
                 ms = timeit(run, warm=2, reps=6)
-                line += f' | {name} nt={nt}: {2 * M * N * K / ms / 1e9:6.1f}'
-            os.environ.pop('D3R_GEMM_NT', None)
+                line += f' | {name} cfg {c or "auto"}: {2 * M * N * K / ms / 1e9:6.1f}'
+            os.environ.pop('D3R_GEMM_CFG', None)
         print(line)
     cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
     m = AsymmetricCroCo3DStereo(precision='bf16', landscape_only=False, **MODEL_CONFIGS[cfg])
@@ -215,7 +218,8 @@ def tune_probe():
     m.to(dev)
     v1, v2 = synthetic_views(32, 384, 512, seed=0, device=dev)
     print('== tune: forward B=32 bf16 (two streams)')
-    variants = [('default', {}), ('plain stores', {'D3R_GEMM_NT': '0'}), ('T256=250', {'D3R_GEMM_T256': '250'}), ('default again', {})]
+    variants = [('default', {}), ('f32 epilogue K<=1024 on 128x128', {'D3R_GEMM_F32CFG': '0'}), ('f32 epilogue K<=1024 on 256x128', {'D3R_GEMM_F32CFG': '2'}),
+                ('f32 epilogue K<=1024 on 256x128 w4', {'D3R_GEMM_F32CFG': '4'}), ('T256=250', {'D3R_GEMM_T256': '250'}), ('default again', {})]
     for name, env in variants:
         for k, v in env.items():
             os.environ[k] = v

@@ -15,7 +15,7 @@ for w in $WHAT; do
     tests) timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log ;;
     testsall) timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -15 $OUT/pytest_gpu.log ;;
     probe) timeout 900 python tools/gpu_probe.py gemm conv attn forward aligner > $OUT/probe.log 2>&1; tail -60 $OUT/probe.log ;;
-    tune) timeout 600 python tools/gpu_probe.py tune aligner > $OUT/probe_tune.log 2>&1; tail -40 $OUT/probe_tune.log ;;
+    tune) timeout 600 python tools/gpu_probe.py tune > $OUT/probe_tune.log 2>&1; tail -40 $OUT/probe_tune.log ;;
     benchq) timeout 600 python bench.py --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.log; grep -E "bench\]" $OUT/bench_quick.log | tail -60 ;;
     bench) timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.log; tail -12 $OUT/bench.log; cat $OUT/bench.json ;;
     prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.log); find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
