@@ -45,6 +45,33 @@ for tag in ('pmc_fetch', 'pmc_write'):
         for (k, c), (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
             print(f'  {c:12s} sum {v:16.1f} over {n:7d} dispatches, mean {v / n:14.2f}  {k}')
 
+# ---- SQ / GRBM passes: per kernel, mean per dispatch of every counter + the derived utilisations ------------------------------
+for tag in ('pmc_sq1', 'pmc_sq2'):
+    for f in sorted(glob.glob(os.path.join(out, tag, '**', '*counter_collection.csv'), recursive=True)):
+        agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = short(row.get('Kernel_Name', '?'))
+                if 'd3r::' not in k:
+                    continue
+                a = agg[k][row.get('Counter_Name', '?')]
+                a[0] += 1
+                a[1] += float(row.get('Counter_Value', 0))
+        print('== pmc (SQ / GRBM), mean per dispatch:', f)
+        order = sorted(agg.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', [0, 0.0])[1])
+        for k, cs in order[:14]:
+            n = max(v[0] for v in cs.values())
+            m = {c: v[1] / max(v[0], 1) for c, v in cs.items()}
+            line = f'  {k[:100]}  x{n}\n      ' + '  '.join(f'{c}={v:.4g}' for c, v in sorted(m.items()))
+            gui = m.get('GRBM_GUI_ACTIVE', 0.0)
+            if gui > 0 and 'SQ_VALU_MFMA_BUSY_CYCLES' in m:
+                line += f'\n      MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs) = {m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024) * 100:.1f} %'
+            if m.get('SQ_WAVE_CYCLES', 0) > 0:
+                w = m['SQ_WAVE_CYCLES']
+                parts = [f'{c}/WAVE_CYCLES={m[c] / w * 100:.1f}%' for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_INST_LDS', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS', 'SQ_INST_CYCLES_VMEM') if c in m]
+                line += '\n      ' + '  '.join(parts)
+            print(line)
+
 # ---- machine-readable digest for bench.py's roofline.traffic (copied by hand to profiles/pmc_latest.json) ------------------
 import json  # noqa: E402
 
