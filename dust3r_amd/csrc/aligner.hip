@@ -85,7 +85,7 @@ D3R_DEV float wave_sum_shfl(float v) {
     return v;
 }
 
-template <bool L2>
+template <bool L2, int PF>   // PF = prefetch distance of the pred / weight stream in edges (1 or 2)
 __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
     const int nchunk = a.nslot;
     const int img = blockIdx.x / nchunk, chunk = blockIdx.x - img * nchunk;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
             sh_M[j][k] = a.d_edge[(es >> 1) * 12 + k];
         }
         __syncthreads();
-        float4 nq0, nq1, nq2, nww;
+        float4 nq0, nq1, nq2, nww, mq0, mq1, mq2, mww;   // edge j + 1 (and, PF == 2, edge j + 2) in flight
         {
             const int es = sh_es[0];
             const float* pp = a.pred[es & 1] + (size_t)(es >> 1) * 3 * a.maxA + pl;
@@ -150,17 +150,31 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
             nq2 = *reinterpret_cast<const float4*>(pp + 2 * (size_t)a.maxA);
             nww = *reinterpret_cast<const float4*>(a.wgt[es & 1] + (size_t)(es >> 1) * a.maxA + pl);
         }
+        if (PF == 2) {
+            const int es = sh_es[nb > 1 ? 1 : 0];
+            const float* pp = a.pred[es & 1] + (size_t)(es >> 1) * 3 * a.maxA + pl;
+            mq0 = *reinterpret_cast<const float4*>(pp);
+            mq1 = *reinterpret_cast<const float4*>(pp + a.maxA);
+            mq2 = *reinterpret_cast<const float4*>(pp + 2 * (size_t)a.maxA);
+            mww = *reinterpret_cast<const float4*>(a.wgt[es & 1] + (size_t)(es >> 1) * a.maxA + pl);
+        }
         for (int j = 0; j < nb; ++j) {
             const int es = sh_es[j];
             const int side = es & 1;
             const float4 q0 = nq0, q1 = nq1, q2 = nq2, ww = nww;
             {   // unconditional (index clamped): a branch here would make the compiler wait for the loads at its join
-                const int es2 = sh_es[j + 1 < nb ? j + 1 : j];
+                const int jn = j + PF < nb ? j + PF : nb - 1;
+                const int es2 = sh_es[jn];
                 const float* pp = a.pred[es2 & 1] + (size_t)(es2 >> 1) * 3 * a.maxA + pl;
-                nq0 = *reinterpret_cast<const float4*>(pp);
-                nq1 = *reinterpret_cast<const float4*>(pp + a.maxA);
-                nq2 = *reinterpret_cast<const float4*>(pp + 2 * (size_t)a.maxA);
-                nww = *reinterpret_cast<const float4*>(a.wgt[es2 & 1] + (size_t)(es2 >> 1) * a.maxA + pl);
+                if (PF == 2) { nq0 = mq0; nq1 = mq1; nq2 = mq2; nww = mww; }
+                float4& d0 = PF == 2 ? mq0 : nq0;
+                float4& d1 = PF == 2 ? mq1 : nq1;
+                float4& d2 = PF == 2 ? mq2 : nq2;
+                float4& dw = PF == 2 ? mww : nww;
+                d0 = *reinterpret_cast<const float4*>(pp);
+                d1 = *reinterpret_cast<const float4*>(pp + a.maxA);
+                d2 = *reinterpret_cast<const float4*>(pp + 2 * (size_t)a.maxA);
+                dw = *reinterpret_cast<const float4*>(a.wgt[es2 & 1] + (size_t)(es2 >> 1) * a.maxA + pl);
             }
             float M[12];
             {
@@ -572,8 +586,16 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
     v.depth_grad = g_depth; v.d_edge = a->d_edge; v.d_img = a->d_img; v.part_edge = a->part_edge; v.part_img = a->part_img;
     v.inv_area[0] = a->inv_area[0]; v.inv_area[1] = a->inv_area[1]; v.l2 = a->l2; v.update = update ? 1 : 0;
     v.use_dpp = a->use_dpp; v.adam = s.adam;
-    if (a->l2) hipLaunchKernelGGL(aligner_main_kernel<true>, dim3(a->n * a->nslot), dim3(256), 0, st, v);
-    else hipLaunchKernelGGL(aligner_main_kernel<false>, dim3(a->n * a->nslot), dim3(256), 0, st, v);
+    // D3R_ALIGNER_PF=2: two edges of the stream in flight per wave (probe; 16 more VGPRs, 3 instead of 4 waves per SIMD)
+    static const int pf = [] { const char* e = getenv("D3R_ALIGNER_PF"); return (e && e[0] == '2') ? 2 : 1; }();
+    const dim3 grid(a->n * a->nslot);
+    if (a->l2) {
+        if (pf == 2) hipLaunchKernelGGL((aligner_main_kernel<true, 2>), grid, dim3(256), 0, st, v);
+        else hipLaunchKernelGGL((aligner_main_kernel<true, 1>), grid, dim3(256), 0, st, v);
+    } else {
+        if (pf == 2) hipLaunchKernelGGL((aligner_main_kernel<false, 2>), grid, dim3(256), 0, st, v);
+        else hipLaunchKernelGGL((aligner_main_kernel<false, 1>), grid, dim3(256), 0, st, v);
+    }
     // part_edge | part_img and red_edge | red_img are contiguous: one launch reduces the 2E + n entries
     hipLaunchKernelGGL(aligner_reduce_kernel, dim3(2 * a->E + a->n), dim3(256), 0, st, a->part_edge, a->red_edge, a->nslot);
     s.update = update ? 1 : 0;

@@ -65,7 +65,8 @@ for tag in ('pmc_sq1', 'pmc_sq2'):
             line = f'  {k[:100]}  x{n}\n      ' + '  '.join(f'{c}={v:.4g}' for c, v in sorted(m.items()))
             gui = m.get('GRBM_GUI_ACTIVE', 0.0)
             if gui > 0 and 'SQ_VALU_MFMA_BUSY_CYCLES' in m:
-                line += f'\n      MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs) = {m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024) * 100:.1f} %'
+                # the csv row of GRBM_GUI_ACTIVE is the sum over the 8 XCDs (each has its own GRBM): 297 us launches read 5.4e6 "cycles"
+                line += f'\n      MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs) = {m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8 * 1024) * 100:.1f} %'
             if m.get('SQ_WAVE_CYCLES', 0) > 0:
                 w = m['SQ_WAVE_CYCLES']
                 parts = [f'{c}/WAVE_CYCLES={m[c] / w * 100:.1f}%' for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_INST_LDS', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS', 'SQ_INST_CYCLES_VMEM') if c in m]
