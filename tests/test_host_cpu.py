@@ -199,3 +199,22 @@ def test_model_state_dict_duplication_and_parsing():
     r = m.load_state_dict(no_dec2, strict=True)                      # model.py:91-98 duplication
     assert not r.missing_keys
     assert torch.equal(m.state_dict()['dec_blocks2.0.attn.qkv.weight'], sd['dec_blocks.0.attn.qkv.weight'])
+
+
+def test_c_abi_is_usable_from_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/dust3r_hip.h must compile as C99 (-pedantic), every entry point a C caller uses
+    must link against libdust3r_hip.so, and argument errors must come back as D3R_ERR_* codes without a device (tests/c_abi/probe.c)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('gcc not available')
+    from dust3r_amd import _lib
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / 'c_abi_probe')
+    cmd = [gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'c_abi', 'probe.c'),
+           '-o', exe, '-L', libdir, '-ldust3r_hip', f'-Wl,-rpath,{libdir}', '-Wl,-rpath,/opt/rocm/lib']
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and 'c_abi probe ok' in r.stdout, r.stdout + r.stderr
