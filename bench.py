@@ -12,7 +12,8 @@ pairwise predictions (dust3r_amd/parallel.py), issued asynchronously so that it 
 
 Usage: python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
 Prints ONE JSON line on rank 0. Extra objects: "roofline" (dominant kernel, live HIP-event timing), "cpu_baseline"
-(the CPU oracle timed on this host's cores on a bounded sample, rank 0 at N=1 only), "aligner", "kernels".
+(the CPU oracle timed on this host's cores on a bounded sample, rank 0 at N=1 only), "aligner", "kernels", "fast_mode"
+(bf16 / fp16 single-pass throughput with their measured error: the headline precision is fp16x3, the mode that meets the 1e-3 bar).
 """
 import argparse
 import ctypes as C
@@ -98,13 +99,15 @@ def read_launch_table(model):
     return sorted(rows, key=lambda r: -r['ms'])
 
 
-def pmc_traffic_gb(cfg):
+def pmc_traffic_gb(cfg, precision=None):
     """HBM bytes per launch of the dominant kernel from the last committed rocprofv3 PMC passes (profiles/pmc_latest.json,
     written by tools/summarize_prof.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950). None when no such file travels with the repository."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')) as f:
             d = json.load(f)
+        if precision is not None and d.get('precision', 'bf16') != precision:
+            return None                       # the committed PMC passes were taken in another precision mode
         return d.get('gemm_cfg', {}).get(str(cfg), {}).get('hbm_gb_per_launch')
     except Exception:
         return None
@@ -154,9 +157,21 @@ def _keep_heap():
         pass
 
 
-def cpu_baseline_forward(budget_s=25.0):
-    """The CPU oracle (fp32 PyTorch restatement of the reference path, oracle/dust3r_ref.py) on this host's cores,
-    on a bounded sample of the same workload: single 512x384 pairs of the same model, until ~budget_s of CPU time."""
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline_forward(reps=3):
+    """SURVEY.md 8(d) protocol: the CPU oracle (fp32 PyTorch restatement of the reference path, oracle/dust3r_ref.py) on this
+    host's cores, same model / image size as the GPU leg, B = 1 and B = 4 pairs per call, `reps` calls each after one untimed
+    call, MEDIAN reported. `value` is the better of the two medians in pairs/s (both are in `sample`)."""
     from oracle.dust3r_ref import build_ref_model_fast
     from dust3r_amd.synthetic import synthetic_views
     from oracle import tune_threads
@@ -165,38 +180,41 @@ def cpu_baseline_forward(budget_s=25.0):
     t = time.time()
     oracle = build_ref_model_fast(MODEL)
     log(f'[bench] cpu oracle built in {time.time() - t:.1f}s, threads {torch.get_num_threads()}')
-    v1, v2 = synthetic_views(1, H, W, seed=0)
-    times = []
-    t_all = time.time()
+    med = {}
     with torch.no_grad():
-        while len(times) < 3 and (time.time() - t_all) < budget_s:
-            t = time.time()
-            oracle(v1, v2)
-            times.append(time.time() - t)
-    best = min(times)
-    return dict(value=1.0 / best, unit='pairs/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{len(times)} x 1 pair 512x384 {MODEL} fp32 (oracle/dust3r_ref.py), best of {len(times)}: {best:.2f} s/pair')
+        for B in (1, 4):
+            v1, v2 = synthetic_views(B, H, W, seed=0)
+            oracle(v1, v2)                      # untimed: first-touch page faults
+            times = []
+            for _ in range(reps):
+                t = time.time()
+                oracle(v1, v2)
+                times.append(time.time() - t)
+            med[B] = sorted(times)[len(times) // 2]
+            log(f'[bench] cpu oracle B={B}: median {med[B]:.2f} s per call ({B / med[B]:.3f} pairs/s)')
+    best = max(B / med[B] for B in med)
+    return dict(value=best, unit='pairs/s', cores=torch.get_num_threads(), cpu_model=_cpu_model(), logical_cpus=os.cpu_count(), kind='port',
+                pairs_per_s_B1=1 / med[1], pairs_per_s_B4=4 / med[4],
+                sample=f'{MODEL} fp32 512x384 (oracle/dust3r_ref.py), median of {reps} calls after 1 untimed: B=1 {med[1]:.2f} s/call, B=4 {med[4]:.2f} s/call')
 
 
-def cpu_baseline_aligner(device, n_edges_full, n_views=8):
-    """CPU oracle of the aligner loop (oracle/aligner_ref.py: the reference's forward restated + torch autograd + Adam) on a
-    bounded sample: a full-resolution sub-scene with fewer views; per-iteration work is linear in the number of edges
-    (E x 196608 residual pairs dominate), so the rate is scaled to the 190-edge workload and the sample is stated."""
+def cpu_baseline_aligner(scene_io, warm=2, timed=20):
+    """SURVEY.md 8(d) protocol: the CPU oracle of the aligner loop (oracle/aligner_ref.py: the reference's forward restated +
+    torch autograd + Adam) on the SAME 20-view / 190-edge 512x384 inputs and initial state as the GPU leg: `warm` untimed
+    iterations, then `timed` iterations on the clock (no edge-count extrapolation)."""
     from oracle.aligner_ref import AlignerRef
-    from dust3r_amd.synthetic import synthetic_scene
-    out, init, _ = synthetic_scene(n_views, H, W, seed=0, symmetrize=False, device=device)
+    out, init = scene_io
     out = {k: ({kk: (vv.cpu() if isinstance(vv, torch.Tensor) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v)
            for k, v in out.items()}
     ref = AlignerRef(out).load_state(init)
     E = len(ref.edges)
-    ref.run(niter=1)                       # untimed: first-touch page faults of the autograd buffers
+    ref.run(niter=warm, total=300)
     t = time.time()
-    ref.run(niter=1)
+    ref.run(niter=timed, total=300, start=warm)
     dt = time.time() - t
-    scaled = dt * n_edges_full / E
-    return dict(value=1.0 / scaled, unit='iters/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'1 timed iteration (after 1 untimed) of a {n_views}-view / {E}-edge 512x384 sub-scene: {dt:.2f} s; scaled by {n_edges_full}/{E} '
-                       f'edges to the 20-view / {n_edges_full}-edge workload = {scaled:.2f} s/iter')
+    return dict(value=timed / dt, unit='iters/s', cores=torch.get_num_threads(), cpu_model=_cpu_model(), kind='port',
+                sample=f'{timed} timed iterations (after {warm} untimed) of the same {ref.n_imgs}-view / {E}-edge 512x384 scene and initial state as the GPU leg: '
+                       f'{dt:.1f} s = {dt / timed:.3f} s/iter; 300 iterations extrapolate to {300 * dt / timed:.0f} s')
 
 
 def main():
@@ -205,11 +223,12 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--pairs', type=int, default=32, help='image pairs per GPU per step (configs[1]: 32)')
-    ap.add_argument('--precision', default=os.environ.get('DUST3R_AMD_PRECISION', 'bf16'))
+    ap.add_argument('--precision', default=os.environ.get('DUST3R_AMD_PRECISION', 'fp16x3'),
+                    help='engine precision of the HEADLINE: fp16x3 (default) is the mode that meets the 1e-3 pointmap bar; bf16 / fp16 are reported under fast_mode')
     ap.add_argument('--no-aligner', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
-    ap.add_argument('--no-accurate', action='store_true', help='skip the fp16x3 (parity-grade precision mode) throughput line')
+    ap.add_argument('--no-fast', '--no-accurate', dest='no_fast', action='store_true', help='skip the fast_mode block (bf16 / fp16 single-pass throughput + their measured error)')
     ap.add_argument('--single-stream', action='store_true', help='keep decoder side 2 / head 2 on the main stream (serialised kernels: use under rocprofv3 so that per-kernel durations are not inflated by overlap)')
     args = ap.parse_args()
 
@@ -317,12 +336,17 @@ def main():
             dom = max(prof['gemm_cfg'], key=lambda c: prof['gemm_cfg'][c]['ms'])
             d = prof['gemm_cfg'][dom]
             total_ms = prof['linear']['ms'] + prof['conv']['ms'] + prof['attention']['ms'] + prof['other']['ms']
-            ach = d['gflop'] / d['ms']                              # GFLOP / ms == TFLOP/s
+            ach = d['gflop'] / d['ms']                              # GFLOP / ms == TFLOP/s (algorithmic: 2 M N K per launch)
+            mfma_per_product = 3 if args.precision == 'fp16x3' else 1   # split-fp16: three f16 MFMAs per logical product
             result['roofline'] = {
                 'bound': 'mfma', 'kernel': f'd3r::gemm_kernel<{args.precision}, {GEMM_CFG_NAMES.get(dom, dom)}>',
                 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                'traffic': pmc_traffic_gb(dom), 'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
+                'achieved_executed_mfma': ach * mfma_per_product, 'frac_executed_mfma': ach * mfma_per_product / PEAK_BF16_TFLOPS,
+                'mfma_per_product': mfma_per_product,
+                'traffic': pmc_traffic_gb(dom, args.precision), 'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
                 'gflop_per_launch': d['gflop'] / d['launches'], 'share_of_step_time': d['ms'] / total_ms,
+                'note': 'achieved / frac = ALGORITHMIC flops (2 M N K per launch, SURVEY 8(d)) over the live HIP-event launch time, against the dense '
+                        '16-bit MFMA peak; achieved_executed_mfma counts the MFMA work the mode actually issues (fp16x3: 3 f16 MFMAs per product)',
                 'timing': 'HIP events around every launch on the launch stream, single-stream schedule, one extra forward after the timed region'}
             kern = {f'gemm_kernel cfg{c}': dict(v, tflops=v['gflop'] / v['ms']) for c, v in prof['gemm_cfg'].items()}
             for k in ('attention', 'other'):
@@ -334,28 +358,41 @@ def main():
             result['launch_table'] = table[:24]
             log('[bench] per-kernel: ' + ', '.join(f"{k} {v['ms']:.1f} ms / {v['launches']} launches / {v['tflops']:.0f} TF/s" for k, v in kern.items()))
 
-    # ---- the precision mode that meets the north-star parity bar (1e-3 on pointmaps), same workload ----------------------
-    if rank == 0 and world == 1 and not args.no_accurate and args.precision != 'fp16x3':
+    # ---- fast modes (single-pass 16-bit operands): NOT parity-grade, reported with their measured error ------------------
+    # Error = per-pixel relative pointmap difference against the headline (parity-grade) engine on the same weights and the
+    # same first two pairs of the batch; the headline mode itself is held to 1e-3 against the CPU oracle by tests/test_forward_gpu.py.
+    if rank == 0 and world == 1 and not args.no_fast:
+        fast = {}
         try:
-            model.set_precision('fp16x3')
-            if args.single_stream:
-                model.set_two_streams(False)
-            for _ in range(2):
-                model(v1, v2)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            nacc = 3
-            for _ in range(nacc):
-                model(v1, v2)
-            torch.cuda.synchronize()
-            dta = (time.perf_counter() - t1) / nacc
-            result['accurate_mode'] = {'dtype': 'fp16x3', 'value': B / dta, 'unit': 'pairs/s', 'ms_per_step': dta * 1e3,
-                                       'note': 'split-fp16 operands (hi + lo), three f16 MFMAs per product: the mode held to <= 1e-3 relative pointmap error '
-                                               'against the CPU oracle (tests/test_forward_gpu.py); algorithmic TFLOP/s = ' + f'{B / dta * GFLOP_PER_PAIR / 1e3:.0f}'}
-            log(f"[bench] fp16x3 (parity-grade) {B / dta:.2f} pairs/s")
+            sub = lambda v, n: {k: (x[:n] if isinstance(x, torch.Tensor) else x[:n]) for k, x in v.items()}   # noqa: E731
+            w1, w2 = sub(v1, 2), sub(v2, 2)
+            r1, r2 = model(w1, w2)
+            ref = torch.cat((r1['pts3d'], r2['pts3d_in_other_view'])).clone()
+            for prec in [p for p in ('bf16', 'fp16') if p != args.precision]:
+                model.set_precision(prec)
+                if args.single_stream:
+                    model.set_two_streams(False)
+                e1, e2 = model(w1, w2)
+                got = torch.cat((e1['pts3d'], e2['pts3d_in_other_view']))
+                rel = ((got - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-12)).flatten()
+                for _ in range(2):
+                    model(v1, v2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                nrep = 5
+                for _ in range(nrep):
+                    model(v1, v2)
+                torch.cuda.synchronize()
+                dtf = (time.perf_counter() - t1) / nrep
+                fast[prec] = {'value': B / dtf, 'unit': 'pairs/s', 'ms_per_step': dtf * 1e3,
+                              'frac_of_bf16_mfma_peak': B / dtf * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS,
+                              'rel_pointmap_err_vs_headline': {'max': float(rel.max()), 'p99': float(rel.kthvalue(int(0.99 * rel.numel())).values), 'mean': float(rel.mean())},
+                              'parity': 'NOT within the 1e-3 bar'}
+                log(f"[bench] fast mode {prec}: {B / dtf:.1f} pairs/s, rel err max {float(rel.max()):.2e} mean {float(rel.mean()):.2e}")
             model.set_precision(args.precision)
         except Exception as e:
-            result['accurate_mode'] = {'error': repr(e)}
+            fast['error'] = repr(e)
+        result['fast_mode'] = fast
 
     if world > 1:
         dist.barrier()
@@ -374,9 +411,7 @@ def main():
                 result['cpu_baseline'] = cpu_baseline_forward()
                 result['cpu_baseline']['gpu_over_cpu'] = result['value'] / result['cpu_baseline']['value']
                 if scene_io is not None:
-                    n_edges_full = result['aligner']['n_edges']
-                    del scene_io
-                    cb = cpu_baseline_aligner(device, n_edges_full)
+                    cb = cpu_baseline_aligner(scene_io)
                     cb['gpu_over_cpu'] = result['aligner']['value'] / cb['value']
                     result['aligner']['cpu_baseline'] = cb
             except Exception as e:

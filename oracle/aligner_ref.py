@@ -130,12 +130,18 @@ class AlignerRef:
         return (di * self.weight_i).sum() / self.total_area_i + (dj * self.weight_j).sum() / self.total_area_j
 
     # ------------------------------------------------------------------ loop
-    def run(self, niter=300, lr=0.01, schedule='cosine', lr_min=1e-6, callback=None):
+    def run(self, niter=300, lr=0.01, schedule='cosine', lr_min=1e-6, callback=None, total=None, start=0):
+        """`niter` Adam iterations. By default one whole schedule (the reference's global_alignment_loop, base_opt.py:326-366);
+        `total` / `start` run iterations [start, start + niter) of a `total`-iteration schedule, keeping the Adam moments of the
+        previous call when start > 0 (a long run cut into pieces gives the same trajectory as one call)."""
+        total = niter if total is None else total
         params = [v for v in self.params.values() if v.requires_grad]
-        opt = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.9))
+        if start == 0 or getattr(self, '_opt', None) is None:
+            self._opt = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.9))
+        opt = self._opt
         losses = []
-        for n in range(niter):
-            t = n / niter
+        for n in range(start, start + niter):
+            t = n / total
             cur = cosine_schedule(t, lr, lr_min) if schedule == 'cosine' else linear_schedule(t, lr, lr_min)
             for grp in opt.param_groups:
                 grp['lr'] = cur

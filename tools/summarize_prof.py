@@ -101,19 +101,29 @@ fetch, write = pmc_means('pmc_fetch', 'FETCH_SIZE'), pmc_means('pmc_write', 'WRI
 digest = {'note': 'per-launch means from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --single-stream`; counters in KiB; '
                   'hbm_gb_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / 1e9 (FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950, '
                   'MI355X_MICROARCH.md section HBM; WRITE_SIZE uncalibrated)', 'gemm_cfg': {}}
-for name in set(fetch) | set(write):
+DT_NAMES = {0: 'bf16', 1: 'fp16', 2: 'fp32', 3: 'fp16x3'}
+names = set(fetch) | set(write)
+# the precision mode of the run = the element type of the most-dispatched gemm_kernel instantiation
+dt_count = defaultdict(int)
+for name in names:
+    mm = re.search(r'gemm_kernel<(\d), d3r::GemmCfg<', name)
+    if mm:
+        dt_count[int(mm.group(1))] += fetch.get(name, write.get(name))[0]
+run_dt = max(dt_count, key=dt_count.get) if dt_count else 0
+digest['precision'] = DT_NAMES.get(run_dt, str(run_dt))
+for name in names:
     fk = fetch.get(name, (0, 0.0))[1]
     wk = write.get(name, (0, 0.0))[1]
     entry = dict(kernel=name[:120], dispatches=fetch.get(name, write.get(name))[0], fetch_size_kib=fk, write_size_kib=wk,
                  hbm_gb_per_launch=(2 * fk + wk) * 1024 / 1e9)
-    mm = re.search(r'gemm_kernel<0, d3r::GemmCfg<([0-9, ]+)>', name)
+    mm = re.search(r'gemm_kernel<(\d), d3r::GemmCfg<([0-9, ]+)>', name)
     if mm:
-        cfg = CFG_OF.get(tuple(int(x) for x in mm.group(1).split(',')))
-        if cfg is not None:
+        cfg = CFG_OF.get(tuple(int(x) for x in mm.group(2).split(',')))
+        if cfg is not None and int(mm.group(1)) == run_dt:
             digest['gemm_cfg'][str(cfg)] = entry
     elif 'aligner_main_kernel' in name:
         digest['aligner_main_kernel'] = entry
-    elif 'attention_kernel<0>' in name:
+    elif f'attention_kernel<{run_dt}>' in name:
         digest['attention_kernel'] = entry
 if fetch or write:
     with open(os.path.join(out, 'pmc_latest.json'), 'w') as f:
