@@ -95,6 +95,12 @@ template <> struct Traits<D3R_F16X3> {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(a), h8(bl), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(a), h8(b), acc, 0, 0, 0);
     }
+    // one of the three terms of mma16x3 (same order: 0 = lo*hi, 1 = hi*lo, 2 = hi*hi), for loops that interleave accumulators
+    D3R_DEV static void mma16_term(int term, f32x4_t& acc, const uint4& a, const uint4& al, const uint4& b, const uint4& bl) {
+        if (term == 0) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(al), h8(b), acc, 0, 0, 0);
+        else if (term == 1) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(a), h8(bl), acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(a), h8(b), acc, 0, 0, 0);
+    }
     D3R_DEV static void mma32x3(f32x16_t& acc, const uint4& a, const uint4& al, const uint4& b, const uint4& bl) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al), h8(b), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a), h8(bl), acc, 0, 0, 0);

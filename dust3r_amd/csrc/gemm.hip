@@ -56,6 +56,11 @@ typedef GemmCfg<1, 8, 8, 4, 2> Cfg512x128;  // M 512 x N 128, 512 threads, 160 K
 typedef GemmCfg<2, 4, 8, 4, 2, 64, 4> Cfg256s4;   // 256 x 256, 8 waves, 64-byte K rows, FOUR LDS stages (128 KiB): three K steps of DMA in flight
 typedef GemmCfg<2, 4, 8, 4, 2, 64, 4, 1> Cfg256pp;   // 256 x 256, 64-byte K rows, 4-stage ring, PING-PONG schedule: waves 0-3 and 4-7 (one of each per
                                                      // SIMD) run half a phase apart, so one group's 16-MFMA burst covers the other's ds_reads + DMA issue
+// split-fp16 (x3) software-pipelined K loop (PP = 2): same tiles, barrier moved into the tail of the MFMA stream (see the K loop)
+typedef GemmCfg<2, 4, 8, 4, 2, 128, 2, 2> Cfg256sw;
+typedef GemmCfg<2, 4, 4, 4, 2, 128, 2, 2> Cfg256x128sw;
+typedef GemmCfg<2, 2, 4, 4, 2, 128, 2, 2> Cfg128sw;
+typedef GemmCfg<1, 8, 8, 4, 2, 128, 2, 2> Cfg512x128sw;
 typedef GemmCfg<1, 4, 8, 4, 2, 64, 3> Cfg256x128w4;  // M 256 x N 128, 4 waves of 128 (n) x 64 (m), 64-byte K rows: 48 KiB LDS, TWO
                                                   // blocks per CU, three stages (72 KiB)
 
@@ -196,7 +201,106 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     // kt+NSTAGE-1 into that freed stage -> math on step kt. NSTAGE-1 steps of HBM/L2 latency are covered.
     constexpr int NS = CF::NSTAGE, LPS = CF::LPS;
     const int nk = p.K / KT;
-    if constexpr (CF::PP) {
+    if constexpr (CF::PP == 2) {
+        // ---- split-fp16, software pipelined (2 stages, ONE barrier per K step, no bubble at the step boundary) ---------------
+        // The plain loop below opens every K step with [vmcnt(0) | s_barrier | 8 DMA issues | first ds_reads] during which none of
+        // the CU's 8 waves has an MFMA to issue: ~25 % of the step at 96 MFMAs per wave. Here the barrier of step kt sits in
+        // front of the LAST `TAIL` fragment rows of step kt (every ds_read of stage kt & 1 has been issued and waited for by
+        // then, so the stage is dead), and behind it, interleaved with those TAIL x FJ x 3 MFMAs: the DMA of step kt + 2 into
+        // the stage just freed, and the ds_reads of step kt + 1's q fragments and first p fragment (published by the same
+        // barrier: every wave waited for ITS DMA pieces of step kt + 1, issued a whole step earlier, before arriving). The next
+        // step's MFMAs then start from registers. Hazards: RAW on stage (kt+1)&1 = vmcnt(0) + barrier; WAR on stage kt&1 =
+        // lgkmcnt(0) + the same barrier.
+        static_assert(DT == D3R_F16X3 && KTB == 128 && NS == 2, "software-pipelined loop: split-fp16 rows, two stages");
+        constexpr int TAIL = 2, NSLOT = TAIL * FJ;
+        const int chi = ((2 * fgrp) ^ fsw) * 16, clo = ((2 * fgrp + 1) ^ fsw) * 16;
+        int cky = 0, ckx = 0, cc0 = 0;           // implicit-GEMM operand: filter tap / first channel of the K step being staged
+        auto conv_step = [&](int kt) __attribute__((always_inline)) {
+            if (p.amode != AMODE_LINEAR) {
+                const int kel = kt * KT;
+                const int tap = kel / p.Cin;
+                cc0 = kel - tap * p.Cin;
+                cky = tap / p.ksize;
+                ckx = tap - cky * p.ksize;
+            }
+        };
+        auto dma_piece = [&](int idx, int kt, int buf) __attribute__((always_inline)) {   // idx: compile-time constant after unrolling
+            const uint32_t sb = lds0 + buf * STAGE_BYTES;
+            const size_t koff = (size_t)kt * KTB;
+            if (idx < CF::APASS) {
+                const int q = idx;
+                if (p.amode == AMODE_LINEAR) {
+                    glds16(reinterpret_cast<const char*>((size_t)arow[q]) + koff, sb + q * (CF::NW * 1024));
+                } else {
+                    const int pk = (int)(arow[q] >> 32), ibase = (int)(unsigned)arow[q];
+                    const int iy = (pk >> 16) + cky, ix = (int)(short)(pk & 0xFFFF) + ckx;
+                    const bool ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+                    const char* src = reinterpret_cast<const char*>(p.act) + ((size_t)(ibase + iy * p.Win + ix) * p.cstride + cc0) * EB + lchunk * 16;
+                    glds16(ok ? src : zsrc, sb + q * (CF::NW * 1024));
+                }
+            } else {
+                const int q = idx - CF::APASS;
+                glds16(wsrc[q] + koff, sb + BM * KTB + q * (CF::NW * 1024));
+            }
+        };
+        auto frag = [&](const char* sbase, int off, int row, int coff) __attribute__((always_inline)) {
+            return *reinterpret_cast<const uint4*>(sbase + off + row * KTB + coff);
+        };
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        d3r_wait_vm0();
+        __syncthreads();
+        uint4 qh[FJ], ql[FJ], p0h, p0l;
+#pragma unroll
+        for (int f = 0; f < FJ; ++f) { qh[f] = frag(smem, q_off, q_row0 + f * 16, chi); ql[f] = frag(smem, q_off, q_row0 + f * 16, clo); }
+        p0h = frag(smem, p_off, p_row0, chi);
+        p0l = frag(smem, p_off, p_row0, clo);
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sb = smem + (kt & 1) * STAGE_BYTES;
+            const char* sn = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            uint4 ch = p0h, cl = p0l;
+#pragma unroll
+            for (int fi = 0; fi < FI - TAIL; ++fi) {
+                const uint4 nh = frag(sb, p_off, p_row0 + (fi + 1) * 16, chi), nl = frag(sb, p_off, p_row0 + (fi + 1) * 16, clo);
+#pragma unroll
+                for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], ch, cl, qh[fj], ql[fj]);
+                ch = nh; cl = nl;
+            }
+            uint4 th[TAIL], tl[TAIL];
+            th[0] = ch; tl[0] = cl;
+#pragma unroll
+            for (int t = 1; t < TAIL; ++t) { th[t] = frag(sb, p_off, p_row0 + (FI - TAIL + t) * 16, chi); tl[t] = frag(sb, p_off, p_row0 + (FI - TAIL + t) * 16, clo); }
+            const bool more2 = kt + 2 < nk;
+            if (more2) conv_step(kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // next step's q fragments + first p fragment (stale but in-bounds bytes after the last step: never used)
+            uint4 nqh[FJ], nql[FJ];
+#pragma unroll
+            for (int f = 0; f < FJ; ++f) { nqh[f] = frag(sn, q_off, q_row0 + f * 16, chi); nql[f] = frag(sn, q_off, q_row0 + f * 16, clo); }
+            const uint4 np0h = frag(sn, p_off, p_row0, chi), np0l = frag(sn, p_off, p_row0, clo);
+            __builtin_amdgcn_sched_barrier(0);
+            // tail: term-major over the TAIL x FJ accumulators (dependent MFMAs NSLOT apart), one DMA piece per 3 MFMAs
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+#pragma unroll
+                for (int u = 0; u < NSLOT; ++u) {
+                    const int t = u / FJ, fj = u % FJ, mf = term * NSLOT + u;
+                    if (mf % 3 == 0 && more2) {
+#pragma unroll
+                        for (int pc = 0; pc < LPS; ++pc)
+                            if (pc * NSLOT / LPS == mf / 3) dma_piece(pc, kt + 2, kt & 1);
+                    }
+                    TR::mma16_term(term, acc[FI - TAIL + t][fj], th[t], tl[t], qh[fj], ql[fj]);
+                    if (mf % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < FJ; ++f) { qh[f] = nqh[f]; ql[f] = nql[f]; }
+            p0h = np0h; p0l = np0l;
+        }
+    } else if constexpr (CF::PP) {
         // ---- ping-pong schedule (non-swapped 16-bit / fp32 operands; KTB = 64: one MFMA k-step per K step) -----------------
         // A K step is two phases, each [L: issue half of the DMA of step kt+2, ds_read this phase's fragments] | s_barrier |
         // [C: 16 MFMAs] | s_barrier. Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in C while its
@@ -341,7 +445,13 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     const bool wide16 = DT16 && !(p.flags & GF_NOWIDE) &&
                         (((p.epi == EPI_GELU || (p.epi == EPI_T && !p.res1 && !p.res2 && !p.out2)) && (p.ldo & 7) == 0) || heads_wide);
     const bool wide32 = p.epi == EPI_F32 && !(p.flags & GF_NOWIDE);
-    if (wide16 || wide32) {
+    // split-fp16 outputs: the same [64 rows j][32 columns i] staging tile as the fp32 epilogue (a 32-column piece of an x3 row
+    // is 128 bytes: 4 groups [hi x8][lo x8]), written in the final byte layout so that the read phase stores whole lines
+    constexpr bool DTX3 = (DT == D3R_F16X3);
+    const bool widex3 = DTX3 && !(p.flags & GF_NOWIDE) &&
+                        (((p.epi == EPI_GELU || (p.epi == EPI_T && !p.res1 && !p.res2 && !p.out2)) && (p.ldo & 7) == 0) ||
+                         (p.epi == EPI_HEADS && (p.ntok & 31) == 0 && (p.ldv & 7) == 0));
+    if (wide16 || wide32 || widex3) {
         __syncthreads();   // every wave is done with the K loop's LDS stages
         char* wreg = smem + wave * (64 * WROW);
         // P side (i, 4 consecutive per lane) base / Q side (j) base in global coordinates
@@ -464,6 +574,105 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                             char* o = reinterpret_cast<char*>(p.out) + ((size_t)j * p.ldo + i) * 2;
                             if (i + 8 <= p.n_store) store16(o, v, nt);
                             else *reinterpret_cast<uint2*>(o) = make_uint2(v.x, v.y);   // n_store % 4 == 0
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                }
+                return;
+            }
+        }
+        if constexpr (DTX3) {
+            if (widex3) {
+                using TX = Traits<D3R_F16X3>;
+                const bool bias_i = !swap && p.bias != nullptr, bias_j = swap && p.bias != nullptr;
+                const float* bsrc = p.bias ? p.bias : reinterpret_cast<const float*>(p.wgt);
+                const bool heads = p.epi == EPI_HEADS;
+                const bool has_tab = heads && p.rope_table != nullptr;
+                const float* rtab = has_tab ? p.rope_table : reinterpret_cast<const float*>(p.wgt);
+                const int r_ntok = has_tab ? p.ntok : 1, r_tokw = has_tab ? p.tok_w : 1, r_M = has_tab ? p.M : 1;
+                float bjv[FJ];     // per-row bias of the operand-swapped (V^T) tiles
+#pragma unroll
+                for (int fj = 0; fj < FJ; ++fj) bjv[fj] = bsrc[max(min(jb + fj * 16 + jl, p.n_store - 1), 0)];
+#pragma unroll
+                for (int g = 0; g < FI / 2; ++g) {
+                    const int ig = ib + g * 32;                 // first i (column n, or token m when swapped) of this 32-wide group
+                    int h = 0;
+                    bool rope = false;
+                    char* hdst = nullptr;
+                    if (heads) {
+                        const int nh = __builtin_amdgcn_readfirstlane(swap ? jb : ig);   // n of this (wave, group): inside one 64-wide head
+                        const int region = nh / p.head_c;
+                        h = (nh - region * p.head_c) >> 6;
+                        rope = !swap && head_kind_of(p, region) == HEAD_ROPE;
+                        hdst = reinterpret_cast<char*>(head_dst_of(p, region));
+                    }
+                    const int xhalf = (ig >> 5) & 1;            // RoPE: columns 0-31 of a head rotate with the y position, 32-63 with x
+                    float4 bq[2];
+#pragma unroll
+                    for (int fl = 0; fl < 2; ++fl) {
+                        const float4 t = *reinterpret_cast<const float4*>(bsrc + max(min(ig + fl * 16 + i4, p.n_store - 4), 0));
+                        bq[fl] = make_float4(bias_i ? t.x : 0.f, bias_i ? t.y : 0.f, bias_i ? t.z : 0.f, bias_i ? t.w : 0.f);
+                    }
+                    float4 rt[2][4];   // RoPE table rows, double buffered across fragments
+                    load_rope_rows(rtab, r_ntok, r_tokw, r_M, jb + jl, i4, rt[0]);
+#pragma unroll
+                    for (int fj = 0; fj < FJ; ++fj) {
+                        const float bj = bias_j ? bjv[fj] : 0.f;
+                        if (fj + 1 < FJ) load_rope_rows(rtab, r_ntok, r_tokw, r_M, jb + (fj + 1) * 16 + jl, i4, rt[(fj + 1) & 1]);
+                        const float4 a0 = xhalf ? rt[fj & 1][2] : rt[fj & 1][0], a1 = xhalf ? rt[fj & 1][3] : rt[fj & 1][1];
+                        const float cc[4] = {a0.x, a0.z, a1.x, a1.z}, ss[4] = {a0.y, a0.w, a1.y, a1.w};
+                        float vals[2][4];
+#pragma unroll
+                        for (int fl = 0; fl < 2; ++fl) {
+                            const float4 bi = swap ? make_float4(bj, bj, bj, bj) : bq[fl];
+                            const f32x4_t a = acc[g * 2 + fl][fj];
+                            vals[fl][0] = a[0] + bi.x; vals[fl][1] = a[1] + bi.y; vals[fl][2] = a[2] + bi.z; vals[fl][3] = a[3] + bi.w;
+                        }
+                        if (rope) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float u = vals[0][r], v = vals[1][r];
+                                vals[0][r] = u * cc[r] - v * ss[r];
+                                vals[1][r] = v * cc[r] + u * ss[r];
+                            }
+                        }
+#pragma unroll
+                        for (int fl = 0; fl < 2; ++fl) {
+                            float v0 = vals[fl][0], v1 = vals[fl][1], v2 = vals[fl][2], v3 = vals[fl][3];
+                            if (p.epi == EPI_GELU) { v0 = gelu<DT>(v0); v1 = gelu<DT>(v1); v2 = gelu<DT>(v2); v3 = gelu<DT>(v3); }
+                            if (p.flags & GF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                            uint2 hh, ll;
+                            TX::split2(v0, v1, hh.x, ll.x);
+                            TX::split2(v2, v3, hh.y, ll.y);
+                            const int c0 = fl * 16 + i4;       // 4 consecutive logical columns inside one 8-group
+                            char* w = wreg + (fj * 16 + jl) * WROW + (c0 >> 3) * 32 + (c0 & 7) * 2;
+                            *reinterpret_cast<uint2*>(w) = hh;
+                            *reinterpret_cast<uint2*>(w + 16) = ll;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // ---- LDS -> global: 8 lanes x 16 B = the 128 bytes of 32 consecutive logical i of row j
+#pragma unroll
+                    for (int pass = 0; pass < 8; ++pass) {
+                        const int row = pass * 8 + rrow;
+                        const uint4 v = *reinterpret_cast<const uint4*>(wreg + row * WROW + rch * 16);
+                        const int j = jb + row;
+                        const int i8 = ig + (rch >> 1) * 8;    // first logical i of this 16-byte chunk (hi or lo half of an 8-group)
+                        if (heads) {
+                            if (!swap) {                        // q / k: [b][h][token][64]
+                                if (j < p.M) {
+                                    const int b = j / p.ntok, t = j - b * p.ntok;
+                                    store16(hdst + (((size_t)(b * p.heads + h) * p.ntok + t) * 64 + xhalf * 32) * 4 + rch * 16, v, nt);
+                                }
+                            } else if (i8 < p.M && j < p.n_store) {   // v^T: [b][h][feature][ldv], 8 consecutive tokens per chunk
+                                const int b = i8 / p.ntok, t = i8 - b * p.ntok;
+                                const int dd = j & 63;
+                                store16(hdst + (((size_t)(b * p.heads + h) * 64 + dd) * p.ldv + t) * 4 + (rch & 1) * 16, v, nt);
+                            }
+                        } else if (j < p.M && i8 < p.n_store) {
+                            char* o = reinterpret_cast<char*>(p.out) + ((size_t)j * p.ldo + i8) * 4 + (rch & 1) * 16;
+                            if (i8 + 8 <= p.n_store) store16(o, v, nt);
+                            else *reinterpret_cast<uint2*>(o) = make_uint2(v.x, v.y);   // n_store % 8 == 4: the group's first 4 elements
                         }
                     }
                     asm volatile("" ::: "memory");
@@ -718,6 +927,19 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
         if (cfg == GEMM_CFG_256x128W4) return launch_cfg<DT, Cfg256x128w4>(p, s);
         if (cfg == GEMM_CFG_256S4) return launch_cfg<DT, Cfg256s4>(p, s);
         if (cfg == GEMM_CFG_256PP) return launch_cfg<DT, Cfg256pp>(p, s);
+    }
+    if constexpr (DT == D3R_F16X3) {
+        // split-fp16: software-pipelined K loop by default (D3R_GEMM_X3SW=0: the plain two-stage loop, for A/B runs and parity tests)
+        const char* e_sw = getenv("D3R_GEMM_X3SW");
+        const bool sw = e_sw ? e_sw[0] != '0' : true;
+        if (sw) {
+            switch (cfg) {
+                case GEMM_CFG_256: return launch_cfg<DT, Cfg256sw>(p, s);
+                case GEMM_CFG_256x128: return launch_cfg<DT, Cfg256x128sw>(p, s);
+                case GEMM_CFG_512x128: return launch_cfg<DT, Cfg512x128sw>(p, s);
+                default: return launch_cfg<DT, Cfg128sw>(p, s);
+            }
+        }
     }
     switch (cfg) {
         case GEMM_CFG_256: return launch_cfg<DT, Cfg256>(p, s);

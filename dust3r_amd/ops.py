@@ -55,6 +55,38 @@ def linear(act, weight, bias=None, epilogue='store', residual=None):
     return out
 
 
+def pack_x3(x):
+    """fp32 (..., K) with K % 8 == 0 -> the engine's split-fp16 row layout, an fp16 tensor (..., 2K): per 8 logical elements
+    a 32-byte group [hi x8][lo x8], hi = fp16(x), lo = fp16(x - hi) (csrc/common.hpp, Traits<D3R_F16X3>)."""
+    x = x.float()
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    sh = x.shape
+    g = torch.stack((hi.reshape(*sh[:-1], sh[-1] // 8, 8), lo.reshape(*sh[:-1], sh[-1] // 8, 8)), dim=-2)
+    return g.reshape(*sh[:-1], sh[-1] * 2).contiguous()
+
+
+def unpack_x3(t):
+    """Inverse of pack_x3: fp16 (..., 2K) -> fp32 (..., K) = hi + lo."""
+    sh = t.shape
+    g = t.reshape(*sh[:-1], sh[-1] // 16, 2, 8).float()
+    return (g[..., 0, :] + g[..., 1, :]).reshape(*sh[:-1], sh[-1] // 2)
+
+
+def linear_x3(act, weight, bias=None, epilogue='store', residual=None):
+    """`linear` in the split-fp16 precision mode: act (M,K), weight (N,K) fp32 (N, K multiples of 8) are packed to the
+    x3 layout, the result comes back as fp32 (unpacked for the 'store' / 'gelu' epilogues)."""
+    _lib.require_device()
+    M, K = act.shape
+    N = weight.shape[0]
+    ap, wp = pack_x3(act), pad_rows(pack_x3(weight))
+    bp = None if bias is None else pad_rows(bias.float())
+    epi = {'store': 0, 'f32': 1, 'gelu': 2}[epilogue]
+    out = torch.empty((M, N), dtype=torch.float32, device=act.device) if epi == 1 else torch.empty((M, 2 * N), dtype=torch.float16, device=act.device)
+    check(lib.d3r_linear(ptr(ap), ptr(wp), ptr(bp), ptr(out), ptr(residual), M, N, K, epi, _lib.DTYPE_F16X3, current_stream()), 'linear(x3)')
+    return out if epi == 1 else unpack_x3(out)
+
+
 def pack_conv_weight(w):
     """torch (Cout, Cin, kh, kw) -> (round_up(Cout,256), kh*kw*Cin) with K index (ky, kx, cin)."""
     return pad_rows(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))

@@ -90,6 +90,76 @@ def aligner_golden(n_views, H, W, seed, niter):
                 state={k: v.detach().clone() for k, v in scene.state_dict(trainable=True).items() if not k.startswith('im_conf')})
 
 
+def aligner_c4_golden(n_views=20, H=384, W=512, seed=0, niter=300):
+    """BASELINE configs[3] at full size (20 views, 190 edges, 384x512, the scene bench.py times): the unmodified reference
+    optimizer in fp32 (what a user of the reference gets), and the restated oracle in fp64 (the arbiter) and fp32, same inputs,
+    same initial state, 300 cosine iterations. Recorded: every iteration's loss and, at the checkpoint iterations, cam2world
+    (n,4,4) and focals after that iteration's Adam step. The fixture lets the GPU test report engine-vs-fp64 next to
+    reference-fp32-vs-fp64 (the reference's own reproducibility floor) without running 300 CPU iterations on the GPU box."""
+    import time
+    from oracle.aligner_ref import AlignerRef
+    out, init, gt = synthetic_scene(n_views, H, W, seed=seed, symmetrize=False)
+    ckpt = sorted(set(list(range(0, 31)) + list(range(39, niter, 10)) + [niter - 1]))
+    res = dict(kind='aligner_c4', n_views=n_views, H=H, W=W, seed=seed, niter=niter, symmetrize=False, unpinned=UNPINNED, checkpoints=ckpt)
+
+    # ---- the unmodified reference, fp32
+    t0 = time.time()
+    scene = global_aligner(copy.deepcopy(out), 'cpu', mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
+    scene.load_state_dict(scene.state_dict(trainable=True) | init)
+    loss0 = scene()
+    loss0.backward()
+    g = {k: getattr(scene, k).grad.clone() for k in ('pw_poses', 'im_poses', 'im_depthmaps', 'im_focals')}
+    res['ref32_loss0'] = float(loss0)
+    res['ref32_grads'] = dict(pw_poses=g['pw_poses'], im_poses=g['im_poses'], im_focals=g['im_focals'],
+                              im_depthmaps_sub=g['im_depthmaps'][:, ::997].clone())     # every 997th pixel of every view
+    for p_ in scene.parameters():
+        p_.grad = None
+    import dust3r.cloud_opt.base_opt as bo
+    losses, poses, focals = [], {}, {}
+    orig = bo.global_alignment_iter
+
+    def spy(*a, **k):
+        l, lr = orig(*a, **k)
+        n = len(losses)
+        losses.append(l)
+        if n in ckpt:
+            poses[n] = scene.get_im_poses().detach().clone()
+            focals[n] = scene.get_focals().detach().flatten().clone()
+        return l, lr
+    bo.global_alignment_iter = spy
+    final = scene.compute_global_alignment(init=None, niter=niter, schedule='cosine', lr=0.01)
+    bo.global_alignment_iter = orig
+    res.update(ref32_losses=torch.tensor(losses, dtype=torch.float64), ref32_final_loss=float(final),
+               ref32_poses=torch.stack([poses[n] for n in ckpt]), ref32_focals=torch.stack([focals[n] for n in ckpt]),
+               ref32_pw_poses=scene.get_pw_poses().detach().clone())
+    print(f'  reference fp32: {time.time() - t0:.0f} s, final loss {float(final):.6f}', flush=True)
+    del scene
+
+    # ---- restated oracle, fp64 (arbiter) and fp32
+    for tag, dt in (('or64', torch.float64), ('or32', torch.float32)):
+        t0 = time.time()
+        ref = AlignerRef(out, dtype=dt).load_state(init)
+        if tag == 'or64':
+            l0, g = ref.grads()
+            res['or64_loss0'] = l0
+            res['or64_grads'] = dict(pw_poses=g['pw_poses'], im_poses=g['im_poses'], im_focals=g['im_focals'],
+                                     im_depthmaps_sub=g['im_depthmaps'][:, ::997].clone())
+        poses, focals = {}, {}
+
+        def cb(n, r):
+            if n in ckpt:
+                with torch.no_grad():
+                    poses[n] = r.im_poses().clone()
+                    focals[n] = r.focals().flatten().clone()
+        losses = ref.run(niter=niter, lr=0.01, schedule='cosine', callback=cb)
+        res.update({f'{tag}_losses': torch.tensor(losses, dtype=torch.float64),
+                    f'{tag}_poses': torch.stack([poses[n] for n in ckpt]), f'{tag}_focals': torch.stack([focals[n] for n in ckpt])})
+        print(f'  oracle {tag}: {time.time() - t0:.0f} s, final loss {losses[-1]:.6f}', flush=True)
+    d32 = (res['ref32_poses'].double() - res['or64_poses']).abs().flatten(1).max(dim=1).values
+    print('  reference-fp32 vs oracle-fp64, max |cam2world diff| at checkpoints:', [f'{ckpt[i]}:{float(d32[i]):.1e}' for i in range(0, len(ckpt), 6)])
+    return res
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -98,7 +168,10 @@ if __name__ == '__main__':
         'forward_tiny_linear.pt': lambda: forward_golden('tiny_linear', 3, 32, 32, seed=2),
         'inference_tiny_dpt.pt': lambda: inference_golden('tiny_dpt', 3, 32, 48, seed=3),
         'aligner_4v.pt': lambda: aligner_golden(4, 24, 32, seed=0, niter=300),
+        'aligner_c4.pt': lambda: aligner_c4_golden(),
     }
+    if len(sys.argv) > 1:        # regenerate only the named fixtures (aligner_c4.pt takes ~20 min of CPU)
+        jobs = {k: v for k, v in jobs.items() if k in sys.argv[1:]}
     for name, fn in jobs.items():
         g = fn()
         torch.save(g, os.path.join(OUT, name))

@@ -98,6 +98,30 @@ def test_forward_16bit_with_pinned_gemm_tile(gpu, cfg, monkeypatch):
     compare(eng, oracle, v1, v2, *TOLS['fp16'], tag=f'tiny_dpt fp16 128x128 cfg{cfg}')
 
 
+@pytest.mark.parametrize('cfg', ['0', '1', '2', '3'])
+def test_forward_split_fp16_kernel_variants(gpu, cfg, monkeypatch):
+    """fp16x3 (the default, parity-grade mode) at 128x128 = 64 tokens, where the attention projections take the LDS-staged
+    x3 epilogue (q / k RoPE scatter, operand-swapped V^T): every (software-pipelined | plain K loop) x (wide | direct epilogue)
+    combination within 1e-3 of the oracle, and all of them within 1e-5 of each other (same MFMA order; RoPE / GELU may
+    contract differently between the two epilogue routes)."""
+    from oracle.dust3r_ref import build_ref_model
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg)
+    oracle = build_ref_model('tiny_dpt')
+    eng = engine_from_oracle(oracle, 'tiny_dpt', 'fp16x3', gpu)
+    v1, v2 = synthetic_views(2, 128, 128, seed=6)
+    outs = []
+    for sw in ('1', '0'):
+        for nowide in ('0', '1'):
+            monkeypatch.setenv('D3R_GEMM_X3SW', sw)
+            monkeypatch.setenv('D3R_GEMM_NOWIDE', nowide)
+            compare(eng, oracle, v1, v2, *TOLS['fp16x3'], tag=f'tiny_dpt fp16x3 128x128 cfg{cfg} sw{sw} nowide{nowide}')
+            e1, e2 = eng(v1, v2)
+            outs.append(torch.cat((e1['pts3d'], e2['pts3d_in_other_view'])))
+    for o in outs[1:]:
+        assert pix_rel(o, outs[0].cpu())[0] < 1e-5
+    assert torch.equal(outs[0], outs[2])        # pipelined vs plain K loop, same epilogue route: bit-identical
+
+
 @pytest.mark.parametrize('name', ['forward_tiny_dpt.pt', 'forward_tiny_linear.pt'])
 def test_forward_matches_reference_golden(gpu, name):
     """fp32 engine against vectors produced by the unmodified reference files (oracle/make_golden.py)."""

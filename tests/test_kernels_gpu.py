@@ -51,6 +51,35 @@ def test_linear_epilogues(gpu, dtype, M, N, K):
     assert relerr(out, F.gelu(ref)) < OUT_TOL[dtype], 'gelu epilogue'
 
 
+@pytest.mark.parametrize('sw', ['1', '0'])
+@pytest.mark.parametrize('cfg', ['0', '1', '2', '3'])
+@pytest.mark.parametrize('M,N,K', [(300, 192, 256), (1000, 3072, 1024), (77, 96, 768), (2100, 1032, 32), (515, 328, 64)])
+def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
+    """The parity-grade precision mode (fp16x3: operands split into fp16 hi + lo, three MFMAs per product) at kernel level:
+    every tile configuration, the software-pipelined K loop (default) and the plain two-stage loop, the LDS-staged wide
+    epilogue and the direct stores; K = 32 / 64 are one- and two-step K loops (pipeline prologue / drain only). Reference =
+    fp32 matmul of the SAME fp32 operands: the split keeps 22 significand bits per operand, so the result is fp32-class."""
+    from dust3r_amd import ops
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg)
+    monkeypatch.setenv('D3R_GEMM_X3SW', sw)
+    g = torch.Generator(device='cpu').manual_seed(M * 7 + N)
+    a = torch.randn((M, K), generator=g).to(gpu)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(gpu)
+    b = torch.randn(N, generator=g).to(gpu)
+    res = torch.randn((M, N), generator=g).to(gpu)
+    ref = (a.double() @ w.double().T + b.double()).float()
+    got = {}
+    for wide in ('0', '1'):
+        monkeypatch.setenv('D3R_GEMM_NOWIDE', wide)
+        o_store, o_res, o_gelu = ops.linear_x3(a, w, b, 'store'), ops.linear_x3(a, w, b, 'f32', residual=res), ops.linear_x3(a, w, b, 'gelu')
+        assert relerr(o_store, ref) < 3e-6, 'store epilogue'
+        assert relerr(o_res, ref + res) < 3e-6, 'fp32 + residual epilogue'
+        assert relerr(o_gelu, F.gelu(ref)) < 3e-6, 'gelu epilogue'
+        got[wide] = (o_store, o_res, o_gelu)
+    for x, y in zip(got['0'], got['1']):       # two routes for the same values
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,H,W,Cin,Cout,k,stride,pad', [(2, 12, 16, 128, 256, 3, 1, 1), (1, 24, 32, 256, 128, 3, 2, 1), (3, 6, 8, 256, 96, 1, 1, 0),
                                                        (1, 7, 5, 64, 128, 3, 1, 1), (2, 21, 32, 128, 128, 3, 2, 1)])
