@@ -70,6 +70,17 @@ def _load():
         'd3r_aligner_loss_grad': (i, [vp, fp, fp, fp, fp, fp, vp]),
         'd3r_nearest_neighbors': (i, [fp, i, fp, i, ip, vp]),
         'd3r_clean_pointcloud': (i, [i, fp, fp, fp, fp, fp, ip, ip, i, f, f, vp]),
+        'd3r_row_means': (i, [fp, i, i, i, fp, vp]),
+        'd3r_similarity_moments_workspace': (C.c_size_t, [i, i]),
+        'd3r_similarity_moments': (i, [i, vp, vp, vp, ip, i, vp, vp, vp]),
+        'd3r_weiszfeld_focals': (i, [i, vp, ip, ip, i, fp, vp]),
+        'd3r_anchor_depth': (i, [i, vp, fp, ip, i, i, fp, vp]),
+        'd3r_pnp_job_bytes': (i, []),
+        'd3r_pnp_max_hypotheses': (i, []),
+        'd3r_pnp_sum_count': (i, []),
+        'd3r_pnp_workspace': (C.c_size_t, [i]),
+        'd3r_pnp_score': (i, [i, vp, fp, i, f, ip, vp]),
+        'd3r_pnp_sums': (i, [i, vp, fp, f, i, vp, vp, vp]),
         'd3r_selftest_aligner_math_host': (i, [i, i, ip, ip, i, i, fp, fp, fp, fp, fp, fp, fp, fp, f, f, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['gemm.hip', 'attention.hip', 'elementwise.hip', 'aligner.hip', 'engine.hip', 'capi.hip']
+SOURCES = ['gemm.hip', 'attention.hip', 'elementwise.hip', 'aligner.hip', 'bootstrap.hip', 'engine.hip', 'capi.hip']
 HEADERS = ['common.hpp', 'kernels.hpp', 'aligner_math.hpp', os.path.join('..', '..', 'include', 'dust3r_hip.h')]
 LIB = os.path.join(CSRC, 'libdust3r_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']

@@ -1,5 +1,5 @@
 """Global alignment -- host-side mirror of the reference `dust3r/cloud_opt/base_opt.py`
-(`BasePCOptimizer`, `global_alignment_loop`, `clean_pointcloud`).
+(`BasePCOptimizer`, `global_alignment_loop`).
 
 Same constructor keywords, attributes (`edges, imshapes, imsizes, im_conf, pred_i, pred_j, conf_i,
 conf_j, pw_poses, pw_adaptors, min_conf_thr, conf_trf, is_symmetrized, n_imgs, n_edges,
@@ -18,7 +18,7 @@ import tqdm
 
 from .. import _lib
 from .._lib import check, current_stream, lib, ptr
-from ..utils.geometry import geotrf, inv
+from ..utils.geometry import inv
 from ..utils.rigid import quat_translation_to_homogeneous, rotmat_to_unitquat
 from . import init_im_poses as init_fun
 from .commons import (cosine_schedule, edge_str, get_conf_trf, get_imshapes, linear_schedule, signed_expm1,
@@ -270,12 +270,11 @@ class BasePCOptimizer(nn.Module):
 
     @torch.no_grad()
     def clean_pointcloud(self, **kw):
+        if self.device.type != 'cuda':
+            raise _lib.D3RError('clean_pointcloud runs on the GPU (dust3r_amd has no CPU execution path)')
         cams = inv(self.get_im_poses())
-        if self.device.type == 'cuda' and not kw.get('dbg'):
-            new_confs = clean_pointcloud_hip(self.im_conf, self.get_intrinsics(), cams, self.get_depthmaps(), self.get_pts3d(),
-                                             tol=kw.get('tol', 0.001), bad_conf=kw.get('bad_conf', 0))
-        else:
-            new_confs = clean_pointcloud(self.im_conf, self.get_intrinsics(), cams, self.get_depthmaps(), self.get_pts3d(), **kw)
+        new_confs = clean_pointcloud_hip(self.im_conf, self.get_intrinsics(), cams, self.get_depthmaps(), self.get_pts3d(),
+                                         tol=kw.get('tol', 0.001), bad_conf=kw.get('bad_conf', 0))
         for i, c in enumerate(new_confs):
             self.im_conf[i][:] = c
         return self
@@ -353,8 +352,10 @@ def global_alignment_loop(net, lr=0.01, niter=300, schedule='cosine', lr_min=1e-
 
 @torch.no_grad()
 def clean_pointcloud_hip(im_confs, K, cams, depthmaps, all_pts3d, tol=0.001, bad_conf=0):
-    """Same result as `clean_pointcloud` below (the reference's host loop), computed by d3r_clean_pointcloud: n launches, one
-    thread per pixel walking the other cameras, instead of n (n - 1) rounds of ~15 elementwise torch kernels."""
+    """The reference's `clean_pointcloud` (base_opt.py:369-405: a point of image i that projects IN FRONT of image j's depthmap while
+    being less confident than the pixel it lands on gets its confidence clipped to `bad_conf`; images visited in order, each seeing
+    the already cleaned confidences of the earlier ones), computed by d3r_clean_pointcloud: n launches, one thread per pixel walking
+    the other cameras, instead of n (n - 1) rounds of ~15 elementwise torch kernels."""
     _lib.require_device()
     n = len(im_confs)
     dev = im_confs[0].device
@@ -376,29 +377,3 @@ def clean_pointcloud_hip(im_confs, K, cams, depthmaps, all_pts3d, tol=0.001, bad
         check(lib.d3r_clean_pointcloud(n, ptr(conf), ptr(depth), ptr(pts), ptr(Kc), ptr(w2c), arr([h for h, w in shapes]),
                                        arr([w for h, w in shapes]), maxA, float(tol), float(bad_conf), current_stream()), 'clean_pointcloud')
     return [conf[i, :h * w].view(h, w).to(im_confs[i].dtype) for i, (h, w) in enumerate(shapes)]
-
-
-@torch.no_grad()
-def clean_pointcloud(im_confs, K, cams, depthmaps, all_pts3d, tol=0.001, bad_conf=0, dbg=()):
-    """Mirror of base_opt.py:369-405: a point of image i that projects IN FRONT of image j's depthmap
-    while being less confident than the pixel it lands on gets its confidence clipped to `bad_conf`."""
-    assert len(im_confs) == len(cams) == len(K) == len(depthmaps) == len(all_pts3d)
-    assert 0 <= tol < 1
-    res = [c.clone() for c in im_confs]
-    all_pts3d = [p.view(*c.shape, 3) for p, c in zip(all_pts3d, im_confs)]
-    depthmaps = [d.view(*c.shape) for d, c in zip(depthmaps, im_confs)]
-    for i, pts3d in enumerate(all_pts3d):
-        for j in range(len(all_pts3d)):
-            if i == j:
-                continue
-            proj = geotrf(cams[j], pts3d)
-            proj_depth = proj[:, :, 2]
-            u, v = geotrf(K[j], proj, norm=1, ncol=2).round().long().unbind(-1)
-            H, W = im_confs[j].shape
-            msk_i = (proj_depth > 0) & (0 <= u) & (u < W) & (0 <= v) & (v < H)
-            msk_j = v[msk_i], u[msk_i]
-            bad_points = (proj_depth[msk_i] < (1 - tol) * depthmaps[j][msk_j]) & (res[i][msk_i] < res[j][msk_j])
-            bad_msk_i = msk_i.clone()
-            bad_msk_i[msk_i] = bad_points
-            res[i][bad_msk_i] = res[i][bad_msk_i].clip_(max=bad_conf)
-    return res

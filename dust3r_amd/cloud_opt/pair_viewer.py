@@ -1,16 +1,13 @@
-"""`PairViewer` -- host-side mirror of the reference `dust3r/cloud_opt/pair_viewer.py:18-127`: the
-no-optimisation "aligner" for exactly one symmetrised pair (BASELINE config 1). Focals by the
-Weiszfeld estimator, relative pose by PnP-RANSAC (own solver instead of cv2), depth taken from the
-more confident direction. Pure host code (numpy / torch CPU), as in the reference."""
+"""`PairViewer`: the no-optimisation "aligner" for exactly one symmetrised pair (BASELINE config 1; reference
+`dust3r/cloud_opt/pair_viewer.py:18-127`). Same recipe -- Weiszfeld focal of each view's own pointmap, relative pose by PnP of a
+view's pixels against its points seen from the other view, depth from the more confident direction -- evaluated by the GPU scene
+bootstrap (csrc/bootstrap.hip through cloud_opt/bootstrap.py): two focal fits in one launch, both PnP problems batched, the two
+depth maps in one launch. Solved lazily on first use, once the scene sits on its GPU (`global_aligner` moves it after building)."""
 import numpy as np
 import torch
-import torch.nn as nn
 
-from ..post_process import estimate_focal_knowing_depth
-from ..utils.geometry import depthmap_to_absolute_camera_coordinates, geotrf, inv
 from .base_opt import BasePCOptimizer
-from .commons import edge_str
-from .pnp import solve_pnp_ransac
+from .bootstrap import PairMaps
 
 
 class PairViewer(BasePCOptimizer):
@@ -18,45 +15,56 @@ class PairViewer(BasePCOptimizer):
         super().__init__(*args, **kwargs)
         assert self.is_symmetrized and self.n_edges == 2
         self.has_im_poses = True
-        focals, pps, rel_poses, confs = [], [], [], []
-        for i in range(self.n_imgs):
-            conf = float(self.conf_i[edge_str(i, 1 - i)].mean() * self.conf_j[edge_str(i, 1 - i)].mean())
-            if self.verbose:
-                print(f'  - {conf=:.3} for edge {i}-{1 - i}')
-            confs.append(conf)
-            H, W = self.imshapes[i]
-            pts3d = self.pred_i[edge_str(i, 1 - i)].cpu()
-            pp = torch.tensor((W / 2, H / 2))
-            focal = float(estimate_focal_knowing_depth(pts3d[None], pp, focal_mode='weiszfeld'))
-            focals.append(focal)
-            pps.append(pp)
-            # pose of camera i in the frame of camera 1-i: PnP of image i's pixels against its points seen from 1-i
-            pixels = np.mgrid[:W, :H].T.astype(np.float32)
-            pts3d = self.pred_j[edge_str(1 - i, i)].cpu().numpy()
-            assert pts3d.shape[:2] == (H, W)
-            msk = self.get_masks()[i].cpu().numpy()
-            K = np.float32([(focal, 0, pp[0]), (0, focal, pp[1]), (0, 0, 1)])
-            pose = np.eye(4)
-            try:
-                ok, R, T, _ = solve_pnp_ransac(pts3d[msk], pixels[msk], K, iterations=100, reproj_err=5)
-                if ok:
-                    pose = inv(np.r_[np.c_[R, T], [(0, 0, 0, 1)]])
-            except Exception:
-                pose = np.eye(4)
-            rel_poses.append(torch.from_numpy(pose.astype(np.float32)))
-        if confs[0] > confs[1]:   # cloud expressed in camera 0
-            im_poses = [torch.eye(4), rel_poses[1]]
-            depth = [self.pred_i['0_1'][..., 2].cpu(), geotrf(inv(rel_poses[1]), self.pred_j['0_1'].cpu())[..., 2]]
-        else:                     # cloud expressed in camera 1
-            im_poses = [rel_poses[0], torch.eye(4)]
-            depth = [geotrf(inv(rel_poses[0]), self.pred_j['1_0'].cpu())[..., 2], self.pred_i['1_0'][..., 2].cpu()]
-        self.im_poses = nn.Parameter(torch.stack(im_poses, dim=0), requires_grad=False)
-        self.focals = nn.Parameter(torch.tensor(focals), requires_grad=False)
-        self.pp = nn.Parameter(torch.stack(pps, dim=0), requires_grad=False)
-        self.depth = nn.ParameterList([nn.Parameter(d, requires_grad=False) for d in depth])
-        for p in self.parameters():
-            p.requires_grad = False
+        self._solution = None
 
+    # ------------------------------------------------------------------ the solve
+    @torch.no_grad()
+    def _solved(self):
+        if self._solution is not None:
+            return self._solution
+        maps = PairMaps(self)                                   # raises when the scene is not on a GPU
+        dev = maps.dev
+        e_of = {ij: e for e, ij in enumerate(self.edges)}
+        mean_i, mean_j = maps.edge_conf_means()
+        lead = [e_of[(i, 1 - i)] for i in (0, 1)]              # edge whose view 1 is image i
+        confs = [float(mean_i[e] * mean_j[e]) for e in lead]
+        focals = maps.weiszfeld_focals([(0, e) for e in lead])
+        if self.verbose:
+            for i in (0, 1):
+                print(f'  - conf={confs[i]:.3} for edge {i}-{1 - i}')
+        jobs = []
+        for i in (0, 1):
+            H, W = self.imshapes[i]
+            e = e_of[(1 - i, i)]                                # image i's points in the frame of camera 1 - i: view 2 of that edge
+            conf = self.im_conf[i].contiguous()
+            jobs.append(dict(map=maps.map_addr(1, e), conf=conf.data_ptr(), G=np.eye(4)[:3], f=float(focals[i]), pp=(W / 2, H / 2),
+                             thr=float(self.min_conf_thr), H=H, W=W, points=maps.preds[1][e][:H * W], confs=conf))
+        rel = []
+        for ok, w2c, _ in maps.solve_pnp(jobs, iterations=100):
+            rel.append(np.linalg.inv(w2c) if ok else np.eye(4))   # camera i -> frame of camera 1 - i
+        a = 0 if confs[0] > confs[1] else 1                       # the cloud lives in camera a's frame
+        poses = [np.eye(4), np.eye(4)]
+        poses[1 - a] = rel[1 - a]
+        e = lead[a]
+        rows = [None, None]
+        rows[a] = np.array([0, 0, 1, 0.0])                        # z of pred_i[a_(1-a)]
+        rows[1 - a] = np.linalg.inv(rel[1 - a])[2]                # z of pred_j[a_(1-a)] seen from camera 1 - a
+        anchors = [None, None]
+        anchors[a], anchors[1 - a] = (0, e), (1, e)
+        depth = torch.empty((2, self.max_area), dtype=torch.float32, device=dev)
+        maps.anchor_depth(anchors, rows, depth, take_log=False)
+        self._solution = dict(
+            im_poses=torch.tensor(np.stack(poses), dtype=torch.float32, device=dev),
+            focals=torch.tensor(np.asarray(focals), dtype=torch.float32, device=dev),
+            pp=torch.tensor([(w / 2, h / 2) for h, w in self.imshapes], dtype=torch.float32, device=dev),
+            depth=[depth[i, :h * w].view(h, w) for i, (h, w) in enumerate(self.imshapes)])
+        return self._solution
+
+    def to(self, device, *a, **k):
+        self._solution = None
+        return super().to(device, *a, **k)
+
+    # ------------------------------------------------------------------ the reference's getter surface
     def trainable_names(self):
         return []
 
@@ -65,37 +73,43 @@ class PairViewer(BasePCOptimizer):
             print('_set_depthmap is ignored in PairViewer')
 
     def get_depthmaps(self, raw=False):
-        return [d.to(self.device) for d in self.depth]
+        return list(self._solved()['depth'])
 
     def _set_focal(self, idx, focal, force=False):
-        self.focals[idx] = focal
+        self._solved()['focals'][idx] = focal
 
     def get_focals(self):
-        return self.focals
+        return self._solved()['focals']
 
     def get_known_focal_mask(self):
-        return torch.tensor([True] * len(self.focals))
+        return torch.tensor([True] * self.n_imgs)
 
     def get_principal_points(self):
-        return self.pp
+        return self._solved()['pp']
 
     def get_intrinsics(self):
-        focals, pps = self.get_focals(), self.get_principal_points()
-        K = torch.zeros((len(focals), 3, 3), device=self.device)
-        for i in range(len(focals)):
-            K[i, 0, 0] = K[i, 1, 1] = focals[i]
-            K[i, :2, 2] = pps[i]
-            K[i, 2, 2] = 1
+        s = self._solved()
+        K = torch.zeros((self.n_imgs, 3, 3), device=s['focals'].device)
+        K[:, 0, 0] = K[:, 1, 1] = s['focals']
+        K[:, :2, 2] = s['pp']
+        K[:, 2, 2] = 1
         return K
 
     def get_im_poses(self):
-        return self.im_poses
+        return self._solved()['im_poses']
 
     def depth_to_pts3d(self):
+        """World points of both views from (depth, intrinsics, pose): X = pose . (d (u - ppx) / f, d (v - ppy) / f, d)."""
+        s = self._solved()
         out = []
-        for d, K, pose in zip(self.depth, self.get_intrinsics(), self.get_im_poses()):
-            pts, _ = depthmap_to_absolute_camera_coordinates(d.cpu().numpy(), K.cpu().numpy(), pose.cpu().numpy())
-            out.append(torch.from_numpy(pts).to(device=self.device))
+        for i, (h, w) in enumerate(self.imshapes):
+            d = s['depth'][i]
+            v, u = torch.meshgrid(torch.arange(h, device=d.device, dtype=torch.float32), torch.arange(w, device=d.device, dtype=torch.float32),
+                                  indexing='ij')
+            f, (px, py) = s['focals'][i], s['pp'][i]
+            cam = torch.stack((d * (u - px) / f, d * (v - py) / f, d), dim=-1)
+            P = s['im_poses'][i]
+            out.append(cam @ P[:3, :3].T + P[:3, 3])
         return out
 
     def get_pts3d(self, raw=False):

@@ -37,19 +37,12 @@ def rotmat_to_rodrigues(R):
     return th * w
 
 
-def _dlt_pose(X, xn):
-    """X (n,3) world points, xn (n,2) normalised image coords -> (R, T) or None."""
-    n = len(X)
-    Xh = np.concatenate((X, np.ones((n, 1))), axis=1)
-    A = np.zeros((2 * n, 12))
-    A[0::2, 0:4] = -Xh
-    A[0::2, 8:12] = xn[:, 0:1] * Xh
-    A[1::2, 4:8] = -Xh
-    A[1::2, 8:12] = xn[:, 1:2] * Xh
+def pose_from_dlt_normal(AtA, mean_point=None):
+    """12x12 normal matrix of the DLT system (unknown = the rows of [R | T] stacked) -> (R, T) or None. The null vector is the
+    eigenvector of the smallest eigenvalue, its 3x3 part is projected onto SO(3). `mean_point`: centroid of the world points,
+    used for the cheirality sign when the points themselves are not at hand (the GPU path only has the moments)."""
     try:
-        # null vector of A = eigenvector of the 12x12 normal matrix for its smallest eigenvalue. (A full SVD of A builds the
-        # 2n x 2n left factor: 43 s per call on a 20 000-point consensus set, 700 s of a 100-view MST initialisation.)
-        _, V = np.linalg.eigh(A.T @ A)
+        _, V = np.linalg.eigh(AtA)
     except np.linalg.LinAlgError:
         return None
     P = V[:, 0].reshape(3, 4)
@@ -61,8 +54,26 @@ def _dlt_pose(X, xn):
     if np.linalg.det(R) < 0:
         R, sgn = -R, -1.0
     T = sgn * P[:, 3] / S.mean()
-    # cheirality: most points in front of the camera
-    if np.median((X @ R.T + T)[:, 2]) < 0:
+    if mean_point is not None and (R[2] @ mean_point + T[2]) < 0:
+        return None
+    return R, T
+
+
+def _dlt_pose(X, xn):
+    """X (n,3) world points, xn (n,2) normalised image coords -> (R, T) or None."""
+    n = len(X)
+    Xh = np.concatenate((X, np.ones((n, 1))), axis=1)
+    A = np.zeros((2 * n, 12))
+    A[0::2, 0:4] = -Xh
+    A[0::2, 8:12] = xn[:, 0:1] * Xh
+    A[1::2, 4:8] = -Xh
+    A[1::2, 8:12] = xn[:, 1:2] * Xh
+    # through the 12x12 normal matrix (a full SVD of A builds the 2n x 2n left factor: 43 s per call on a 20 000-point consensus set)
+    sol = pose_from_dlt_normal(A.T @ A)
+    if sol is None:
+        return None
+    R, T = sol
+    if np.median((X @ R.T + T)[:, 2]) < 0:      # cheirality: most points in front of the camera
         return None
     return R, T
 

@@ -201,6 +201,43 @@ int d3r_clean_pointcloud(int n_imgs, float* conf, const float* depth, const floa
  * two SciPy KD-tree queries in the reference; caller: visloc.py:105). */
 int d3r_nearest_neighbors(const float* query, int n_query, const float* ref, int n_ref, int* idx_out, void* stream);
 
+/* ---- scene bootstrap: the one-shot initialisation of the aligner (csrc/bootstrap.hip) -----------------------------------------
+ * Replaces the per-edge / per-image host loops of dust3r/cloud_opt/init_im_poses.py:67-287 (roma.rigid_points_registration at
+ * :220-223, estimate_focal -> post_process.py:40-56, fast_pnp -> cv2.solvePnPRansac at :247-287) and pair_viewer.py:30-76. All
+ * pointer TABLES (`*_ptrs`) are DEVICE arrays of device addresses; sums come back as DEVICE fp64. Nothing synchronises. */
+
+/* out[r] = mean(x[r][0..cols)), x row stride ld (multiple of 4 floats): the edge confidence scores of commons.py:20-25. */
+int d3r_row_means(const float* x, int rows, int cols, int ld, float* out, void* stream);
+
+/* Weighted similarity-registration moments of n_jobs independent cloud pairs in one launch. Job j: source cloud src_ptrs[j]
+ * ([npix[j]][3] fp32), target cloud tgt_ptrs[j], weights wgt_ptrs[j] ([npix[j]]). out[j][17] = { W, Sx[3], Sy[3], Sxy[3][3] (x_a y_b),
+ * Sxx } with S = sum_p w_p (.); the caller finishes Umeyama (centre, 3x3 SVD, scale) on the host. npix: DEVICE int array. */
+size_t d3r_similarity_moments_workspace(int n_jobs, int max_points);
+int d3r_similarity_moments(int n_jobs, const void* src_ptrs, const void* tgt_ptrs, const void* wgt_ptrs, const int* npix, int max_points,
+                           void* workspace, double* out, void* stream);
+
+/* Weiszfeld focal of n_jobs pointmaps (map_ptrs[j]: [H][W][3]; heights / widths DEVICE int arrays), principal point at the image
+ * centre, `iterations` re-weighting rounds after the closed-form start (the reference uses 10): post_process.py:40-56. */
+int d3r_weiszfeld_focals(int n_jobs, const void* map_ptrs, const int* heights, const int* widths, int iterations, float* focals, void* stream);
+
+/* out[i][p] = z = rows[i] . (map_i[p], 1); with take_log: log(z), 0 where z <= 0 (depth.log().nan_to_num(neginf=0),
+ * optimizer.py:112-117); zero padded to max_area: the aligner's im_depthmaps straight from each image's anchor pointmap. */
+int d3r_anchor_depth(int n_imgs, const void* map_ptrs, const float* rows, const int* npix, int max_area, int take_log, float* out, void* stream);
+
+/* PnP support, batched over images. `jobs`: DEVICE array of d3r_pnp_job_bytes()-sized records
+ *   { const float* map [H][W][3]; const float* conf [H][W]; float G[12] (3x4 applied to the map: world points); float f, ppx, ppy,
+ *     conf_thr; int H, W }   (points with conf <= conf_thr are ignored)
+ * d3r_pnp_score: counts[j][h] = inliers of hypothesis h (world->camera [R|t], 12 floats; hypotheses laid out
+ *   [j][d3r_pnp_max_hypotheses()][12]) at reprojection error < reproj_err px, in front of the camera.
+ * d3r_pnp_sums: per job, over the inliers of poses[j]: mode 0 = the 40 moments of the DLT normal matrix (+ count at [40]),
+ *   mode 1 = Gauss-Newton J^T J (21, upper triangle row-major), J^T r (6), cost, count; out[j][d3r_pnp_sum_count()] fp64. */
+int d3r_pnp_job_bytes(void);
+int d3r_pnp_max_hypotheses(void);
+int d3r_pnp_sum_count(void);
+size_t d3r_pnp_workspace(int n_jobs);
+int d3r_pnp_score(int n_jobs, const void* jobs, const float* hypotheses, int n_hyp, float reproj_err, int* counts, void* stream);
+int d3r_pnp_sums(int n_jobs, const void* jobs, const float* poses, float reproj_err, int mode, void* workspace, double* out, void* stream);
+
 /* Host-only self test of the analytic gradient formulas shared with the kernels (no GPU touched; all pointers HOST).
  * Not a compute path: the product never calls it. */
 int d3r_selftest_aligner_math_host(int n_imgs, int n_edges, const int* ei, const int* ej, int H, int W, const float* pred_i,

@@ -160,6 +160,29 @@ def aligner_c4_golden(n_views=20, H=384, W=512, seed=0, niter=300):
     return res
 
 
+def mst_init_golden(n_views, H, W, seed, scene_graph='complete', noise=0.01):
+    """The unmodified reference's `init_minimum_spanning_tree` (init_im_poses.py:67-209; roma and cv2 through the shims) on a
+    synthetic scene: the initial parameters it writes, for the GPU scene bootstrap to reproduce."""
+    import dust3r.cloud_opt.init_im_poses as ref_init
+    out, _, gt = synthetic_scene(n_views, H, W, seed=seed, scene_graph=scene_graph, symmetrize=True, noise=noise)
+    torch.manual_seed(seed)
+    scene = global_aligner(copy.deepcopy(out), 'cpu', mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
+    ref_init.init_minimum_spanning_tree(scene, niter_PnP=10)
+    st = {k: v.detach().clone() for k, v in scene.state_dict(trainable=True).items() if not k.startswith('im_conf')}
+    return dict(kind='mst_init', n_views=n_views, H=H, W=W, seed=seed, scene_graph=scene_graph, noise=noise, unpinned=UNPINNED,
+                pw_poses=st['pw_poses'], im_poses=st['im_poses'], im_focals=st['im_focals'], im_depthmaps_sub=st['im_depthmaps'][:, ::97].clone(),
+                cam2world=scene.get_im_poses().detach().clone(), focals=scene.get_focals().detach().clone(), init_loss=float(scene()))
+
+
+def pair_viewer_golden(H, W, seed):
+    """The unmodified reference's PairViewer (pair_viewer.py:18-127) on a synthetic symmetrised pair."""
+    out, _, gt = synthetic_scene(2, H, W, seed=seed, symmetrize=True, noise=0.005)
+    scene = global_aligner(copy.deepcopy(out), 'cpu', mode=GlobalAlignerMode.PairViewer, verbose=False)
+    return dict(kind='pair_viewer', H=H, W=W, seed=seed, noise=0.005, unpinned=UNPINNED, focals=scene.get_focals().detach().clone(),
+                im_poses=scene.get_im_poses().detach().clone(), depth=[d.detach().clone() for d in scene.get_depthmaps()],
+                pts3d=[p.detach().clone() for p in scene.get_pts3d()])
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -169,6 +192,9 @@ if __name__ == '__main__':
         'inference_tiny_dpt.pt': lambda: inference_golden('tiny_dpt', 3, 32, 48, seed=3),
         'aligner_4v.pt': lambda: aligner_golden(4, 24, 32, seed=0, niter=300),
         'aligner_c4.pt': lambda: aligner_c4_golden(),
+        'mst_init_8v.pt': lambda: mst_init_golden(8, 64, 96, seed=3),
+        'mst_init_12v_swin.pt': lambda: mst_init_golden(12, 48, 64, seed=4, scene_graph='swin-2'),
+        'pair_viewer.pt': lambda: pair_viewer_golden(64, 96, seed=5),
     }
     if len(sys.argv) > 1:        # regenerate only the named fixtures (aligner_c4.pt takes ~20 min of CPU)
         jobs = {k: v for k, v in jobs.items() if k in sys.argv[1:]}

@@ -1,0 +1,141 @@
+"""Host logic of the scene bootstrap (cloud_opt/bootstrap.py): the spanning-tree plan, the composition of per-edge similarities and
+the parameter commit, checked on CPU against parameters written by the UNMODIFIED reference's init_minimum_spanning_tree
+(tests/golden/mst_init_*.pt, oracle/make_golden.py). The HIP kernels are replaced by a numpy stand-in with the same interface
+(test infrastructure); tests/test_aligner_gpu.py runs the same comparison through the kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dust3r_amd.synthetic import synthetic_scene
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+class NumpyMaps:
+    """Stand-in for bootstrap.PairMaps: same methods, numpy arithmetic on the scene's (CPU) tensors."""
+
+    def __init__(self, scene):
+        self.scene, self.dev = scene, torch.device('cpu')
+        self.preds = (scene._stacked_pred_i, scene._stacked_pred_j)
+        self.confs = (scene._conf_i, scene._conf_j)
+        self.max_area, self.edges, self.imshapes = scene.max_area, scene.edges, scene.imshapes
+
+    def npix(self, side, e):
+        h, w = self.imshapes[self.edges[e][side]]
+        return h * w
+
+    def map_addr(self, side, e):
+        return (side, e)
+
+    def conf_addr(self, side, e):
+        return (side, e)
+
+    def _map(self, side, e):
+        return self.preds[side][e][:self.npix(side, e)].double().numpy()
+
+    def edge_conf_means(self):
+        return tuple(np.array([float(self.confs[s][e][:self.npix(s, e)].mean()) for e in range(len(self.edges))]) for s in (0, 1))
+
+    def similarity_moments(self, jobs):
+        out = np.zeros((len(jobs), 17))
+        for k, (src, tgt, wm) in enumerate(jobs):
+            x, y = self._map(*src), self._map(*tgt)
+            w = self.confs[wm[0]][wm[1]][:len(x)].double().numpy()
+            out[k, 0] = w.sum()
+            out[k, 1:4], out[k, 4:7] = (w[:, None] * x).sum(0), (w[:, None] * y).sum(0)
+            out[k, 7:16] = ((w[:, None] * x)[:, :, None] * y[:, None, :]).sum(0).ravel()
+            out[k, 16] = (w[:, None] * x * x).sum()
+        return out
+
+    def weiszfeld_focals(self, maps, iterations=10):
+        from oracle.cloud_ref import estimate_focal_weiszfeld
+        out = []
+        for side, e in maps:
+            h, w = self.imshapes[self.edges[e][side]]
+            out.append(estimate_focal_weiszfeld(self.preds[side][e][:h * w].view(h, w, 3), iterations))
+        return np.array(out)
+
+    def anchor_depth(self, anchors, rows, out, take_log=True):
+        for k, (a, r) in enumerate(zip(anchors, rows)):
+            p = self._map(*a)
+            z = p @ np.asarray(r[:3], np.float64) + r[3]
+            v = np.where(z > 0, np.log(np.where(z > 0, z, 1.0)), 0.0) if take_log else z
+            out[k].zero_()
+            out[k, :len(v)] = torch.from_numpy(v.astype(np.float32))
+        return out
+
+    def solve_pnp(self, jobs, iterations=10):
+        from dust3r_amd.cloud_opt.pnp import solve_pnp_ransac
+        res = []
+        for j in jobs:
+            H, W = j['H'], j['W']
+            G = np.asarray(j['G'], np.float64).reshape(3, 4)
+            pts = j['points'].double().numpy() @ G[:, :3].T + G[:, 3]
+            msk = (j['confs'].reshape(-1) > j['thr']).numpy()
+            pix = np.mgrid[:W, :H].T.reshape(-1, 2).astype(np.float64)
+            K = np.array([[j['f'], 0, j['pp'][0]], [0, j['f'], j['pp'][1]], [0, 0, 1.0]])
+            ok, R, T, inl = solve_pnp_ransac(pts[msk], pix[msk], K, iterations=iterations, reproj_err=5)
+            M = np.eye(4)
+            if ok:
+                M[:3, :3], M[:3, 3] = R, T
+            res.append((bool(ok), M, 0 if inl is None else len(inl)))
+        return res
+
+
+def _scene(g):
+    from dust3r_amd.cloud_opt import global_aligner
+    out, _, gt = synthetic_scene(g['n_views'], g['H'], g['W'], seed=g['seed'], scene_graph=g['scene_graph'], symmetrize=True, noise=g['noise'])
+    return global_aligner(out, 'cpu', verbose=False), gt
+
+
+def check_against_reference_init(scene, g, plan_pose_jobs=None):
+    """Parameters written by the bootstrap vs the reference's: images whose pose comes from a registration (and every pairwise pose,
+    focal, depth map) tightly; images posed by PnP to the accuracy of two different RANSAC solvers."""
+    pw, ref_pw = scene.pw_poses.detach().cpu().double(), g['pw_poses'].double()
+    # quaternion sign is free
+    sgn = torch.sign((pw[:, :4] * ref_pw[:, :4]).sum(dim=1, keepdim=True))
+    assert float((pw[:, :4] * sgn - ref_pw[:, :4]).abs().max()) < 2e-4
+    assert float((pw[:, 4:] - ref_pw[:, 4:]).abs().max()) < 2e-4
+    assert float((scene.get_focals().detach().cpu().flatten() / g['focals'].flatten() - 1).abs().max()) < 2e-4
+    c2w, ref_c2w = scene.get_im_poses().detach().cpu().double(), g['cam2world'].double()
+    err = (c2w - ref_c2w).abs().flatten(1).max(dim=1).values
+    posed_by_pnp = [k for k in range(len(err)) if plan_pose_jobs is not None and plan_pose_jobs[k] is None]
+    for k in range(len(err)):
+        assert float(err[k]) < (3e-2 if k in posed_by_pnp else 2e-4), (k, float(err[k]), posed_by_pnp)
+    d, ref_d = scene.im_depthmaps.detach().cpu()[:, ::97].double(), g['im_depthmaps_sub'].double()
+    for k in range(len(err)):
+        assert float((d[k] - ref_d[k]).abs().max()) < (3e-2 if k in posed_by_pnp else 3e-4), k
+    return posed_by_pnp
+
+
+@pytest.mark.parametrize('name', ['mst_init_8v.pt', 'mst_init_12v_swin.pt'])
+def test_spanning_tree_bootstrap_host_logic_matches_reference(name):
+    from dust3r_amd.cloud_opt import bootstrap as B
+    g = torch.load(os.path.join(GOLD, name), weights_only=False)
+    scene, gt = _scene(g)
+    maps = NumpyMaps(scene)
+    plan = B.plan_spanning_tree(scene.n_imgs, scene.edges, *maps.edge_conf_means())
+    assert len(plan.tree_edges) == scene.n_imgs - 1 and all(a is not None for a in plan.anchor)
+    scene.forward = lambda: torch.tensor(float('nan'))          # the loss needs the GPU engine; not part of this check
+    B.bootstrap_from_spanning_tree(scene, niter_PnP=10, maps=maps)
+    pnp_imgs = check_against_reference_init(scene, g, plan.pose_job)
+    print(f'{name}: {len(pnp_imgs)} of {scene.n_imgs} images posed by PnP')
+
+
+def test_similarity_from_moments_is_weighted_umeyama():
+    from dust3r_amd.cloud_opt.bootstrap import similarity_from_moments, split_similarity
+    from oracle.roma_ref import rigid_points_registration
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((500, 3), generator=g, dtype=torch.float64)
+    w = torch.rand(500, generator=g, dtype=torch.float64) + 0.1
+    A = torch.linalg.qr(torch.randn((3, 3), generator=g, dtype=torch.float64))[0]
+    A = A * torch.sign(torch.linalg.det(A))
+    y = 1.7 * x @ A.T + torch.tensor([0.3, -1.0, 2.0]) + 0.01 * torch.randn((500, 3), generator=g, dtype=torch.float64)
+    R, t, s = rigid_points_registration(x, y, weights=w, compute_scaling=True)
+    xn, yn, wn = x.numpy(), y.numpy(), w.numpy()
+    m = np.concatenate(([wn.sum()], (wn[:, None] * xn).sum(0), (wn[:, None] * yn).sum(0),
+                        ((wn[:, None] * xn)[:, :, None] * yn[:, None, :]).sum(0).ravel(), [(wn[:, None] * xn * xn).sum()]))
+    s2, R2, t2 = split_similarity(similarity_from_moments(m))
+    assert abs(s2 - float(s)) < 1e-10 and np.abs(R2 - R.numpy()).max() < 1e-10 and np.abs(t2 - t.numpy()).max() < 1e-10

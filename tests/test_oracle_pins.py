@@ -108,3 +108,37 @@ def test_state_dict_keys_match_reference_for_release_configs():
         assert set(spec) == set(sd), (set(spec) ^ set(sd))
         for k, shape in spec.items():
             assert tuple(sd[k].shape) == tuple(shape), k
+
+
+@pytest.mark.skipif(not reference_available(), reason='/root/reference only exists in the build container')
+def test_cloud_restatements_equal_live_reference():
+    """oracle/cloud_ref.py (Weiszfeld focal, clean_pointcloud) against the unmodified reference functions on the same inputs."""
+    from oracle.ref_import import import_reference
+    import_reference()
+    from dust3r.cloud_opt.base_opt import clean_pointcloud as ref_clean
+    from dust3r.post_process import estimate_focal_knowing_depth as ref_focal
+    from dust3r_amd.synthetic import synthetic_scene
+    from oracle.cloud_ref import clean_pointcloud_ref, estimate_focal_weiszfeld
+    out, init, gt = synthetic_scene(4, 32, 48, seed=3, symmetrize=True, noise=0.02)
+    for e in (0, 5):
+        pts = out['pred1']['pts3d'][e]
+        f_ref = float(ref_focal(pts[None], torch.tensor((48 / 2, 32 / 2))[None], focal_mode='weiszfeld'))
+        assert abs(estimate_focal_weiszfeld(pts) / f_ref - 1) < 1e-5
+    # clean_pointcloud: world clouds of 4 views with one of them pulled towards its camera
+    g = torch.Generator().manual_seed(0)
+    c2w = gt['cam2world']
+    w2c = torch.linalg.inv(c2w)
+    f = gt['focal']
+    K = torch.tensor([[f, 0, 24.0], [0, f, 16.0], [0, 0, 1]]).repeat(4, 1, 1)
+    depth = [gt['depth'][i] * (0.8 if i == 1 else 1.0) for i in range(4)]
+    vs, us = torch.meshgrid(torch.arange(32.), torch.arange(48.), indexing='ij')
+    pts = []
+    for i in range(4):
+        cam = torch.stack((depth[i] * (us - 24) / f, depth[i] * (vs - 16) / f, depth[i]), dim=-1)
+        pts.append(cam @ c2w[i, :3, :3].T + c2w[i, :3, 3])
+    confs = [1 + 3 * torch.rand((32, 48), generator=g) for _ in range(4)]
+    ref = ref_clean([c.clone() for c in confs], K, w2c, depth, pts, tol=0.001, bad_conf=0)
+    got = clean_pointcloud_ref([c.clone() for c in confs], K, w2c, depth, pts, tol=0.001, bad_conf=0)
+    changed = sum(int((r != c).sum()) for r, c in zip(ref, confs))
+    assert changed > 50
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))

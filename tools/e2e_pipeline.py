@@ -30,6 +30,8 @@ def main():
     from dust3r_amd.model import AsymmetricCroCo3DStereo
     from dust3r_amd.synthetic import MODEL_CONFIGS, OUT_GAIN, synthetic_image_list, synthetic_scene, synthetic_state_dict
     cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
+    if '--align-only' in sys.argv:
+        return align_stage(n, graph, H, W, dev)
     m = AsymmetricCroCo3DStereo(precision='bf16', landscape_only=False, **MODEL_CONFIGS[cfg])
     m.load_state_dict(synthetic_state_dict({k: torch.empty(v, device='meta') for k, v in m._spec.items()}, 0, OUT_GAIN[cfg], device=dev))
     m.to(dev)
@@ -49,13 +51,23 @@ def main():
         print(f'  inference, {mode:36s}: {len(pairs)} pairs in {dt:6.2f} s = {len(pairs) / dt:6.1f} pairs/s (host to host)')
     del out
 
+    align_stage(n, graph, H, W, dev)
+
+
+def align_stage(n, graph, H, W, dev):
+    from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
+    from dust3r_amd.synthetic import synthetic_scene
     # ---- stage B: global alignment of a consistent scene of the same shape ------------------------------------------------
     t = time.time()
     out, _, gt = synthetic_scene(n, H, W, seed=0, scene_graph=graph, symmetrize=True, noise=0.002, device=dev)
-    out = {k: ({kk: (vv.cpu() if isinstance(vv, torch.Tensor) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in out.items()}
-    print(f'  (synthetic scene built in {time.time() - t:.1f} s: {len(out["view1"]["idx"])} edges)')
+    host_out = '--host-predictions' in sys.argv     # predictions handed over on the host (the reference's inference() format) or resident in HBM
+    if host_out:
+        out = {k: ({kk: (vv.cpu() if isinstance(vv, torch.Tensor) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in out.items()}
+    print(f'  (synthetic scene built in {time.time() - t:.1f} s: {len(out["view1"]["idx"])} edges; predictions {"on the host" if host_out else "resident in HBM"})')
+    torch.cuda.synchronize()
     t0 = time.time()
     scene = global_aligner(out, device=dev, mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
+    torch.cuda.synchronize()
     t1 = time.time()
     from dust3r_amd.cloud_opt import init_im_poses as init_fun
     init_fun.init_minimum_spanning_tree(scene, niter_PnP=10)
@@ -68,7 +80,7 @@ def main():
     masks = scene.get_masks()
     torch.cuda.synchronize()
     t4 = time.time()
-    print(f'  global_aligner(): build {t1 - t0:5.2f} s | init=mst (host) {t2 - t1:6.2f} s | 300 iterations {t3 - t2:5.2f} s = {300 / (t3 - t2):6.1f} it/s | getters {t4 - t3:4.2f} s')
+    print(f'  global_aligner(): build {t1 - t0:5.2f} s | init=mst (GPU bootstrap) {t2 - t1:6.2f} s | 300 iterations {t3 - t2:5.2f} s = {300 / (t3 - t2):6.1f} it/s | getters {t4 - t3:4.2f} s')
     print(f'  final loss {loss:.5f}; focal error vs ground truth {float((focals.flatten().cpu() / gt["focal"] - 1).abs().max()):.3f}; '
           f'{len(pts)} pointmaps of {tuple(pts[0].shape)}, {sum(int(mk.sum()) for mk in masks)} confident points, poses {tuple(poses.shape)}')
 
