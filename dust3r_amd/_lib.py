@@ -80,7 +80,7 @@ def _load():
         'd3r_pnp_sum_count': (i, []),
         'd3r_pnp_workspace': (C.c_size_t, [i]),
         'd3r_pnp_score': (i, [i, vp, fp, i, f, ip, vp]),
-        'd3r_pnp_sums': (i, [i, vp, fp, f, i, vp, vp, vp]),
+        'd3r_pnp_sums': (i, [i, vp, fp, f, vp, vp, vp]),
         'd3r_selftest_aligner_math_host': (i, [i, i, ip, ip, i, i, fp, fp, fp, fp, fp, fp, fp, fp, f, f, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():

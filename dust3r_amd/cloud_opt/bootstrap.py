@@ -271,8 +271,8 @@ class _PnpJobRec(C.Structure):
 def solve_pnp_batch(dev, jobs, iterations=10, reproj_err=5.0, seed=0, refine_iters=10):
     """jobs: list of dict(map=addr of (H,W,3), conf=addr of (H,W), G=3x4 (world = G . map point), f, pp=(x, y), thr, H, W,
     points=torch (H,W,3) view, confs=torch (H,W) view). Returns per job (success, world->cam 4x4, inlier count).
-    Hypotheses: 6-point DLT on random masked points (host, tiny); consensus scoring, DLT normal moments of the consensus set and
-    Gauss-Newton sums: GPU, all jobs in the same launches."""
+    Hypotheses: 6-point DLT on random masked points (host, tiny); consensus scoring and the Gauss-Newton sums of the polish: GPU, all
+    jobs in the same launches."""
     assert lib.d3r_pnp_job_bytes() == C.sizeof(_PnpJobRec)
     n = len(jobs)
     if n == 0:
@@ -323,53 +323,41 @@ def solve_pnp_batch(dev, jobs, iterations=10, reproj_err=5.0, seed=0, refine_ite
     ws = torch.empty(int(lib.d3r_pnp_workspace(n)), dtype=torch.uint8, device=dev)
     sums = torch.empty((n, nv), dtype=torch.float64, device=dev)
 
-    def gpu_sums(P, mode):
+    def gn_sums(P):
         P_d = torch.from_numpy(np.ascontiguousarray(P.reshape(n, 12), np.float32)).to(dev)
         with torch.cuda.device(dev):
-            check(lib.d3r_pnp_sums(n, ptr(recs_d), ptr(P_d), float(reproj_err), mode, ptr(ws), ptr(sums), current_stream()), 'pnp_sums')
+            check(lib.d3r_pnp_sums(n, ptr(recs_d), ptr(P_d), float(reproj_err), ptr(ws), ptr(sums), current_stream()), 'pnp_sums')
         return sums.cpu().numpy()
 
-    iu = np.triu_indices(4)
+    # polish: Gauss-Newton on the reprojection error of the consensus set (re-selected at every step). The converged pose replaces the
+    # minimal-sample hypothesis unless it lost more than 5 % of the consensus (a 6-point hypothesis that is a few 1e-3 off can hold a
+    # handful of stray points inside the 5-pixel band that the least-squares pose drops: count alone must not veto the polish).
     ju = np.triu_indices(6)
-    for _ in range(2):                               # refit on the consensus set, then polish (as cloud_opt/pnp.py does on the host)
-        s = gpu_sums(poses, 0)
-        cand_poses = poses.copy()
+    cand = poses.copy()
+    hyp_count = best_count.astype(np.float64)
+    for _ in range(refine_iters):
+        g = gn_sums(cand)
+        step = 0.0
         for a in range(n):
-            if s[a, 40] < 6:
+            if g[a, 28] < 6:
                 continue
-
-            def sym(v):
-                M = np.zeros((4, 4))
-                M[iu] = v
-                return M + M.T - np.diag(np.diag(M))
-            S0, Sx, Sy, Sr = sym(s[a, 0:10]), sym(s[a, 10:20]), sym(s[a, 20:30]), sym(s[a, 30:40])
-            Z = np.zeros((4, 4))
-            AtA = np.block([[S0, Z, -Sx], [Z, S0, -Sy], [-Sx, -Sy, Sr]])
-            sol = pnp_host.pose_from_dlt_normal(AtA, mean_point=S0[:3, 3] / S0[3, 3])
-            if sol is not None:
-                cand_poses[a] = np.concatenate((sol[0], sol[1][:, None]), axis=1)
-        for _ in range(refine_iters):
-            g = gpu_sums(cand_poses, 1)
-            step = 0.0
-            for a in range(n):
-                if g[a, 28] < 6:
-                    continue
-                Hm = np.zeros((6, 6))
-                Hm[ju] = g[a, 0:21]
-                Hm = Hm + Hm.T - np.diag(np.diag(Hm)) + 1e-9 * np.eye(6)
-                try:
-                    d = np.linalg.solve(Hm, -g[a, 21:27])
-                except np.linalg.LinAlgError:
-                    continue
-                cand_poses[a, :, :3] = pnp_host.rodrigues_to_rotmat(d[:3]) @ cand_poses[a, :, :3]      # R <- exp([w]x) R about the camera origin,
-                cand_poses[a, :, 3] += d[3:]                                                           # t <- t + dt (the kernel's Jacobian convention)
-                step = max(step, float(np.linalg.norm(d)))
-            if step < 1e-10:
-                break
-        new_count = gpu_sums(cand_poses, 1)[:, 28]
-        for a in range(n):
-            if new_count[a] >= best_count[a]:
-                poses[a], best_count[a] = cand_poses[a], new_count[a]
+            Hm = np.zeros((6, 6))
+            Hm[ju] = g[a, 0:21]
+            Hm = Hm + Hm.T - np.diag(np.diag(Hm)) + 1e-9 * np.eye(6)
+            try:
+                d = np.linalg.solve(Hm, -g[a, 21:27])
+            except np.linalg.LinAlgError:
+                continue
+            cand[a, :, :3] = pnp_host.rodrigues_to_rotmat(d[:3]) @ cand[a, :, :3]      # R <- exp([w]x) R about the camera origin,
+            cand[a, :, 3] += d[3:]                                                      # t <- t + dt (the kernel's Jacobian convention)
+            step = max(step, float(np.linalg.norm(d)))
+        if step < 1e-9:
+            break
+    g = gn_sums(cand)
+    best_count = best_count.astype(np.float64)
+    for a in range(n):
+        if g[a, 28] >= 0.95 * hyp_count[a]:
+            poses[a], best_count[a] = cand[a], g[a, 28]
     out = []
     for a in range(n):
         M = np.eye(4)

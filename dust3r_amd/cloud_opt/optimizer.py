@@ -28,13 +28,17 @@ class PointCloudOptimizer(BasePCOptimizer):
         self.focal_break = focal_break
         n = self.n_imgs
         # same initial distributions as optimizer.py:29-34
-        self.im_depthmaps = nn.Parameter(torch.stack([_ravel_hw(torch.randn(H, W) / 10 - 3, self.max_area) for H, W in self.imshapes]))
+        areas = torch.tensor([H * W for H, W in self.imshapes])
+        depth0 = torch.randn((n, self.max_area)) / 10 - 3                                    # one draw for all images (zero in the padding)
+        if int(areas.min()) < self.max_area:
+            depth0 = depth0 * (torch.arange(self.max_area)[None, :] < areas[:, None])
+        self.im_depthmaps = nn.Parameter(depth0)
         self.im_poses = nn.Parameter(torch.stack([self.rand_pose(self.POSE_DIM) for _ in range(n)]).float())
         self.im_focals = nn.Parameter(torch.tensor([[self.focal_break * np.log(max(H, W))] for H, W in self.imshapes], dtype=torch.float32))
         self.im_pp = nn.Parameter(torch.zeros((n, 2)), requires_grad=False)
         self.imshape = self.imshapes[0]
         self.register_buffer('_pp', torch.tensor([(w / 2, h / 2) for h, w in self.imshapes], dtype=torch.float32))
-        self.register_buffer('_grid', torch.stack([_ravel_hw(xy_grid(W, H, device='cpu').float(), self.max_area) for H, W in self.imshapes]))
+        self._grid_cache = None        # (n, max_area, 2) pixel grid of depth_to_pts3d, built on first use on the scene's device
         self.register_buffer('_ei', torch.tensor([i for i, j in self.edges]))
         self.register_buffer('_ej', torch.tensor([j for i, j in self.edges]))
         im_areas = [h * w for h, w in self.imshapes]
@@ -139,6 +143,15 @@ class PointCloudOptimizer(BasePCOptimizer):
         if not raw:
             res = [dm[:h * w].view(h, w) for dm, (h, w) in zip(res, self.imshapes)]
         return res
+
+    @property
+    def _grid(self):
+        g = self._grid_cache
+        if g is None or g.device != self.device:
+            dev = self.device
+            per_shape = {hw: _ravel_hw(xy_grid(hw[1], hw[0], device=dev).float(), self.max_area) for hw in set(self.imshapes)}
+            g = self._grid_cache = torch.stack([per_shape[hw] for hw in self.imshapes])
+        return g
 
     def depth_to_pts3d(self):
         focals = self.get_focals().unsqueeze(1)                 # (n,1,1)

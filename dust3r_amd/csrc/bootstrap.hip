@@ -15,8 +15,8 @@
 //   * `weiszfeld_focal_kernel`: one 1024-thread workgroup per image keeps its 2.4 MB map in L2 for the 11 passes.
 //   * `anchor_depth_kernel`: log-depth of every image from its anchor map and one 1x4 row (no world cloud is ever materialised).
 //   * PnP: hypotheses and 12x12 / 6x6 solves on the host (a few hundred flops); scoring every hypothesis against every masked point
-//     (`pnp_score_kernel`), the DLT normal-equation moments (`pnp_dlt_kernel`) and the Gauss-Newton sums (`pnp_gn_kernel`) on the
-//     GPU, batched over all images that need a pose.
+//     (`pnp_score_kernel`) and the Gauss-Newton sums of the polish (`pnp_sums_kernel`) on the GPU, batched over all images that need
+//     a pose.
 // Sums are accumulated in fp32 per lane over at most 8 points, then in fp64 across lanes / workgroups in a fixed order (deterministic).
 #include "../../include/dust3r_hip.h"
 #include "kernels.hpp"
@@ -260,12 +260,11 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const PnpJob* jobs, cons
     if (threadIdx.x < nh && cnt[threadIdx.x]) atomicAdd(&counts[blockIdx.y * PNP_MAXH + threadIdx.x], cnt[threadIdx.x]);
 }
 
-// Sums over the inliers of pose[job] (reprojection error^2 < thr2, in front of the camera):
-//   mode 0 (DLT refit, normalised image coordinates xh = (u - ppx) / f): the 40 moments of the 12x12 normal matrix
-//          S0 = sum h h^T (10), Sx = sum xh h h^T (10), Sy = sum yh h h^T (10), Sr = sum (xh^2 + yh^2) h h^T (10), h = (X, 1); + count
-//   mode 1 (Gauss-Newton on the reprojection error over (rotation increment w, translation t)): J^T J (21), J^T r (6), cost, count
-static constexpr int PNP_NV = 44;
-__global__ __launch_bounds__(256) void pnp_sums_kernel(const PnpJob* jobs, const float* pose, float thr2, int mode, int nchunk, double* partial) {
+// Gauss-Newton sums over the inliers of pose[job] (reprojection error^2 < thr2, in front of the camera), unknowns = (rotation increment
+// w about the camera origin, translation increment): J^T J (21, upper triangle row-major), J^T r (6), cost, inlier count.
+// (A DLT refit of the consensus set from fp32 moments was tried first: the 12x12 normal matrix is too ill-conditioned for it.)
+static constexpr int PNP_NV = 29;
+__global__ __launch_bounds__(256) void pnp_sums_kernel(const PnpJob* jobs, const float* pose, float thr2, int nchunk, double* partial) {
     __shared__ double red[4 * PNP_NV];
     const PnpJob j = jobs[blockIdx.y];
     const float* P = pose + blockIdx.y * 12;
@@ -282,20 +281,7 @@ __global__ __launch_bounds__(256) void pnp_sums_kernel(const PnpJob* jobs, const
         const float iz = 1.f / zc;
         const float ru = j.f * xc * iz + j.ppx - u, rv = j.f * yc * iz + j.ppy - v;
         if (!(zc > 0.f && ru * ru + rv * rv < thr2)) continue;
-        if (mode == 0) {
-            const float xh = (u - j.ppx) / j.f, yh = (v - j.ppy) / j.f, rr = xh * xh + yh * yh;
-            const float h[4] = {X[0], X[1], X[2], 1.f};
-            int k = 0;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = a; b < 4; ++b) {
-                    const float m = h[a] * h[b];
-                    acc[k] += (double)m; acc[10 + k] += (double)(xh * m); acc[20 + k] += (double)(yh * m); acc[30 + k] += (double)(rr * m);
-                    ++k;
-                }
-            acc[40] += 1.0;
-        } else {
+        {
             // d(proj)/d(Xc) and d(Xc)/d(w, t) with R <- exp([w]x) R:  dXc = -[Xc - t]x w + t'
             const float fx = j.f * iz, a0 = -j.f * xc * iz * iz, a1 = -j.f * yc * iz * iz;
             const float Xr[3] = {xc - P[3], yc - P[7], zc - P[11]};
@@ -391,10 +377,10 @@ extern "C" int d3r_pnp_score(int n_jobs, const void* jobs, const float* hypothes
     return rc_of(hipGetLastError());
 }
 
-extern "C" int d3r_pnp_sums(int n_jobs, const void* jobs, const float* poses, float reproj_err, int mode, void* workspace, double* out, void* stream) {
-    if (n_jobs <= 0 || !jobs || !poses || !workspace || !out || (mode != 0 && mode != 1)) return D3R_ERR_INVALID;
+extern "C" int d3r_pnp_sums(int n_jobs, const void* jobs, const float* poses, float reproj_err, void* workspace, double* out, void* stream) {
+    if (n_jobs <= 0 || !jobs || !poses || !workspace || !out) return D3R_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pnp_sums_kernel, dim3(PNP_GRID, n_jobs), dim3(256), 0, st, (const PnpJob*)jobs, poses, reproj_err * reproj_err, mode, PNP_GRID,
+    hipLaunchKernelGGL(pnp_sums_kernel, dim3(PNP_GRID, n_jobs), dim3(256), 0, st, (const PnpJob*)jobs, poses, reproj_err * reproj_err, PNP_GRID,
                        (double*)workspace);
     hipLaunchKernelGGL(pnp_reduce_kernel, dim3(n_jobs), dim3(64), 0, st, (const double*)workspace, PNP_GRID, out);
     return rc_of(hipGetLastError());

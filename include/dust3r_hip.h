@@ -229,14 +229,15 @@ int d3r_anchor_depth(int n_imgs, const void* map_ptrs, const float* rows, const 
  *     conf_thr; int H, W }   (points with conf <= conf_thr are ignored)
  * d3r_pnp_score: counts[j][h] = inliers of hypothesis h (world->camera [R|t], 12 floats; hypotheses laid out
  *   [j][d3r_pnp_max_hypotheses()][12]) at reprojection error < reproj_err px, in front of the camera.
- * d3r_pnp_sums: per job, over the inliers of poses[j]: mode 0 = the 40 moments of the DLT normal matrix (+ count at [40]),
- *   mode 1 = Gauss-Newton J^T J (21, upper triangle row-major), J^T r (6), cost, count; out[j][d3r_pnp_sum_count()] fp64. */
+ * d3r_pnp_sums: per job, over the inliers of poses[j], the Gauss-Newton sums of the reprojection error over (rotation increment about
+ *   the camera origin, translation increment): J^T J (21, upper triangle row-major), J^T r (6), cost, inlier count;
+ *   out[j][d3r_pnp_sum_count()] fp64. */
 int d3r_pnp_job_bytes(void);
 int d3r_pnp_max_hypotheses(void);
 int d3r_pnp_sum_count(void);
 size_t d3r_pnp_workspace(int n_jobs);
 int d3r_pnp_score(int n_jobs, const void* jobs, const float* hypotheses, int n_hyp, float reproj_err, int* counts, void* stream);
-int d3r_pnp_sums(int n_jobs, const void* jobs, const float* poses, float reproj_err, int mode, void* workspace, double* out, void* stream);
+int d3r_pnp_sums(int n_jobs, const void* jobs, const float* poses, float reproj_err, void* workspace, double* out, void* stream);
 
 /* Host-only self test of the analytic gradient formulas shared with the kernels (no GPU touched; all pointers HOST).
  * Not a compute path: the product never calls it. */

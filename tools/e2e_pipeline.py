@@ -66,9 +66,17 @@ def align_stage(n, graph, H, W, dev):
     print(f'  (synthetic scene built in {time.time() - t:.1f} s: {len(out["view1"]["idx"])} edges; predictions {"on the host" if host_out else "resident in HBM"})')
     torch.cuda.synchronize()
     t0 = time.time()
+    if '--profile-build' in sys.argv:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
     scene = global_aligner(out, device=dev, mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
     torch.cuda.synchronize()
     t1 = time.time()
+    if '--profile-build' in sys.argv:
+        pr.disable()
+        pstats.Stats(pr).sort_stats('cumulative').print_stats(14)
     from dust3r_amd.cloud_opt import init_im_poses as init_fun
     init_fun.init_minimum_spanning_tree(scene, niter_PnP=10)
     torch.cuda.synchronize()
