@@ -295,8 +295,8 @@ def test_pnp_batch_recovers_camera_poses(gpu):
         d = 2 + 0.5 * rng.rand(H, W)
         cam = np.stack((d * (u - W / 2) / f, d * (v - H / 2) / f, d), axis=-1)             # camera-frame points
         world = (cam - T) @ R                                                               # X with R X + T = cam
-            bad = rng.rand(H, W) < 0.05
-            world[bad] += rng.randn(int(bad.sum()), 3) + 2.0 * np.sign(rng.randn(int(bad.sum()), 3))   # gross, incoherent outliers
+        bad = rng.rand(H, W) < 0.05
+        world[bad] += rng.randn(int(bad.sum()), 3) + 2.0 * np.sign(rng.randn(int(bad.sum()), 3))   # gross, incoherent outliers
         pts = torch.tensor(world, dtype=torch.float32, device=gpu).contiguous()
         conf = torch.full((H, W), 5.0, device=gpu)
         keep += [pts, conf]
