@@ -53,6 +53,7 @@ def _load():
         'd3r_model_load_tensor_device': (i, [vp, C.c_char_p, fp, i, C.POINTER(C.c_int64)]),
         'd3r_model_missing': (i, [vp]),
         'd3r_model_forward': (i, [vp, fp, fp, i, i, i, fp, fp, fp, fp, vp]),
+        'd3r_model_forward_mixed': (i, [vp, fp, i, i, fp, i, i, i, fp, fp, fp, fp, vp]),
         'd3r_model_forward_packed': (i, [vp, fp, fp, i, i, i, fp, vp]),
         'd3r_model_device_bytes': (C.c_size_t, [vp]),
         'd3r_model_feature_bytes': (C.c_size_t, [vp, i, i]),
@@ -67,7 +68,7 @@ def _load():
         'd3r_aligner_destroy': (i, [vp]),
         'd3r_aligner_set_option': (i, [vp, i, i]),
         'd3r_aligner_run': (i, [vp, i, i, i, f, f, i, fp, vp]),
-        'd3r_aligner_loss_grad': (i, [vp, fp, fp, fp, fp, fp, vp]),
+        'd3r_aligner_loss_grad': (i, [vp, fp, fp, fp, fp, fp, fp, fp, vp]),
         'd3r_nearest_neighbors': (i, [fp, i, fp, i, ip, vp]),
         'd3r_clean_pointcloud': (i, [i, fp, fp, fp, fp, fp, ip, ip, i, f, f, vp]),
         'd3r_row_means': (i, [fp, i, i, i, fp, vp]),

@@ -74,8 +74,6 @@ class BasePCOptimizer(nn.Module):
 
     def _init_from_views(self, view1, view2, pred1, pred2, dist='l1', conf='log', min_conf_thr=3, base_scale=0.5,
                          allow_pw_adaptors=False, pw_break=20, rand_pose=torch.randn, iterationsCount=None, verbose=True):
-        if allow_pw_adaptors:
-            raise NotImplementedError('allow_pw_adaptors=True is not supported by the fused aligner (frozen in every reference recipe)')
         if dist not in ('l1', 'l2'):
             raise KeyError(dist)
         if not isinstance(view1['idx'], list):
@@ -129,7 +127,7 @@ class BasePCOptimizer(nn.Module):
         self.pw_break = pw_break
         self.POSE_DIM = 7
         self.pw_poses = nn.Parameter(rand_pose((self.n_edges, 1 + self.POSE_DIM)).float())
-        self.pw_adaptors = nn.Parameter(torch.zeros((self.n_edges, 2)), requires_grad=False)
+        self.pw_adaptors = nn.Parameter(torch.zeros((self.n_edges, 2)), requires_grad=bool(allow_pw_adaptors))     # base_opt.py:92
         self.has_im_poses = False
         self.rand_pose = rand_pose
 

@@ -22,8 +22,6 @@ from .base_opt import BasePCOptimizer, _ravel_hw
 class PointCloudOptimizer(BasePCOptimizer):
     def __init__(self, *args, optimize_pp=False, focal_break=20, **kwargs):
         super().__init__(*args, **kwargs)
-        if optimize_pp:
-            raise NotImplementedError('optimize_pp=True is not supported by the fused aligner yet')
         self.has_im_poses = True
         self.focal_break = focal_break
         n = self.n_imgs
@@ -35,7 +33,7 @@ class PointCloudOptimizer(BasePCOptimizer):
         self.im_depthmaps = nn.Parameter(depth0)
         self.im_poses = nn.Parameter(torch.stack([self.rand_pose(self.POSE_DIM) for _ in range(n)]).float())
         self.im_focals = nn.Parameter(torch.tensor([[self.focal_break * np.log(max(H, W))] for H, W in self.imshapes], dtype=torch.float32))
-        self.im_pp = nn.Parameter(torch.zeros((n, 2)), requires_grad=False)
+        self.im_pp = nn.Parameter(torch.zeros((n, 2)), requires_grad=bool(optimize_pp))       # optimizer.py:34: im_pp.requires_grad_(optimize_pp)
         self.imshape = self.imshapes[0]
         self.register_buffer('_pp', torch.tensor([(w / 2, h / 2) for h, w in self.imshapes], dtype=torch.float32))
         self._grid_cache = None        # (n, max_area, 2) pixel grid of depth_to_pts3d, built on first use on the scene's device
@@ -46,7 +44,7 @@ class PointCloudOptimizer(BasePCOptimizer):
         self.total_area_j = sum(im_areas[j] for i, j in self.edges)
 
     def trainable_names(self):
-        return [k for k in ('pw_poses', 'im_depthmaps', 'im_poses', 'im_focals') if getattr(self, k).requires_grad]
+        return [k for k in ('pw_poses', 'pw_adaptors', 'im_depthmaps', 'im_poses', 'im_focals', 'im_pp') if getattr(self, k).requires_grad]
 
     # ------------------------------------------------------------------ presets (optimizer.py:63-125)
     def _check_all_imgs_are_selected(self, msk):
@@ -96,6 +94,7 @@ class PointCloudOptimizer(BasePCOptimizer):
                 print(f' (setting principal point #{idx} = {pp})')
             self._set_principal_point(idx, pp, force=True)
         self.im_pp.requires_grad_(False)
+        self._destroy_engine()
 
     def _set_focal(self, idx, focal, force=False):
         if self.im_focals.requires_grad or force:
@@ -165,7 +164,7 @@ class PointCloudOptimizer(BasePCOptimizer):
         _lib.require_device()
         if self.device.type != 'cuda':
             raise _lib.D3RError('the aligner is not on a GPU: call .to("cuda") (dust3r_amd has no CPU execution path)')
-        sig = (self.norm_pw_scale, self.im_poses.requires_grad, self.im_focals.requires_grad, self.dist_name,
+        sig = (self.norm_pw_scale, self.im_poses.requires_grad, self.im_focals.requires_grad, self.im_pp.requires_grad, self.pw_adaptors.requires_grad, self.dist_name,
                tuple(getattr(self, k).data_ptr() for k in ('pw_poses', 'im_depthmaps', 'im_poses', 'im_focals', 'im_pp', 'pw_adaptors')))
         if self._engine is not None and sig == self._engine_sig:
             return self._engine
@@ -186,6 +185,8 @@ class PointCloudOptimizer(BasePCOptimizer):
                                          ptr(self.im_focals.data), ptr(self.im_pp.data), float(self.base_scale), float(self.pw_break),
                                          float(self.focal_break), int(self.dist_name == 'l2'), int(self.norm_pw_scale),
                                          int(self.im_poses.requires_grad), int(self.im_focals.requires_grad), 1024), 'aligner_create')
+            check(lib.d3r_aligner_set_option(h, 3, int(self.im_pp.requires_grad)), 'set_option(optimize_pp)')
+            check(lib.d3r_aligner_set_option(h, 4, int(self.pw_adaptors.requires_grad)), 'set_option(allow_pw_adaptors)')
         self._engine, self._engine_sig = h, sig
         return h
 
@@ -194,7 +195,7 @@ class PointCloudOptimizer(BasePCOptimizer):
         """The alignment loss (optimizer.py:188-201), evaluated by the engine (no parameter update)."""
         eng = self._ensure_engine()
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
-        check(lib.d3r_aligner_loss_grad(eng, ptr(loss), None, None, None, None, current_stream()), 'aligner_loss')
+        check(lib.d3r_aligner_loss_grad(eng, ptr(loss), None, None, None, None, None, None, current_stream()), 'aligner_loss')
         return loss[0]
 
     @torch.no_grad()
@@ -202,9 +203,9 @@ class PointCloudOptimizer(BasePCOptimizer):
         """(loss, {name: grad}) of one forward/backward without a step -- the engine's analytic gradients."""
         eng = self._ensure_engine()
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
-        g = {k: torch.zeros_like(getattr(self, k).data) for k in ('pw_poses', 'im_poses', 'im_depthmaps', 'im_focals')}
+        g = {k: torch.zeros_like(getattr(self, k).data) for k in ('pw_poses', 'im_poses', 'im_depthmaps', 'im_focals', 'im_pp', 'pw_adaptors')}
         check(lib.d3r_aligner_loss_grad(eng, ptr(loss), ptr(g['pw_poses']), ptr(g['im_poses']), ptr(g['im_depthmaps']),
-                                        ptr(g['im_focals']), current_stream()), 'aligner_loss_grad')
+                                        ptr(g['im_focals']), ptr(g['im_pp']), ptr(g['pw_adaptors']), current_stream()), 'aligner_loss_grad')
         return loss[0], g
 
     def set_reduction(self, use_dpp=True):

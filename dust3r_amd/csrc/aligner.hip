@@ -303,21 +303,21 @@ __global__ __launch_bounds__(256) void aligner_reduce_kernel(const float* __rest
 struct SmallView {
     int n, E;
     float* pw_poses;     // [E][8]
-    const float* pw_adaptors;  // [E][2]
+    float* pw_adaptors;  // [E][2] (updated when opt_adapt)
     float* im_poses;     // [n][7]
     float* im_focals;    // [n]
-    const float* im_pp;  // [n][2]
+    float* im_pp;        // [n][2] (updated when opt_pp)
     const int* img_w; const int* img_h;
-    float *pw_m, *pw_v, *imp_m, *imp_v, *foc_m, *foc_v;
+    float *pw_m, *pw_v, *imp_m, *imp_v, *foc_m, *foc_v, *pp_m, *pp_v, *pa_m, *pa_v;
     const double* red_edge;  // [2E][16]
     const double* red_img;   // [n][16]
     float* d_edge;           // [E][12]
     float* d_img;            // [n][16]
     double* scratch;         // [E][8]: gradient wrt P_e[0:7] from pass 1, and gs*s~ in slot 7
     float* loss_hist; int iter;
-    float* g_pw; float* g_imp; float* g_foc;  // optional gradient export (tests)
+    float* g_pw; float* g_imp; float* g_foc; float* g_pp; float* g_pa;  // optional gradient export (tests)
     float base_scale, pw_break, focal_break;
-    int norm_pw_scale, opt_poses, opt_focals, update;
+    int norm_pw_scale, opt_poses, opt_focals, opt_pp, opt_adapt, update;
     AdamCoef adam;
 };
 
@@ -379,6 +379,32 @@ __global__ __launch_bounds__(256) void aligner_small_kernel(SmallView s) {
             gP[7] = s.scratch[(size_t)e * 8 + 7] - (s.norm_pw_scale ? sum_gs / (double)s.E : 0.0);
             if (s.g_pw)
                 for (int k = 0; k < 8; ++k) s.g_pw[e * 8 + k] = (float)gP[k];
+            if (s.g_pa || (s.update && s.opt_adapt)) {
+                // pairwise adaptors (base_opt.py:143-149: adapt = exp((A - mean A) / pw_break), A = (a0, a0, a1)): M_e[r][c] =
+                // s~ R[r][c] adapt_c, so dL/d adapt_c = s~ sum_r GM[r][c] R[r][c]; then through exp and the mean-centring
+                float R[9];
+                quat_to_rotmat(P, R);
+                const float a0 = s.pw_adaptors[e * 2], a1 = s.pw_adaptors[e * 2 + 1];
+                const float mean = s.norm_pw_scale ? (2.f * a0 + a1) / 3.f : 0.f;
+                const double ad[3] = {exp((double)(a0 - mean) / s.pw_break), exp((double)(a0 - mean) / s.pw_break), exp((double)(a1 - mean) / s.pw_break)};
+                const double st = exp((double)P[7]) * (double)nf;
+                double gA[3], tot = 0.0;
+                for (int c = 0; c < 3; ++c) {
+                    double gc = 0.0;
+                    for (int r = 0; r < 3; ++r)
+                        gc += (s.red_edge[(size_t)(2 * e) * PW + r * 4 + c] + s.red_edge[(size_t)(2 * e + 1) * PW + r * 4 + c]) * (double)R[r * 3 + c];
+                    gA[c] = gc * st * ad[c] / (double)s.pw_break;      // dL/d((A_c - mean) / b) chain through exp
+                    tot += gA[c];
+                }
+                if (s.norm_pw_scale)
+                    for (int c = 0; c < 3; ++c) gA[c] -= tot / 3.0;
+                const double g0 = gA[0] + gA[1], g1 = gA[2];
+                if (s.g_pa) { s.g_pa[e * 2] = (float)g0; s.g_pa[e * 2 + 1] = (float)g1; }
+                if (s.update && s.opt_adapt) {
+                    s.pw_adaptors[e * 2] = adam_update(a0, (float)g0, s.pa_m[e * 2], s.pa_v[e * 2], s.adam);
+                    s.pw_adaptors[e * 2 + 1] = adam_update(a1, (float)g1, s.pa_m[e * 2 + 1], s.pa_v[e * 2 + 1], s.adam);
+                }
+            }
             if (s.update)
                 for (int k = 0; k < 8; ++k) P[k] = adam_update(P[k], (float)gP[k], s.pw_m[e * 8 + k], s.pw_v[e * 8 + k], s.adam);
         }
@@ -396,7 +422,21 @@ __global__ __launch_bounds__(256) void aligner_small_kernel(SmallView s) {
             if (s.g_foc) s.g_foc[i] = (float)gf;
             if (s.update && s.opt_poses)
                 for (int k = 0; k < 7; ++k) P[k] = adam_update(P[k], (float)gP[k], s.imp_m[i * 7 + k], s.imp_v[i * 7 + k], s.adam);
+            const float focal_param_old = s.im_focals[i];
             if (s.update && s.opt_focals) s.im_focals[i] = adam_update(s.im_focals[i], (float)gf, s.foc_m[i], s.foc_v[i], s.adam);
+            if (s.g_pp || (s.update && s.opt_pp)) {
+                // principal point (optimizer.py:141-142: pp = (W/2, H/2) + 10 im_pp): dX/dppx = -exp(d)/F R[:,0], so
+                // dL/d im_pp = -(10 / F) (R^T S)_{0,1} with S = sum_p g_p exp(d_p), the record's last three sums
+                const double F = exp((double)focal_param_old / (double)s.focal_break);   // the focal the gradients were taken at
+                const double S0 = s.red_img[(size_t)i * PW + 12], S1 = s.red_img[(size_t)i * PW + 13], S2 = s.red_img[(size_t)i * PW + 14];
+                const double gx = -(10.0 / F) * ((double)R[0] * S0 + (double)R[3] * S1 + (double)R[6] * S2);
+                const double gy = -(10.0 / F) * ((double)R[1] * S0 + (double)R[4] * S1 + (double)R[7] * S2);
+                if (s.g_pp) { s.g_pp[i * 2] = (float)gx; s.g_pp[i * 2 + 1] = (float)gy; }
+                if (s.update && s.opt_pp) {
+                    s.im_pp[i * 2] = adam_update(s.im_pp[i * 2], (float)gx, s.pp_m[i * 2], s.pp_v[i * 2], s.adam);
+                    s.im_pp[i * 2 + 1] = adam_update(s.im_pp[i * 2 + 1], (float)gy, s.pp_m[i * 2 + 1], s.pp_v[i * 2 + 1], s.adam);
+                }
+            }
         }
         __syncthreads();   // the updated P7 values are read by other threads below
     }
@@ -451,12 +491,13 @@ struct d3r_aligner {
     float* planar = nullptr;  // [2][E][3][maxA] re-laid-out copies of pred_i / pred_j
     float *pw_poses = nullptr, *pw_adaptors = nullptr, *im_poses = nullptr, *im_depth = nullptr, *im_focals = nullptr, *im_pp = nullptr;
     float* state = nullptr;  // one arena: Adam moments, derived matrices, partials
-    float *depth_m, *depth_v, *pw_m, *pw_v, *imp_m, *imp_v, *foc_m, *foc_v, *d_edge, *d_img, *part_edge, *part_img, *loss_hist, *g_scratch;
+    float *depth_m, *depth_v, *pw_m, *pw_v, *imp_m, *imp_v, *foc_m, *foc_v, *pp_m, *pp_v, *pa_m, *pa_v, *d_edge, *d_img, *part_edge, *part_img, *loss_hist, *g_scratch;
     double *red_edge, *red_img, *scratch;
     size_t state_bytes = 0;
     float base_scale = 0.5f, pw_break = 20.f, focal_break = 20.f, inv_area[2] = {0, 0};
-    int l2 = 0, norm_pw_scale = 1, opt_poses = 1, opt_focals = 1, use_dpp = 1;
+    int l2 = 0, norm_pw_scale = 1, opt_poses = 1, opt_focals = 1, opt_pp = 0, opt_adapt = 0, use_dpp = 1;
     long step = 0;
+    bool reset_pending = false;   // D3R_ALIGNER_OPT_RESET_ADAM: cleared on the next run's stream
     int loss_cap = 0;
 };
 
@@ -510,6 +551,7 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     auto take = [&](size_t cnt) { size_t o = fl; fl += (cnt + 3) & ~(size_t)3; return o; };
     const size_t o_dm = take(nA), o_dv = take(nA), o_pwm = take((size_t)n_edges * 8), o_pwv = take((size_t)n_edges * 8),
                  o_im = take((size_t)n_imgs * 7), o_iv = take((size_t)n_imgs * 7), o_fm = take(n_imgs), o_fv = take(n_imgs),
+                 o_pm = take((size_t)n_imgs * 2), o_pv = take((size_t)n_imgs * 2), o_am = take((size_t)n_edges * 2), o_av = take((size_t)n_edges * 2),
                  o_de = take((size_t)n_edges * 12), o_di = take((size_t)n_imgs * 16),
                  o_pe = take((size_t)2 * n_edges * a->nslot * PW), o_pi = take((size_t)n_imgs * a->nslot * PW),
                  o_lh = take(a->loss_cap), o_gs = take((size_t)n_edges * 8);
@@ -519,7 +561,7 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     (void)hipMemset(a->state, 0, a->state_bytes);
     float* b = a->state;
     a->depth_m = b + o_dm; a->depth_v = b + o_dv; a->pw_m = b + o_pwm; a->pw_v = b + o_pwv; a->imp_m = b + o_im;
-    a->imp_v = b + o_iv; a->foc_m = b + o_fm; a->foc_v = b + o_fv; a->d_edge = b + o_de; a->d_img = b + o_di;
+    a->imp_v = b + o_iv; a->foc_m = b + o_fm; a->foc_v = b + o_fv; a->pp_m = b + o_pm; a->pp_v = b + o_pv; a->pa_m = b + o_am; a->pa_v = b + o_av; a->d_edge = b + o_de; a->d_img = b + o_di;
     a->part_edge = b + o_pe; a->part_img = b + o_pi; a->loss_hist = b + o_lh; a->g_scratch = b + o_gs;
     double* db = reinterpret_cast<double*>(reinterpret_cast<char*>(b) + ((fl * sizeof(float) + 63) & ~(size_t)63));
     a->red_edge = db; a->red_img = db + (size_t)2 * n_edges * PW; a->scratch = a->red_img + (size_t)n_imgs * PW;
@@ -564,11 +606,13 @@ static AdamCoef adam_coef(double lr, long step) {
 }
 
 static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, float* g_pw, float* g_imp, float* g_depth, float* g_foc,
-                        bool refresh_derived_first, hipStream_t st) {
+                        bool refresh_derived_first, hipStream_t st, float* g_pp = nullptr, float* g_pa = nullptr) {
     SmallView s;
     s.n = a->n; s.E = a->E; s.pw_poses = a->pw_poses; s.pw_adaptors = a->pw_adaptors; s.im_poses = a->im_poses;
     s.im_focals = a->im_focals; s.im_pp = a->im_pp; s.img_w = a->d_w; s.img_h = a->d_h;
     s.pw_m = a->pw_m; s.pw_v = a->pw_v; s.imp_m = a->imp_m; s.imp_v = a->imp_v; s.foc_m = a->foc_m; s.foc_v = a->foc_v;
+    s.pp_m = a->pp_m; s.pp_v = a->pp_v; s.g_pp = nullptr; s.opt_pp = a->opt_pp;
+    s.pa_m = a->pa_m; s.pa_v = a->pa_v; s.g_pa = nullptr; s.opt_adapt = a->opt_adapt;
     s.red_edge = a->red_edge; s.red_img = a->red_img; s.d_edge = a->d_edge; s.d_img = a->d_img; s.scratch = a->scratch;
     s.loss_hist = a->loss_hist; s.iter = hist_idx; s.g_pw = nullptr; s.g_imp = nullptr; s.g_foc = nullptr;
     s.base_scale = a->base_scale; s.pw_break = a->pw_break; s.focal_break = a->focal_break;
@@ -599,7 +643,7 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
     // part_edge | part_img and red_edge | red_img are contiguous: one launch reduces the 2E + n entries
     hipLaunchKernelGGL(aligner_reduce_kernel, dim3(2 * a->E + a->n), dim3(256), 0, st, a->part_edge, a->red_edge, a->nslot);
     s.update = update ? 1 : 0;
-    s.g_pw = g_pw; s.g_imp = g_imp; s.g_foc = g_foc;
+    s.g_pw = g_pw; s.g_imp = g_imp; s.g_foc = g_foc; s.g_pp = g_pp; s.g_pa = g_pa;
     hipLaunchKernelGGL(aligner_small_kernel, dim3(1), dim3(256), 0, st, s);
     if (update) a->step++;
     return hipGetLastError() == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
@@ -609,8 +653,12 @@ extern "C" int d3r_aligner_set_option(d3r_aligner* a, int option, int value) {
     if (!a) return D3R_ERR_INVALID;
     switch (option) {
         case D3R_ALIGNER_OPT_DPP_REDUCE: a->use_dpp = value; return D3R_OK;
+        case D3R_ALIGNER_OPT_OPTIMIZE_PP: a->opt_pp = value != 0; return D3R_OK;
+        case D3R_ALIGNER_OPT_OPTIMIZE_ADAPTORS: a->opt_adapt = value != 0; return D3R_OK;
         case D3R_ALIGNER_OPT_RESET_ADAM:
-            (void)hipMemset(a->depth_m, 0, (size_t)((char*)a->d_edge - (char*)a->depth_m));
+            // the moments are cleared on the stream of the NEXT d3r_aligner_run / loss_grad call (ordered against the iterations that
+            // are still in flight there), not on the legacy NULL stream
+            a->reset_pending = true;
             a->step = 0;
             return D3R_OK;
     }
@@ -623,6 +671,10 @@ extern "C" int d3r_aligner_run(d3r_aligner* a, int niter, int iter0, int niter_t
                                float* losses_out_device, void* stream) {
     if (!a || niter <= 0 || niter > a->loss_cap || niter_total <= 0) return D3R_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    if (a->reset_pending) {
+        HIPCHK(hipMemsetAsync(a->depth_m, 0, (size_t)((char*)a->d_edge - (char*)a->depth_m), st));
+        a->reset_pending = false;
+    }
     for (int k = 0; k < niter; ++k) {
         const double t = (double)(iter0 + k) / (double)niter_total;
         const double lr = schedule == D3R_SCHEDULE_COSINE ? (double)lr_min + ((double)lr_base - (double)lr_min) * (1.0 + cos(t * M_PI)) / 2.0
@@ -636,11 +688,11 @@ extern "C" int d3r_aligner_run(d3r_aligner* a, int niter, int iter0, int niter_t
 
 // one forward/backward WITHOUT a step: loss (device float[1]) and gradients (device, any may be null)
 extern "C" int d3r_aligner_loss_grad(d3r_aligner* a, float* loss_device, float* g_pw_poses, float* g_im_poses, float* g_im_depth,
-                                     float* g_im_focals, void* stream) {
+                                     float* g_im_focals, float* g_im_pp, float* g_pw_adaptors, void* stream) {
     if (!a) return D3R_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     float* gpw = g_pw_poses ? g_pw_poses : a->g_scratch;  // forces the gradient branch of the small kernel
-    const int rc = aligner_pass(a, false, 0.0, 0, gpw, g_im_poses, g_im_depth, g_im_focals, true, st);
+    const int rc = aligner_pass(a, false, 0.0, 0, gpw, g_im_poses, g_im_depth, g_im_focals, true, st, g_im_pp, g_pw_adaptors);
     if (rc != D3R_OK) return rc;
     if (loss_device) HIPCHK(hipMemcpyAsync(loss_device, a->loss_hist, sizeof(float), hipMemcpyDeviceToDevice, st));
     return D3R_OK;

@@ -14,6 +14,8 @@
 //   and no transposing LDS read is needed -- V^T rows are read as two 4-key groups.
 //   K / V^T tiles (64 keys) are staged through LDS (padded rows: conflict-free b128 / b64 reads),
 //   double buffered with the global loads of tile t+1 in flight during the math of tile t.
+#include <atomic>
+
 #include "kernels.hpp"
 
 namespace d3r {
@@ -248,11 +250,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
 }
 
 template <int DT> static hipError_t launch_t(const AttnParams& p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device function attribute: raise it once on every device this process launches on
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    const unsigned long long dev_bit = 1ull << (dev_id & 63);
+    if (!(attr_done.load(std::memory_order_relaxed) & dev_bit)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   AttnCfg<DT>::LDS);
-        attr_set = true;
+        attr_done.fetch_or(dev_bit, std::memory_order_relaxed);
     }
     const int grid = p.B * p.H * ((p.Nq + 127) / 128);
     hipLaunchKernelGGL(attention_kernel<DT>, dim3(grid), dim3(256), AttnCfg<DT>::LDS, s, p);

@@ -352,8 +352,10 @@ extern "C" const char* d3r_version(void) { return "dust3r_amd 0.1 (gfx950)"; }
 extern "C" int d3r_device_check(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return D3R_ERR_STATE;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return D3R_ERR_STATE;     // the CURRENT device is the one the engine will run on
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return D3R_ERR_STATE;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return D3R_ERR_STATE;
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? D3R_OK : D3R_ERR_STATE;
 }
 
@@ -365,7 +367,7 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     if (!m) return D3R_ERR_ALLOC;
     m->cfg = *cfg; m->dt = cfg->dtype; m->ktile = 128 / (int)dt_bytes(cfg->dtype);
     if (cfg->enc_embed_dim % m->ktile || cfg->dec_embed_dim % m->ktile || (3 * cfg->patch_size * cfg->patch_size) % m->ktile ||
-        (cfg->head_type == 1 && cfg->dec_depth <= 9)) { delete m; return D3R_ERR_INVALID; }
+        (cfg->head_type == 1 && (cfg->dec_depth <= 9 || cfg->patch_size != 16))) { delete m; return D3R_ERR_INVALID; }   // run_dpt assumes 16 x th == H
     if (!build_slots(m)) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
     m->rope_table = (float*)m->dalloc(512 * 16 * 2 * sizeof(float));
     m->zero_page = m->dalloc(4096);
@@ -607,44 +609,66 @@ size_t dpt_arena_bytes(const d3r_model* m, const DptHead& D, int bc, int th, int
 // heads run over B pairs whose features are feat[0..B) (view 1) and feat[B..2B) (view 2). forward = both phases with
 // feat inside the workspace; encode / decode run one phase with a caller-owned feature buffer.
 enum { PH_ENCODE = 1, PH_DECODE = 2 };
+// The two views of a pair may have different sizes (dust3r/model.py:148-150: the reference then encodes them separately): every
+// per-side quantity of the decoder / heads is indexed by side -- token grid (th, tw), tokens per image N, rows M = B N, V^T row
+// stride -- and cross attention runs Nq != Nk. With equal sizes this is the old schedule bit for bit.
+struct SideDim { int H, W, th, tw, N, ldv; };
+static SideDim side_dim(int H, int W, int ps) {
+    SideDim d;
+    d.H = H; d.W = W; d.th = H / ps; d.tw = W / ps; d.N = d.th * d.tw; d.ldv = rup(d.N, 64);
+    return d;
+}
+
 size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const float* img1, const float* img2, int nimg1, int nimg, void* feat_ext,
-                    int B, int H, int W, float* pts1, float* conf1, float* pts2, float* conf2, hipStream_t st, int* rc_out) {
+                    int B, SideDim d0, SideDim d1, float* pts1, float* conf1, float* pts2, float* conf2, hipStream_t st, int* rc_out) {
     const d3r_model_config& cf = m->cfg;
-    const int ps = cf.patch_size, th = H / ps, tw = W / ps, N = th * tw;
+    const int ps = cf.patch_size;
+    const SideDim D[2] = {d0, d1};
+    const bool same = d0.H == d1.H && d0.W == d1.W;
     const int Ce = cf.enc_embed_dim, Cd = cf.dec_embed_dim, He = cf.enc_num_heads, Hd = cf.dec_num_heads;
+    const int Cmax = Ce > Cd ? Ce : Cd, Hmax = He > Hd ? He : Hd;     // shared scratch is sized for the wider of encoder / decoder
     const bool do_enc = (phases & PH_ENCODE) != 0, do_dec = (phases & PH_DECODE) != 0;
-    const int Me = do_enc ? nimg * N : 0;                    // encoder rows
-    const int M1 = do_dec ? B * N : 0, M2d = 2 * M1;         // decoder rows per side / both sides
-    const int M2 = Me > M2d ? Me : M2d;                      // rows of the shared scratch buffers
+    // encoder rows: one pass over all images when the views share a size, else one pass per view (view 1 rows first)
+    const int Me = !do_enc ? 0 : (same ? nimg * d0.N : nimg1 * d0.N + (nimg - nimg1) * d1.N);
+    const int Ms[2] = {do_dec ? B * d0.N : 0, do_dec ? B * d1.N : 0};     // decoder rows per side
+    const int Roff[2] = {0, Ms[0]};                                       // first row of a side in the two-sided buffers
+    const int M2d = Ms[0] + Ms[1];
+    const int Mmax = Ms[0] > Ms[1] ? Ms[0] : Ms[1];                       // a side's scratch part holds its own rows OR the other view's (cross attention)
+    const int M2 = Me > 2 * Mmax ? Me : 2 * Mmax;                         // rows of the shared scratch buffers
+    const int ldv_max = d0.ldv > d1.ldv ? d0.ldv : d1.ldv;
     const int nvt = (do_enc ? nimg : 0) > 2 * (do_dec ? B : 0) ? nimg : 2 * B;   // images the v^T buffer must hold
-    const int ldv = rup(N, 64);
     const size_t eb = dt_bytes(m->dt);
     const bool dry = ws == nullptr;
     Arena ar(ws, ws_cap);
     Ctx c{m, st};
 
     float* x = (float*)ar.take((size_t)Me * Ce * 4);
-    void* xn = ar.take((size_t)M2 * Ce * eb);
-    void* q = ar.take((size_t)M2 * Ce * eb);
-    void* k = ar.take((size_t)M2 * Ce * eb);
-    void* vt = ar.take((size_t)nvt * He * 64 * ldv * eb);
-    void* ao = ar.take((size_t)M2 * Ce * eb);
-    void* hb = ar.take((size_t)M2 * 4 * Ce * eb);   // MLP hidden; also holds the gathered patches
+    void* xn = ar.take((size_t)M2 * Cmax * eb);
+    void* q = ar.take((size_t)M2 * Cmax * eb);
+    void* k = ar.take((size_t)M2 * Cmax * eb);
+    void* vt = ar.take((size_t)nvt * Hmax * 64 * ldv_max * eb);
+    void* ao = ar.take((size_t)M2 * Cmax * eb);
+    void* hb = ar.take((size_t)M2 * 4 * Cmax * eb);   // MLP hidden; also holds the gathered patches
     void* encn = feat_ext ? feat_ext : ar.take((size_t)(Me > M2d ? Me : M2d) * Ce * eb);
     float* f[2] = {(float*)ar.take((size_t)M2d * Cd * 4), (float*)ar.take((size_t)M2d * Cd * 4)};
-    void* yn = ar.take((size_t)M2d * Cd * eb);
+    void* yn = ar.take((size_t)2 * Mmax * Cd * eb);
     void* hook[2][3];
     for (int s = 0; s < 2; ++s)
-        for (int j = 0; j < 3; ++j) hook[s][j] = ar.take((size_t)M1 * Cd * eb);
+        for (int j = 0; j < 3; ++j) hook[s][j] = ar.take((size_t)Ms[s] * Cd * eb);
     float* lin_out = cf.head_type == 0 ? (float*)ar.take((size_t)M2d * 4 * ps * ps * 4) : nullptr;
     const size_t common_end = (ar.off + 255) & ~(size_t)255;
     const int chunk = B < 32 ? B : 32;   // 288 GB of HBM: batch the head as wide as the encoder (low-resolution stages need the rows)
-    const size_t head_arena = (cf.head_type == 1 && do_dec) ? dpt_arena_bytes(m, m->dpt[0], chunk, th, tw) : 0;
+    size_t head_arena = 0;
+    if (cf.head_type == 1 && do_dec)
+        for (int s = 0; s < 2; ++s) {
+            const size_t a = dpt_arena_bytes(m, m->dpt[0], chunk, D[s].th, D[s].tw);
+            head_arena = a > head_arena ? a : head_arena;
+        }
 
     if (!dry) {
         // stream plan: encoder on the caller's stream; then side 0 stays there and side 1 runs on the model's second
         // stream, re-joined at every layer boundary (each side reads the other's previous-layer output) and at the end.
-        // Each side has its own half of every scratch buffer and its own head arena.
+        // Each side has its own part of every scratch buffer and its own head arena.
         const bool two = m->two_streams && !m->prof_on && m->side != nullptr;
         hipStream_t S[2] = {st, two ? m->side : st};
         auto cross_sync = [&]() {
@@ -654,23 +678,37 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
             c.chk(hipStreamWaitEvent(S[0], m->ev_side, 0));
             c.chk(hipStreamWaitEvent(S[1], m->ev_main, 0));
         };
-        if (ldv != N) D3R_OTHER(hipMemsetAsync(vt, 0, (size_t)nvt * He * 64 * ldv * eb, st));
+        if (d0.ldv != d0.N || d1.ldv != d1.N) D3R_OTHER(hipMemsetAsync(vt, 0, (size_t)nvt * Hmax * 64 * ldv_max * eb, st));
         if (do_enc) {
-            // ---- encoder: all images of the call in one pass (model.py:142-151 concatenates the two views) --------
+            // ---- encoder: all images of the call in one pass when the views share a size (model.py:142-151 concatenates the
+            // two views), else view 1's images then view 2's (model.py:148-150) -----------------------------------------------
             const size_t pk = 3 * (size_t)ps * ps;
-            if (nimg1 > 0) D3R_OTHER(launch_patchify(m->dt, img1, hb, nimg1, H, W, ps, st));
-            if (nimg > nimg1) D3R_OTHER(launch_patchify(m->dt, img2, (char*)hb + (size_t)nimg1 * N * pk * eb, nimg - nimg1, H, W, ps, st));
-            gemm_linear(c, hb, (int)pk, m->patch, Me, EPI_F32, x, Ce);
-            for (int l = 0; l < cf.enc_depth; ++l) {
-                const EncBlk& b = m->enc[l];
-                D3R_OTHER(launch_layernorm(m->dt, x, b.n1.g, b.n1.b, xn, Me, Ce, 1e-6f, st));
-                self_attention(c, xn, b.qkv, Me, Ce, He, nimg, N, tw, ldv, q, k, vt, ao);
-                gemm_linear(c, ao, Ce, b.proj, Me, EPI_F32, x, Ce, x);
-                D3R_OTHER(launch_layernorm(m->dt, x, b.n2.g, b.n2.b, xn, Me, Ce, 1e-6f, st));
-                gemm_linear(c, xn, Ce, b.fc1, Me, EPI_GELU, hb, 4 * Ce);
-                gemm_linear(c, hb, 4 * Ce, b.fc2, Me, EPI_F32, x, Ce, x);
+            const int npass = same ? 1 : 2;
+            for (int pass = 0; pass < npass; ++pass) {
+                const SideDim& dd = D[pass];
+                const int n_img = same ? nimg : (pass == 0 ? nimg1 : nimg - nimg1);
+                if (n_img <= 0) continue;
+                const int Mp = n_img * dd.N;
+                const size_t row0 = (same || pass == 0) ? 0 : (size_t)nimg1 * d0.N;
+                float* xp = x + row0 * Ce;
+                if (same) {
+                    if (nimg1 > 0) D3R_OTHER(launch_patchify(m->dt, img1, hb, nimg1, dd.H, dd.W, ps, st));
+                    if (nimg > nimg1) D3R_OTHER(launch_patchify(m->dt, img2, (char*)hb + (size_t)nimg1 * dd.N * pk * eb, nimg - nimg1, dd.H, dd.W, ps, st));
+                } else {
+                    D3R_OTHER(launch_patchify(m->dt, pass == 0 ? img1 : img2, hb, n_img, dd.H, dd.W, ps, st));
+                }
+                gemm_linear(c, hb, (int)pk, m->patch, Mp, EPI_F32, xp, Ce);
+                for (int l = 0; l < cf.enc_depth; ++l) {
+                    const EncBlk& b = m->enc[l];
+                    D3R_OTHER(launch_layernorm(m->dt, xp, b.n1.g, b.n1.b, xn, Mp, Ce, 1e-6f, st));
+                    self_attention(c, xn, b.qkv, Mp, Ce, He, n_img, dd.N, dd.tw, dd.ldv, q, k, vt, ao);
+                    gemm_linear(c, ao, Ce, b.proj, Mp, EPI_F32, xp, Ce, xp);
+                    D3R_OTHER(launch_layernorm(m->dt, xp, b.n2.g, b.n2.b, xn, Mp, Ce, 1e-6f, st));
+                    gemm_linear(c, xn, Ce, b.fc1, Mp, EPI_GELU, hb, 4 * Ce);
+                    gemm_linear(c, hb, 4 * Ce, b.fc2, Mp, EPI_F32, xp, Ce, xp);
+                }
+                D3R_OTHER(launch_layernorm(m->dt, xp, m->enc_norm.g, m->enc_norm.b, (char*)encn + row0 * Ce * eb, Mp, Ce, 1e-6f, st));
             }
-            D3R_OTHER(launch_layernorm(m->dt, x, m->enc_norm.g, m->enc_norm.b, encn, Me, Ce, 1e-6f, st));
             m->last_encn = encn; m->last_encn_elems = (size_t)Me * Ce;
         }
         if (do_dec) {
@@ -685,42 +723,44 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
         for (int l = 0; l < cf.dec_depth; ++l) {
             for (int s = 0; s < 2; ++s) {
                 c.st = S[s];
-                // this side's half of the scratch buffers (the encoder used them whole)
-                void* sxn = (char*)xn + (size_t)s * M1 * Ce * eb;
-                void* sq = (char*)q + (size_t)s * M1 * Ce * eb;
-                void* sk = (char*)k + (size_t)s * M1 * Ce * eb;
-                void* svt = (char*)vt + (size_t)s * B * He * 64 * ldv * eb;
-                void* sao = (char*)ao + (size_t)s * M1 * Ce * eb;
-                void* shb = (char*)hb + (size_t)s * M1 * 4 * Ce * eb;
-                void* syn = (char*)yn + (size_t)s * M1 * Cd * eb;
+                const SideDim& own = D[s];
+                const SideDim& oth = D[1 - s];
+                // this side's part of the scratch buffers (the encoder used them whole)
+                void* sxn = (char*)xn + (size_t)s * Mmax * Cmax * eb;
+                void* sq = (char*)q + (size_t)s * Mmax * Cmax * eb;
+                void* sk = (char*)k + (size_t)s * Mmax * Cmax * eb;
+                void* svt = (char*)vt + (size_t)s * B * Hmax * 64 * ldv_max * eb;
+                void* sao = (char*)ao + (size_t)s * Mmax * Cmax * eb;
+                void* shb = (char*)hb + (size_t)s * Mmax * 4 * Cmax * eb;
+                void* syn = (char*)yn + (size_t)s * Mmax * Cd * eb;         // norm_y of the OTHER view's tokens (Ms[1 - s] <= Mmax rows)
                 const DecBlk& b = m->dec[s][l];
-                const float* xo = f[cur] + (size_t)s * M1 * Cd;         // own stream (old)
-                const float* yo = f[cur] + (size_t)(1 - s) * M1 * Cd;   // other view (old)
-                float* xw = f[cur ^ 1] + (size_t)s * M1 * Cd;           // own stream (new)
-                D3R_OTHER(launch_layernorm(m->dt, xo, b.n1.g, b.n1.b, sxn, M1, Cd, 1e-6f, c.st));
-                self_attention(c, sxn, b.qkv, M1, Cd, Hd, B, N, tw, ldv, sq, sk, svt, sao);
-                gemm_linear(c, sao, Cd, b.proj, M1, EPI_F32, xw, Cd, xo);
-                // cross attention: q from norm2(x), k/v from norm_y(y)
-                D3R_OTHER(launch_layernorm(m->dt, yo, b.ny.g, b.ny.b, syn, M1, Cd, 1e-6f, c.st));
-                D3R_OTHER(launch_layernorm(m->dt, xw, b.n2.g, b.n2.b, sxn, M1, Cd, 1e-6f, c.st));
+                const float* xo = f[cur] + (size_t)Roff[s] * Cd;         // own stream (old)
+                const float* yo = f[cur] + (size_t)Roff[1 - s] * Cd;     // other view (old)
+                float* xw = f[cur ^ 1] + (size_t)Roff[s] * Cd;           // own stream (new)
+                D3R_OTHER(launch_layernorm(m->dt, xo, b.n1.g, b.n1.b, sxn, Ms[s], Cd, 1e-6f, c.st));
+                self_attention(c, sxn, b.qkv, Ms[s], Cd, Hd, B, own.N, own.tw, own.ldv, sq, sk, svt, sao);
+                gemm_linear(c, sao, Cd, b.proj, Ms[s], EPI_F32, xw, Cd, xo);
+                // cross attention: q from norm2(x), k/v from norm_y(y): Nk = the other view's token count
+                D3R_OTHER(launch_layernorm(m->dt, yo, b.ny.g, b.ny.b, syn, Ms[1 - s], Cd, 1e-6f, c.st));
+                D3R_OTHER(launch_layernorm(m->dt, xw, b.n2.g, b.n2.b, sxn, Ms[s], Cd, 1e-6f, c.st));
                 {
                     const int kq[1] = {HEAD_ROPE};
                     void* dq[1] = {sq};
-                    gemm_heads(c, sxn, Cd, b.cq, M1, Cd, 1, kq, dq, Hd, N, tw, ldv);
+                    gemm_heads(c, sxn, Cd, b.cq, Ms[s], Cd, 1, kq, dq, Hd, own.N, own.tw, own.ldv);
                     const int kkv[2] = {HEAD_ROPE, HEAD_VT};
                     void* dkv[2] = {sk, svt};
-                    gemm_heads(c, syn, Cd, b.ckv, M1, Cd, 2, kkv, dkv, Hd, N, tw, ldv);
+                    gemm_heads(c, syn, Cd, b.ckv, Ms[1 - s], Cd, 2, kkv, dkv, Hd, oth.N, oth.tw, oth.ldv);
                     AttnParams a;
-                    a.q = sq; a.k = sk; a.vt = svt; a.out = sao; a.B = B; a.H = Hd; a.Nq = N; a.Nk = N; a.ldv = ldv; a.scale = 0.125f;
-                    c.mark(PRF_ATTN, 4.0 * B * Hd * (double)N * N * 64, B * Hd, N, N);
+                    a.q = sq; a.k = sk; a.vt = svt; a.out = sao; a.B = B; a.H = Hd; a.Nq = own.N; a.Nk = oth.N; a.ldv = oth.ldv; a.scale = 0.125f;
+                    c.mark(PRF_ATTN, 4.0 * B * Hd * (double)own.N * oth.N * 64, B * Hd, own.N, oth.N);
                     c.chk(launch_attention(m->dt, a, c.st));
                 }
-                gemm_linear(c, sao, Cd, b.cproj, M1, EPI_F32, xw, Cd, xw);
-                D3R_OTHER(launch_layernorm(m->dt, xw, b.n3.g, b.n3.b, sxn, M1, Cd, 1e-6f, c.st));
-                gemm_linear(c, sxn, Cd, b.fc1, M1, EPI_GELU, shb, 4 * Cd);
+                gemm_linear(c, sao, Cd, b.cproj, Ms[s], EPI_F32, xw, Cd, xw);
+                D3R_OTHER(launch_layernorm(m->dt, xw, b.n3.g, b.n3.b, sxn, Ms[s], Cd, 1e-6f, c.st));
+                gemm_linear(c, sxn, Cd, b.fc1, Ms[s], EPI_GELU, shb, 4 * Cd);
                 const int layer_no = l + 1;
                 void* hcopy = (cf.head_type == 1 && (layer_no == hk6 || layer_no == hk9)) ? hook[s][layer_no == hk6 ? 0 : 1] : nullptr;
-                gemm_linear(c, shb, 4 * Cd, b.fc2, M1, EPI_F32, xw, Cd, xw, hcopy, Cd);
+                gemm_linear(c, shb, 4 * Cd, b.fc2, Ms[s], EPI_F32, xw, Cd, xw, hcopy, Cd);
             }
             cross_sync();
             cur ^= 1;
@@ -730,19 +770,21 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
         float* cnf[2] = {conf1, conf2};
         for (int s = 0; s < 2; ++s) {
             c.st = S[s];
-            D3R_OTHER(launch_layernorm(m->dt, f[cur] + (size_t)s * M1 * Cd, m->dec_norm.g, m->dec_norm.b, hook[s][2], M1, Cd, 1e-6f, c.st));
+            const SideDim& own = D[s];
+            D3R_OTHER(launch_layernorm(m->dt, f[cur] + (size_t)Roff[s] * Cd, m->dec_norm.g, m->dec_norm.b, hook[s][2], Ms[s], Cd, 1e-6f, c.st));
             if (cf.head_type == 0) {
-                float* lo = lin_out + (size_t)s * M1 * 4 * ps * ps;
-                gemm_linear(c, hook[s][2], Cd, m->lin_head[s], M1, EPI_F32, lo, 4 * ps * ps);
-                D3R_OTHER(launch_linear_head_post(lo, pts[s], cnf[s], B, th, tw, ps, m->out_pstride, m->out_cstride, c.st));
+                float* lo = lin_out + (size_t)Roff[s] * 4 * ps * ps;
+                gemm_linear(c, hook[s][2], Cd, m->lin_head[s], Ms[s], EPI_F32, lo, 4 * ps * ps);
+                D3R_OTHER(launch_linear_head_post(lo, pts[s], cnf[s], B, own.th, own.tw, ps, m->out_pstride, m->out_cstride, c.st));
             } else {
                 for (int b0 = 0; b0 < B; b0 += chunk) {
                     const int bc = (B - b0) < chunk ? (B - b0) : chunk;
                     Arena sub((char*)ws + common_end + (size_t)s * head_arena, head_arena);
-                    const void* hooks[4] = {(const char*)encn + ((size_t)s * M1 + (size_t)b0 * N) * Ce * eb, (const char*)hook[s][0] + (size_t)b0 * N * Cd * eb,
-                                            (const char*)hook[s][1] + (size_t)b0 * N * Cd * eb, (const char*)hook[s][2] + (size_t)b0 * N * Cd * eb};
+                    const void* hooks[4] = {(const char*)encn + ((size_t)Roff[s] + (size_t)b0 * own.N) * Ce * eb, (const char*)hook[s][0] + (size_t)b0 * own.N * Cd * eb,
+                                            (const char*)hook[s][1] + (size_t)b0 * own.N * Cd * eb, (const char*)hook[s][2] + (size_t)b0 * own.N * Cd * eb};
                     const int hc[4] = {Ce, Cd, Cd, Cd};
-                    run_dpt(c, m->dpt[s], sub, hooks, hc, bc, th, tw, pts[s] + (size_t)b0 * H * W * m->out_pstride, cnf[s] + (size_t)b0 * H * W * m->out_cstride);
+                    run_dpt(c, m->dpt[s], sub, hooks, hc, bc, own.th, own.tw, pts[s] + (size_t)b0 * own.H * own.W * m->out_pstride,
+                            cnf[s] + (size_t)b0 * own.H * own.W * m->out_cstride);
                 }
             }
         }
@@ -760,12 +802,16 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
 
 }  // namespace
 
-static int run_phases(d3r_model* m, int phases, const float* img1, const float* img2, int nimg1, int nimg, void* feat, int B, int H, int W,
-                      float* pts1, float* conf1, float* pts2, float* conf2, hipStream_t st) {
+static int run_phases(d3r_model* m, int phases, const float* img1, const float* img2, int nimg1, int nimg, void* feat, int B, int H1, int W1,
+                      int H2, int W2, float* pts1, float* conf1, float* pts2, float* conf2, hipStream_t st) {
     const int ps = m->cfg.patch_size;
-    if (H % ps || W % ps || H <= 0 || W <= 0 || H / ps > 511 || W / ps > 511) return D3R_ERR_SHAPE;
+    for (int v = 0; v < 2; ++v) {
+        const int H = v ? H2 : H1, W = v ? W2 : W1;
+        if (H % ps || W % ps || H <= 0 || W <= 0 || H / ps > 511 || W / ps > 511) return D3R_ERR_SHAPE;
+    }
     if (d3r_model_missing(m) != 0) return D3R_ERR_STATE;
-    const size_t need = forward_impl(m, nullptr, 0, phases, img1, img2, nimg1, nimg, feat, B, H, W, pts1, conf1, pts2, conf2, st, nullptr);
+    const SideDim d0 = side_dim(H1, W1, ps), d1 = side_dim(H2, W2, ps);
+    const size_t need = forward_impl(m, nullptr, 0, phases, img1, img2, nimg1, nimg, feat, B, d0, d1, pts1, conf1, pts2, conf2, st, nullptr);
     if (need > m->ws_bytes) {
         (void)hipStreamSynchronize(st);
         if (m->side) (void)hipStreamSynchronize(m->side);
@@ -776,20 +822,26 @@ static int run_phases(d3r_model* m, int phases, const float* img1, const float* 
     }
     int rc = D3R_OK;
     m->prof_rec.clear();
-    forward_impl(m, m->ws, m->ws_bytes, phases, img1, img2, nimg1, nimg, feat, B, H, W, pts1, conf1, pts2, conf2, st, &rc);
+    forward_impl(m, m->ws, m->ws_bytes, phases, img1, img2, nimg1, nimg, feat, B, d0, d1, pts1, conf1, pts2, conf2, st, &rc);
     return rc;
 }
 
 extern "C" int d3r_model_forward(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1,
                                  float* pts2, float* conf2, void* stream) {
     if (!m || !img1 || !img2 || B <= 0 || !pts1 || !conf1 || !pts2 || !conf2) return D3R_ERR_INVALID;
-    return run_phases(m, PH_ENCODE | PH_DECODE, img1, img2, B, 2 * B, nullptr, B, H, W, pts1, conf1, pts2, conf2, (hipStream_t)stream);
+    return run_phases(m, PH_ENCODE | PH_DECODE, img1, img2, B, 2 * B, nullptr, B, H, W, H, W, pts1, conf1, pts2, conf2, (hipStream_t)stream);
+}
+
+extern "C" int d3r_model_forward_mixed(d3r_model* m, const float* img1, int H1, int W1, const float* img2, int H2, int W2, int B, float* pts1,
+                                       float* conf1, float* pts2, float* conf2, void* stream) {
+    if (!m || !img1 || !img2 || B <= 0 || !pts1 || !conf1 || !pts2 || !conf2) return D3R_ERR_INVALID;
+    return run_phases(m, PH_ENCODE | PH_DECODE, img1, img2, B, 2 * B, nullptr, B, H1, W1, H2, W2, pts1, conf1, pts2, conf2, (hipStream_t)stream);
 }
 
 extern "C" int d3r_model_forward_packed(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* out8, void* stream) {
     if (!m || !img1 || !img2 || B <= 0 || !out8) return D3R_ERR_INVALID;
     m->out_pstride = 8; m->out_cstride = 8;
-    const int rc = run_phases(m, PH_ENCODE | PH_DECODE, img1, img2, B, 2 * B, nullptr, B, H, W, out8, out8 + 3, out8 + 4, out8 + 7, (hipStream_t)stream);
+    const int rc = run_phases(m, PH_ENCODE | PH_DECODE, img1, img2, B, 2 * B, nullptr, B, H, W, H, W, out8, out8 + 3, out8 + 4, out8 + 7, (hipStream_t)stream);
     m->out_pstride = 3; m->out_cstride = 1;
     return rc;
 }
@@ -802,11 +854,11 @@ extern "C" size_t d3r_model_feature_bytes(const d3r_model* m, int H, int W) {
 
 extern "C" int d3r_model_encode(d3r_model* m, const float* img, int n, int H, int W, void* feat_out, void* stream) {
     if (!m || !img || n <= 0 || !feat_out) return D3R_ERR_INVALID;
-    return run_phases(m, PH_ENCODE, img, nullptr, n, n, feat_out, 0, H, W, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    return run_phases(m, PH_ENCODE, img, nullptr, n, n, feat_out, 0, H, W, H, W, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int d3r_model_decode(d3r_model* m, const void* feat, int B, int H, int W, float* pts1, float* conf1, float* pts2, float* conf2,
                                 void* stream) {
     if (!m || !feat || B <= 0 || !pts1 || !conf1 || !pts2 || !conf2) return D3R_ERR_INVALID;
-    return run_phases(m, PH_DECODE, nullptr, nullptr, 0, 0, const_cast<void*>(feat), B, H, W, pts1, conf1, pts2, conf2, (hipStream_t)stream);
+    return run_phases(m, PH_DECODE, nullptr, nullptr, 0, 0, const_cast<void*>(feat), B, H, W, H, W, pts1, conf1, pts2, conf2, (hipStream_t)stream);
 }

@@ -25,6 +25,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "kernels.hpp"
 
 namespace d3r {
@@ -992,10 +994,14 @@ static DevInfo dev_info() {
 
 // ---- host side: configuration choice + launch ------------------------------------------------------------------
 template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device function attribute: raise it once on every device this process launches on
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    const unsigned long long dev_bit = 1ull << (dev_id & 63);
+    if (!(attr_done.load(std::memory_order_relaxed) & dev_bit)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<DT, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
-        attr_set = true;
+        attr_done.fetch_or(dev_bit, std::memory_order_relaxed);
     }
     const int grid = cdiv(p.M, CF::BM) * cdiv(p.n_store, CF::BN);
     GemmParams q = p;

@@ -145,10 +145,16 @@ class AsymmetricCroCo3DStereo(nn.Module):
         self._engine = None
         self._engine_device = None
         self._device = torch.device('cpu')
+        # the weights live in the engine, not in nn.Parameters; one empty parameter keeps the `next(model.parameters()).device` idiom working
+        self._anchor = nn.Parameter(torch.empty(0), requires_grad=False)
+        if landscape_only:
+            import warnings
+            warnings.warn('landscape_only=True is evaluated with landscape_only=False semantics (what load_model forces for inference, '
+                          'dust3r/model.py:31-36): portrait inputs are NOT transposed by the engine')
 
     # ------------------------------------------------------------------ weights
     def state_dict(self, *a, **k):
-        return OrderedDict(self._weights)
+        return OrderedDict(self._weights)          # checkpoint keys only (the device anchor is not a weight)
 
     def load_state_dict(self, ckpt, strict=True, **kw):
         new = dict(ckpt)
@@ -182,7 +188,12 @@ class AsymmetricCroCo3DStereo(nn.Module):
         if device is None:
             return self
         device = torch.device(device)
+        if device.type == 'cuda':
+            _lib.require_device()                                # no GPU: the package's own error, not torch's
+            if device.index is None:                             # 'cuda' means the current device: tensors report cuda:<index>
+                device = torch.device('cuda', torch.cuda.current_device())
         self._device = device
+        self._anchor.data = self._anchor.data.to(device)
         if device.type == 'cuda':
             self._build_engine(device)
         return self
@@ -261,21 +272,25 @@ class AsymmetricCroCo3DStereo(nn.Module):
         for sh in (shape1, shape2):                                       # misc.py:59-64 (wrapper_no)
             sh = torch.as_tensor(sh)
             assert sh[0:1].allclose(sh), 'true_shape must be all identical'
-        if img1.shape != img2.shape:
-            raise NotImplementedError('pairs of two different image sizes are not supported by the engine yet')
-        H, W = img1.shape[-2:]
-        assert H % self.patch_size == 0, f'Input image height ({H}) is not a multiple of patch size ({self.patch_size}).'
-        assert W % self.patch_size == 0, f'Input image width ({W}) is not a multiple of patch size ({self.patch_size}).'
+        assert img2.shape[0] == B
+        (H, W), (H2, W2) = img1.shape[-2:], img2.shape[-2:]
+        for h, w in ((H, W), (H2, W2)):
+            assert h % self.patch_size == 0, f'Input image height ({h}) is not a multiple of patch size ({self.patch_size}).'
+            assert w % self.patch_size == 0, f'Input image width ({w}) is not a multiple of patch size ({self.patch_size}).'
         dev = self._engine_device
         with torch.cuda.device(dev):
             i1 = img1.to(dev, torch.float32).contiguous()
             i2 = img2.to(dev, torch.float32).contiguous()
             pts1 = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
-            pts2 = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+            pts2 = torch.empty((B, H2, W2, 3), dtype=torch.float32, device=dev)
             conf1 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-            conf2 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-            check(lib.d3r_model_forward(self._engine, ptr(i1), ptr(i2), B, H, W, ptr(pts1), ptr(conf1), ptr(pts2), ptr(conf2),
-                                        current_stream()), 'model_forward')
+            conf2 = torch.empty((B, H2, W2), dtype=torch.float32, device=dev)
+            if (H, W) == (H2, W2):
+                check(lib.d3r_model_forward(self._engine, ptr(i1), ptr(i2), B, H, W, ptr(pts1), ptr(conf1), ptr(pts2), ptr(conf2),
+                                            current_stream()), 'model_forward')
+            else:       # two views of different sizes: encoded separately, cross attention with Nq != Nk (model.py:148-150)
+                check(lib.d3r_model_forward_mixed(self._engine, ptr(i1), H, W, ptr(i2), H2, W2, B, ptr(pts1), ptr(conf1), ptr(pts2), ptr(conf2),
+                                                  current_stream()), 'model_forward_mixed')
         res1 = dict(pts3d=pts1, conf=conf1)
         res2 = dict(pts3d_in_other_view=pts2, conf=conf2)
         return res1, res2

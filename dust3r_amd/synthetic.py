@@ -95,6 +95,24 @@ def synthetic_image_list(n_views, H, W, seed=0):
                  instance=str(i)) for i in range(n_views)]
 
 
+def synthetic_photo(W, H, seed):
+    """Deterministic smooth RGB test picture, uint8 (H, W, 3): gradients, a few sinusoids and mild noise, so that resampling filters act
+    non-trivially on it (load_images tests; no image file is shipped)."""
+    rng = np.random.RandomState(seed)
+    y, x = np.mgrid[:H, :W].astype(np.float64)
+    chans = []
+    for c in range(3):
+        a, b, p1, p2 = rng.uniform(0.01, 0.2, 4)
+        v = 0.5 + 0.25 * np.sin(a * x + p1 * 10) * np.cos(b * y + p2 * 10) + 0.2 * (x / W - y / H) * (1 if c != 1 else -1)
+        chans.append(v + 0.03 * rng.randn(H, W))
+    return (np.clip(np.stack(chans, axis=-1), 0, 1) * 255).round().astype('uint8')
+
+
+# (source W, H, size, square_ok): landscape / portrait / square (4:3 rule and square_ok) / odd sizes / enlargement (BICUBIC) / the 224 rule
+LOAD_IMAGES_CASES = [(640, 480, 160, False), (480, 640, 160, False), (500, 500, 160, False), (500, 500, 160, True), (333, 517, 128, False),
+                     (100, 75, 160, False), (417, 300, 224, False), (300, 417, 224, False), (1001, 333, 192, False)]
+
+
 # ------------------------------------------------------------------ aligner scenes
 def _rotmat_to_quat_xyzw(R):
     """numpy, single 3x3 -> XYZW unit quaternion (largest-component branch)."""

@@ -118,6 +118,12 @@ int d3r_model_missing(const d3r_model* m);
  * pts2 (= pred2['pts3d_in_other_view']) and conf2. Workspace is owned by the model and grown on demand. */
 int d3r_model_forward(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1, float* pts2,
                       float* conf2, void* stream);
+/* forward for a batch whose two views have DIFFERENT sizes (img1: B x 3 x H1 x W1, img2: B x 3 x H2 x W2), the else-branch of
+ * dust3r/model.py:148-150 (_encode_image_pairs encodes the two views separately); outputs pts1/conf1 at (H1, W1), pts2/conf2 at (H2, W2).
+ * Cross attention runs with Nq != Nk; with equal sizes it is d3r_model_forward. */
+int d3r_model_forward_mixed(d3r_model* m, const float* img1, int H1, int W1, const float* img2, int H2, int W2, int B, float* pts1, float* conf1,
+                            float* pts2, float* conf2, void* stream);
+
 /* same forward, outputs interleaved per pixel: out8 fp32 [B][H][W][8] = (pts1 xyz, conf1, pts2 xyz, conf2) -- the single payload the
  * pair-sharded multi-GPU path all-gathers (dust3r_amd/parallel.py), written directly by the head epilogues */
 int d3r_model_forward_packed(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* out8, void* stream);
@@ -170,7 +176,9 @@ typedef struct d3r_aligner d3r_aligner;
 #define D3R_SCHEDULE_COSINE 0
 #define D3R_SCHEDULE_LINEAR 1
 #define D3R_ALIGNER_OPT_DPP_REDUCE 1 /* 1 (default): DPP wave reduction; 0: __shfl_xor butterfly */
-#define D3R_ALIGNER_OPT_RESET_ADAM 2
+#define D3R_ALIGNER_OPT_RESET_ADAM 2   /* clear the Adam moments, ordered on the stream of the next d3r_aligner_run */
+#define D3R_ALIGNER_OPT_OPTIMIZE_PP 3 /* 1: im_pp is a trainable parameter (PointCloudOptimizer(optimize_pp=True), optimizer.py:22,34) */
+#define D3R_ALIGNER_OPT_OPTIMIZE_ADAPTORS 4 /* 1: pw_adaptors are trainable (allow_pw_adaptors=True, base_opt.py:49,92) */
 
 int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, const int* ei, const int* ej, const int* img_h, const int* img_w,
                        int max_area, const float* pred_i, const float* pred_j, const float* w_i, const float* w_j, float* pw_poses,
@@ -184,9 +192,11 @@ int d3r_aligner_set_option(d3r_aligner* a, int option, int value);
  * at base_opt.py:366 -- but without the reference's per-iteration host synchronisation. */
 int d3r_aligner_run(d3r_aligner* a, int niter, int iter0, int niter_total, float lr_base, float lr_min, int schedule,
                     float* losses_out, void* stream);
-/* one forward/backward without a step (parity tests): loss[1] and the gradients w.r.t. each parameter tensor */
+/* one forward/backward without a step (parity tests): loss[1] and the gradients w.r.t. each parameter tensor (any may be NULL);
+ * g_im_pp [n][2]: principal-point parameters (optimizer.py:141-142, trained when optimize_pp=True); g_pw_adaptors [E][2]: pairwise
+ * xy / z adaptors (base_opt.py:143-149, trained when allow_pw_adaptors=True) */
 int d3r_aligner_loss_grad(d3r_aligner* a, float* loss, float* g_pw_poses, float* g_im_poses, float* g_im_depthmaps,
-                          float* g_im_focals, void* stream);
+                          float* g_im_focals, float* g_im_pp, float* g_pw_adaptors, void* stream);
 
 /* clean_pointcloud -- replaces the host-driven O(n^2 A) double loop of dust3r/cloud_opt/base_opt.py:369-405 (called through
  * BasePCOptimizer.clean_pointcloud, base_opt.py:234-244, by the demo's post-processing). conf [n][max_area] is updated in place with

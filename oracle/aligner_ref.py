@@ -70,8 +70,10 @@ class AlignerRef:
         self.params = None
 
     # ------------------------------------------------------------------ state
-    def load_state(self, state):
-        self.params = {k: state[k].detach().clone().to(self.dtype).requires_grad_(k not in ('pw_adaptors', 'im_pp'))
+    def load_state(self, state, optimize_pp=False, allow_pw_adaptors=False):
+        # optimizer.py:34: im_pp.requires_grad_(optimize_pp); base_opt.py:92: pw_adaptors.requires_grad_(allow_pw_adaptors)
+        frozen = tuple(k for k, on in (('pw_adaptors', allow_pw_adaptors), ('im_pp', optimize_pp)) if not on)
+        self.params = {k: state[k].detach().clone().to(self.dtype).requires_grad_(k not in frozen)
                        for k in ('pw_poses', 'pw_adaptors', 'im_poses', 'im_depthmaps', 'im_focals', 'im_pp')}
         return self
 

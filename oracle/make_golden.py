@@ -183,6 +183,26 @@ def pair_viewer_golden(H, W, seed):
                 pts3d=[p.detach().clone() for p in scene.get_pts3d()])
 
 
+def load_images_golden():
+    """The unmodified reference's load_images (utils/image.py:74-128; torchvision's ToTensor / Normalize through the stand-in) on
+    synthetic pictures written as PNG: resize rule, filter choice, crop rule, normalisation. Stored as the uint8 pixels the fp32
+    output decodes to exactly (x = (u8 / 255 - 0.5) / 0.5), which keeps the fixture small."""
+    import tempfile
+    import PIL.Image
+    from dust3r.utils.image import load_images
+    from dust3r_amd.synthetic import LOAD_IMAGES_CASES, synthetic_photo
+    out = []
+    with tempfile.TemporaryDirectory() as d:
+        for k, (W, H, size, sq) in enumerate(LOAD_IMAGES_CASES):
+            path = os.path.join(d, f'img{k}.png')
+            PIL.Image.fromarray(synthetic_photo(W, H, seed=k)).save(path)
+            v = load_images([path], size=size, square_ok=sq, verbose=False)[0]
+            u8 = ((v['img'][0] * 0.5 + 0.5) * 255).round().to(torch.uint8)
+            assert torch.equal(((u8.float().div(255) - 0.5) / 0.5), v['img'][0])
+            out.append(dict(src=(W, H), size=size, square_ok=sq, seed=k, true_shape=v['true_shape'].copy(), u8=u8))
+    return dict(kind='load_images', cases=out, unpinned='torchvision ToTensor / Normalize restated in oracle/shims/torchvision')
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -195,6 +215,7 @@ if __name__ == '__main__':
         'mst_init_8v.pt': lambda: mst_init_golden(8, 64, 96, seed=3),
         'mst_init_12v_swin.pt': lambda: mst_init_golden(12, 48, 64, seed=4, scene_graph='swin-2'),
         'pair_viewer.pt': lambda: pair_viewer_golden(64, 96, seed=5),
+        'load_images.pt': lambda: load_images_golden(),
     }
     if len(sys.argv) > 1:        # regenerate only the named fixtures (aligner_c4.pt takes ~20 min of CPU)
         jobs = {k: v for k, v in jobs.items() if k in sys.argv[1:]}

@@ -159,6 +159,40 @@ def test_c4_trajectory_against_fp64_and_reference_floor(gpu):
           f'worst engine deviation while the reference is inside 1e-4: {worst_early:.2e}')
 
 
+def test_principal_point_and_adaptor_parameters(gpu):
+    """PointCloudOptimizer(optimize_pp=True) (optimizer.py:22,34) and allow_pw_adaptors=True (base_opt.py:49,92): the two parameter
+    groups the released recipes keep frozen. Gradients against fp64 autograd at a state where both are non-zero, then 15 Adam
+    iterations against the fp32 oracle with both groups trainable."""
+    from dust3r_amd.cloud_opt import global_aligner
+    from dust3r_amd.cloud_opt.base_opt import global_alignment_loop
+    from oracle.aligner_ref import AlignerRef
+    out, init, gt = synthetic_scene(4, 32, 48, seed=21, symmetrize=True)
+    g = torch.Generator().manual_seed(5)
+    init = dict(init, im_pp=0.3 * torch.randn((4, 2), generator=g), pw_adaptors=0.5 * torch.randn((len(out['view1']['idx']), 2), generator=g))
+    scene = global_aligner(out, gpu, optimize_pp=True, allow_pw_adaptors=True, verbose=False)
+    scene.load_state_dict(init)
+    assert scene.im_pp.requires_grad and scene.pw_adaptors.requires_grad and 'im_pp' in scene.trainable_names()
+    ref = AlignerRef(out, dtype=torch.float64).load_state(init, optimize_pp=True, allow_pw_adaptors=True)
+    loss_ref, g_ref = ref.grads()
+    loss, grads = scene.loss_and_grads()
+    assert abs(float(loss) / loss_ref - 1) < 1e-5
+    for k in ('pw_poses', 'im_poses', 'im_depthmaps', 'im_focals', 'im_pp', 'pw_adaptors'):
+        err = rel(grads[k].reshape(g_ref[k].shape), g_ref[k])
+        print(k, err)
+        assert err < 5e-5, (k, err)
+    ref32 = AlignerRef(out).load_state(init, optimize_pp=True, allow_pw_adaptors=True)
+    ref_losses = ref32.run(niter=15, lr=0.01, schedule='cosine', lr_min=1e-6)
+    last = global_alignment_loop(scene, lr=0.01, niter=15, schedule='cosine', lr_min=1e-6)
+    assert abs(last / ref_losses[-1] - 1) < 1e-3
+    st = ref32.state()
+    assert rel(scene.im_pp.data, st['im_pp']) < 2e-3 and rel(scene.pw_adaptors.data, st['pw_adaptors']) < 2e-3
+    assert float((scene.im_pp.data.cpu() - init['im_pp']).abs().max()) > 1e-3        # they did move
+    assert rel(scene.get_principal_points(), (ref32.pp0 + 10 * st['im_pp'])) < 1e-4
+    # frozen by default
+    frozen = global_aligner(out, gpu, verbose=False)
+    assert not frozen.im_pp.requires_grad and not frozen.pw_adaptors.requires_grad
+
+
 def test_noise_free_ground_truth_is_a_fixed_point(gpu):
     """With exact pairwise geometry and the ground-truth state, the loss is ~0 and stays there."""
     scene, out, init, gt = make_scene(gpu, 4, 32, 48, seed=2, noise=0.0, perturb=False)

@@ -1,0 +1,110 @@
+"""The demo's reconstruction body on the engine: the call sequence of the reference's `get_reconstructed_scene` +
+`get_3D_model_from_scene` (dust3r/demo.py:110-186, minus gradio / GLB export / matplotlib), issued against dust3r_amd under the
+reference's names -- files on disk -> load_images -> make_pairs -> inference -> global_aligner -> compute_global_alignment(init='mst')
+-> clean_pointcloud -> getters. (tests/test_oracle_pins.py checks in the build container that the reference's own demo module binds
+to these functions through the INTEGRATION.md aliasing.)"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_images(tmp_path, sizes):
+    import PIL.Image
+    from dust3r_amd.synthetic import synthetic_photo
+    paths = []
+    for k, (W, H) in enumerate(sizes):
+        p = os.path.join(str(tmp_path), f'view{k}.png')
+        PIL.Image.fromarray(synthetic_photo(W, H, seed=20 + k)).save(p)
+        paths.append(p)
+    return paths
+
+
+def _engine(gpu):
+    from dust3r_amd.model import AsymmetricCroCo3DStereo
+    from dust3r_amd.synthetic import MODEL_CONFIGS
+    from oracle.dust3r_ref import build_ref_model
+    m = AsymmetricCroCo3DStereo(landscape_only=False, **MODEL_CONFIGS['tiny_dpt'])        # default precision = the parity-grade mode
+    assert m.precision == 'fp16x3'
+    m.load_state_dict(build_ref_model('tiny_dpt').state_dict())
+    return m.to(gpu)
+
+
+def reconstruct(filelist, model, device, image_size, schedule, niter, min_conf_thr, clean_depth, scenegraph_type, winsize=1, refid=0):
+    """dust3r/demo.py:135-186 + :110-132, same order, same arguments."""
+    from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.inference import inference
+    from dust3r_amd.utils.device import to_numpy
+    from dust3r_amd.utils.image import load_images
+    try:
+        square_ok = model.square_ok
+    except Exception:
+        square_ok = False
+    imgs = load_images(filelist, size=image_size, verbose=False, patch_size=model.patch_size, square_ok=square_ok)
+    if len(imgs) == 1:
+        imgs = [imgs[0], copy.deepcopy(imgs[0])]
+        imgs[1]['idx'] = 1
+    if scenegraph_type == 'swin':
+        scenegraph_type = scenegraph_type + '-' + str(winsize)
+    elif scenegraph_type == 'oneref':
+        scenegraph_type = scenegraph_type + '-' + str(refid)
+    pairs = make_pairs(imgs, scene_graph=scenegraph_type, prefilter=None, symmetrize=True)
+    output = inference(pairs, model, device, batch_size=1, verbose=False)
+    mode = GlobalAlignerMode.PointCloudOptimizer if len(imgs) > 2 else GlobalAlignerMode.PairViewer
+    scene = global_aligner(output, device=device, mode=mode, verbose=False)
+    loss = None
+    if mode == GlobalAlignerMode.PointCloudOptimizer:
+        loss = scene.compute_global_alignment(init='mst', niter=niter, schedule=schedule, lr=0.01)
+    if clean_depth:
+        scene = scene.clean_pointcloud()
+    rgbimg = scene.imgs
+    focals = scene.get_focals().cpu()
+    cams2world = scene.get_im_poses().cpu()
+    pts3d = to_numpy(scene.get_pts3d())
+    scene.min_conf_thr = float(scene.conf_trf(torch.tensor(min_conf_thr)))
+    msk = to_numpy(scene.get_masks())
+    depths = to_numpy(scene.get_depthmaps())
+    confs = to_numpy([c for c in scene.im_conf])
+    return scene, loss, dict(rgbimg=rgbimg, focals=focals, cams2world=cams2world, pts3d=pts3d, msk=msk, depths=depths, confs=confs)
+
+
+@pytest.mark.parametrize('graph,n', [('complete', 3), ('swin', 4), ('oneref', 3)])
+def test_demo_body_multi_view(gpu, tmp_path, graph, n):
+    files = _write_images(tmp_path, [(200, 150)] * n)
+    model = _engine(gpu)
+    scene, loss, out = reconstruct(files, model, gpu, image_size=96, schedule='linear', niter=30, min_conf_thr=3.0, clean_depth=True,
+                                   scenegraph_type=graph)
+    H, W = 64, 96                                     # 200x150 -> long side 96 -> 96x72 -> cropped to multiples of 16
+    assert loss is not None and np.isfinite(loss)
+    assert len(out['rgbimg']) == n and out['rgbimg'][0].shape == (H, W, 3) and 0 <= out['rgbimg'][0].min() and out['rgbimg'][0].max() <= 1
+    assert out['focals'].shape == (n, 1) and out['cams2world'].shape == (n, 4, 4) and torch.isfinite(out['cams2world']).all()
+    assert len(out['pts3d']) == n and out['pts3d'][0].shape == (H, W, 3) and out['msk'][0].shape == (H, W) and out['msk'][0].dtype == bool
+    assert out['depths'][0].shape == (H, W) and out['confs'][0].shape == (H, W) and all(np.isfinite(p).all() for p in out['pts3d'])
+
+
+def test_demo_body_single_image_and_pair(gpu, tmp_path):
+    """One file (the demo duplicates it) and two files: both go through GlobalAlignerMode.PairViewer."""
+    model = _engine(gpu)
+    for sizes in ([(160, 160)], [(200, 150), (180, 150)]):
+        files = _write_images(tmp_path, sizes)
+        scene, loss, out = reconstruct(files, model, gpu, image_size=96, schedule='linear', niter=10, min_conf_thr=3.0, clean_depth=False,
+                                       scenegraph_type='complete')
+        assert loss is None and type(scene).__name__ == 'PairViewer'
+        assert len(out['pts3d']) == 2 and out['cams2world'].shape == (2, 4, 4) and out['focals'].shape == (2,)
+        assert all(np.isfinite(p).all() for p in out['pts3d']) and out['pts3d'][0].shape[:2] == out['msk'][0].shape
+
+
+def test_demo_body_mixed_portrait_and_landscape(gpu, tmp_path):
+    """A folder mixing landscape and portrait pictures: inference() takes its mixed-shape path (lists), the engine the two-size forward,
+    the aligner the padded (max_area) layout."""
+    files = _write_images(tmp_path, [(200, 150), (150, 200), (200, 150)])
+    model = _engine(gpu)
+    scene, loss, out = reconstruct(files, model, gpu, image_size=96, schedule='cosine', niter=20, min_conf_thr=3.0, clean_depth=True,
+                                   scenegraph_type='complete')
+    assert np.isfinite(loss) and [p.shape[:2] for p in out['pts3d']] == [(64, 96), (96, 64), (64, 96)]
+    assert all(np.isfinite(p).all() for p in out['pts3d'])

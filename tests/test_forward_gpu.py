@@ -10,6 +10,8 @@ Tolerances (per-pixel relative pointmap error |d| / |ref|):
 """
 import os
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -300,3 +302,57 @@ def test_packed_forward_equals_forward(gpu):
         p1, p2 = unpack_predictions(eng.forward_packed(v1, v2))
         assert torch.equal(p1['pts3d'], r1['pts3d']) and torch.equal(p1['conf'], r1['conf'])
         assert torch.equal(p2['pts3d_in_other_view'], r2['pts3d_in_other_view']) and torch.equal(p2['conf'], r2['conf'])
+
+
+def test_sharded_inference_on_the_engine_with_rccl(gpu):
+    """The CUDA branch of dust3r_amd.parallel.inference_sharded (engine heads write the packed all-gather payload in place, then ONE
+    all_gather_into_tensor over RCCL): world size 1 on this box's GPU, bit-identical to the single-process inference(). The multi-rank
+    behaviour of the same code is covered by the gloo tests (tests/test_parallel_cpu.py, world 2 and 4)."""
+    import socket
+    import torch.distributed as dist
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.inference import inference
+    from dust3r_amd.parallel import inference_sharded
+    from dust3r_amd.synthetic import synthetic_image_list
+    from oracle.dust3r_ref import build_ref_model
+    eng = engine_from_oracle(build_ref_model('tiny_dpt'), 'tiny_dpt', 'fp16x3', gpu)
+    pairs = make_pairs(synthetic_image_list(4, 32, 48, seed=8), 'complete', None, symmetrize=False)
+    ref = inference(pairs, eng, gpu, batch_size=4, verbose=False, encode_once=False)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=gpu)
+    try:
+        out = inference_sharded(pairs, eng, gpu, batch_size=4)
+    finally:
+        dist.destroy_process_group()
+    assert out['view1']['idx'] == ref['view1']['idx'] and out['view2']['idx'] == ref['view2']['idx']
+    assert torch.equal(out['pred1']['pts3d'], ref['pred1']['pts3d']) and torch.equal(out['pred1']['conf'], ref['pred1']['conf'])
+    assert torch.equal(out['pred2']['pts3d_in_other_view'], ref['pred2']['pts3d_in_other_view']) and torch.equal(out['pred2']['conf'], ref['pred2']['conf'])
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+@pytest.mark.parametrize('hw1,hw2', [((32, 48), (48, 32)), ((64, 64), (32, 48)), ((48, 80), (64, 128))])
+def test_pairs_of_two_image_sizes(gpu, precision, hw1, hw2):
+    """The else-branch of dust3r/model.py:148-150 (a landscape image paired with a portrait one): the two views are encoded separately
+    and cross attention runs with Nq != Nk (d3r_model_forward_mixed). Against the oracle, same 1e-3 bar; and through inference()'s
+    mixed-shape path (batch size 1, lists instead of concatenated tensors, inference.py:60-72)."""
+    from oracle.dust3r_ref import build_ref_model
+    from dust3r_amd.inference import inference
+    oracle = build_ref_model('tiny_dpt')
+    eng = engine_from_oracle(oracle, 'tiny_dpt', precision, gpu)
+    g = torch.Generator().manual_seed(hw1[0] * 7 + hw2[1])
+    B = 2
+    v1 = dict(img=torch.rand((B, 3) + hw1, generator=g) * 2 - 1, true_shape=torch.tensor([hw1] * B, dtype=torch.int32), idx=[0, 2], instance=['0', '2'])
+    v2 = dict(img=torch.rand((B, 3) + hw2, generator=g) * 2 - 1, true_shape=torch.tensor([hw2] * B, dtype=torch.int32), idx=[1, 3], instance=['1', '3'])
+    compare(eng, oracle, v1, v2, *TOLS[precision], tag=f'tiny_dpt {precision} {hw1} x {hw2}')
+    e1, e2 = eng(v1, v2)
+    assert e1['pts3d'].shape == (B,) + hw1 + (3,) and e2['pts3d_in_other_view'].shape == (B,) + hw2 + (3,) and e2['conf'].shape == (B,) + hw2
+    # inference(): one same-size pair + one mixed pair -> the multiple-shapes path
+    mk = lambda img, hw, i: dict(img=img[None], true_shape=np.int32([hw]), idx=i, instance=str(i))  # noqa: E731
+    pairs = [(mk(v1['img'][0], hw1, 0), mk(v2['img'][0], hw2, 1)), (mk(v1['img'][1], hw1, 2), mk(v1['img'][0], hw1, 0))]
+    out = inference(pairs, eng, gpu, batch_size=8, verbose=False)
+    assert isinstance(out['pred1']['pts3d'], list) and len(out['pred1']['pts3d']) == 2
+    assert out['pred2']['pts3d_in_other_view'][0].shape[-3:-1] == hw2 and out['pred2']['pts3d_in_other_view'][1].shape[-3:-1] == hw1
+    assert torch.equal(out['pred1']['pts3d'][0].reshape(hw1 + (3,)), e1['pts3d'][0].cpu())

@@ -201,3 +201,53 @@ def test_c_abi_is_usable_from_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and 'c_abi probe ok' in r.stdout, r.stdout + r.stderr
+
+
+def _write_case_png(tmp_path, k, W, H):
+    import PIL.Image
+    from dust3r_amd.synthetic import synthetic_photo
+    path = os.path.join(str(tmp_path), f'img{k}.png')
+    PIL.Image.fromarray(synthetic_photo(W, H, seed=k)).save(path)
+    return path
+
+
+def test_load_images_matches_reference_golden(tmp_path):
+    """utils/image.py::load_images against tensors produced by the unmodified reference's load_images on the same synthetic
+    pictures (tests/golden/load_images.pt): resize rule, LANCZOS / BICUBIC choice, crop rule (4:3 for squares, multiples of the patch
+    size, the 224 rule), normalisation -- bit for bit."""
+    from dust3r_amd.synthetic import LOAD_IMAGES_CASES
+    from dust3r_amd.utils.image import load_images
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'load_images.pt'), weights_only=False)
+    assert len(g['cases']) == len(LOAD_IMAGES_CASES)
+    for k, c in enumerate(g['cases']):
+        W, H = c['src']
+        v = load_images([_write_case_png(tmp_path, k, W, H)], size=c['size'], square_ok=c['square_ok'], verbose=False)[0]
+        ref = (c['u8'].float().div(255) - 0.5) / 0.5
+        assert v['img'].shape == (1,) + tuple(ref.shape) and v['img'].dtype == torch.float32, (k, v['img'].shape, ref.shape)
+        assert torch.equal(v['img'][0], ref), k
+        assert (v['true_shape'] == c['true_shape']).all() and v['true_shape'].dtype == np.int32 and v['idx'] == 0 and v['instance'] == '0'
+
+
+def test_load_images_equals_live_reference(tmp_path):
+    """Same comparison against the LIVE reference function over a sweep of source sizes at the release resolutions (512, 224); needs
+    /root/reference (build container only)."""
+    from oracle.ref_import import import_reference, reference_available
+    if not reference_available():
+        pytest.skip('/root/reference only exists in the build container')
+    import_reference()
+    from dust3r.utils.image import load_images as ref_load
+    from dust3r_amd.utils.image import fit_geometry, load_images
+    paths, k = [], 0
+    for (W, H) in [(1280, 960), (960, 1280), (800, 800), (1023, 577), (400, 300), (513, 512), (511, 512), (2000, 500), (64, 48)]:
+        paths.append(_write_case_png(tmp_path, k, W, H))
+        k += 1
+    for size, sq in ((512, False), (512, True), (224, False)):
+        ours, refs = load_images(paths, size=size, square_ok=sq, verbose=False), ref_load(paths, size=size, square_ok=sq, verbose=False)
+        assert len(ours) == len(refs)
+        for a, b in zip(ours, refs):
+            assert torch.equal(a['img'], b['img']) and (a['true_shape'] == b['true_shape']).all() and a['idx'] == b['idx'] and a['instance'] == b['instance']
+    # the geometry alone, exhaustively over small sizes, against what the reference's arithmetic gives (image.py:98-116)
+    for W1 in range(30, 140, 7):
+        for H1 in range(30, 140, 11):
+            (W, H), box = fit_geometry(W1, H1, 96)
+            assert max(W, H) == 96 and box[2] - box[0] <= W and (box[2] - box[0]) % 16 == 0

@@ -12,6 +12,8 @@ from oracle.aligner_ref import AlignerRef
 from oracle.dust3r_ref import build_ref_model
 from oracle.ref_import import reference_available
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
@@ -142,3 +144,40 @@ def test_cloud_restatements_equal_live_reference():
     changed = sum(int((r != c).sum()) for r, c in zip(ref, confs))
     assert changed > 50
     assert all(torch.equal(a, b) for a, b in zip(ref, got))
+
+
+@pytest.mark.skipif(not reference_available(), reason='/root/reference only exists in the build container')
+def test_reference_demo_binds_to_the_engine_through_the_integration_aliases():
+    """with `dust3r.<hot-path module>` aliased to `dust3r_amd.<module>`, the reference's OWN dust3r/demo.py
+    (imported unmodified; gradio / matplotlib / trimesh stubbed) resolves every function of its reconstruction body to the engine's."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, types
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/oracle/shims')
+import dust3r_amd, dust3r_amd.model, dust3r_amd.inference, dust3r_amd.image_pairs, dust3r_amd.cloud_opt, dust3r_amd.utils.image, dust3r_amd.utils.device
+for stub in ('gradio', 'matplotlib', 'matplotlib.pyplot', 'scipy.spatial.transform'):
+    if stub not in sys.modules:
+        try:
+            __import__(stub)
+        except Exception:
+            sys.modules[stub] = types.ModuleType(stub)
+sys.modules['matplotlib'].pyplot = sys.modules['matplotlib.pyplot']
+sys.path.insert(0, '/root/reference')
+sys.modules['dust3r.utils.path_to_croco'] = types.ModuleType('dust3r.utils.path_to_croco')
+import dust3r
+for name in ('model', 'inference', 'image_pairs', 'cloud_opt', 'utils.image', 'utils.device'):
+    sys.modules['dust3r.' + name] = sys.modules['dust3r_amd.' + name]
+viz = types.ModuleType('dust3r.viz')
+for k in ('add_scene_cam', 'CAM_COLORS', 'OPENGL', 'pts3d_to_trimesh', 'cat_meshes'):
+    setattr(viz, k, None)
+sys.modules['dust3r.viz'] = viz
+import dust3r.demo as demo
+import dust3r_amd.inference as I, dust3r_amd.image_pairs as P, dust3r_amd.cloud_opt as Cl, dust3r_amd.utils.image as U
+assert demo.inference is I.inference and demo.make_pairs is P.make_pairs and demo.load_images is U.load_images
+assert demo.global_aligner is Cl.global_aligner and demo.GlobalAlignerMode is Cl.GlobalAlignerMode
+assert demo.get_reconstructed_scene.__module__ == 'dust3r.demo'
+print('aliases ok')
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'aliases ok' in r.stdout, r.stderr[-2000:]

@@ -1,5 +1,5 @@
-"""World-size-2 gloo tests (CPU) of the pair-sharded inference path (dust3r_amd/parallel.py): the sharded result
-must equal the single-process `inference()` result bit for bit, including ragged shards (odd pair counts)."""
+"""gloo tests (CPU, world size 2 and 4) of the pair-sharded inference path (dust3r_amd/parallel.py): the sharded result must equal the
+single-process `inference()` result bit for bit, including ragged shards (odd pair counts) and BASELINE configs[2]'s 190 pairs."""
 import os
 import socket
 import sys
@@ -33,12 +33,12 @@ def _pairs(n_views, H, W):
     return make_pairs(synthetic_image_list(n_views, H, W, seed=3), 'complete', None, symmetrize=False)
 
 
-def _worker(rank, world, port, n_views, outdir):
+def _worker(rank, world, port, n_views, outdir, H=16, W=32):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from dust3r_amd.parallel import inference_sharded
-        out = inference_sharded(_pairs(n_views, 16, 32), StandInModel(), 'cpu', batch_size=2)
+        out = inference_sharded(_pairs(n_views, H, W), StandInModel(), 'cpu', batch_size=2)
         torch.save((rank, out['pred1']['pts3d'], out['pred1']['conf'], out['pred2']['pts3d_in_other_view'], out['pred2']['conf'],
                     out['view1']['idx'], out['view2']['idx']), os.path.join(outdir, f'rank{rank}.pt'))
         dist.barrier()
@@ -52,19 +52,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('n_views', [4, 3])          # 6 pairs (even shards) and 3 pairs (ragged: 2 + 1 + padding)
-def test_sharded_inference_equals_single_process(n_views, tmp_path):
+# 6 pairs on 2 ranks (even shards), 3 pairs on 2 ranks (ragged: 2 + 1 + padding), and BASELINE configs[2]: 20 views -> 190 pairs on 4 ranks
+# (48 + 48 + 48 + 46 with two padding slots)
+@pytest.mark.parametrize('n_views,world,H,W', [(4, 2, 16, 32), (3, 2, 16, 32), (20, 4, 8, 16)])
+def test_sharded_inference_equals_single_process(n_views, world, H, W, tmp_path):
     from dust3r_amd.inference import inference
-    ref = inference(_pairs(n_views, 16, 32), StandInModel(), 'cpu', batch_size=2, verbose=False)
+    ref = inference(_pairs(n_views, H, W), StandInModel(), 'cpu', batch_size=2, verbose=False)
+    assert len(ref['view1']['idx']) == n_views * (n_views - 1) // 2
     ctx = mp.get_context('spawn')
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_views, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_views, str(tmp_path), H, W)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=240)
         assert p.exitcode == 0
-    got = [torch.load(os.path.join(str(tmp_path), f'rank{r}.pt')) for r in range(2)]
+    got = [torch.load(os.path.join(str(tmp_path), f'rank{r}.pt')) for r in range(world)]
     for rank, pts1, conf1, pts2, conf2, idx1, idx2 in got:
         assert torch.equal(pts1, ref['pred1']['pts3d']) and torch.equal(conf1, ref['pred1']['conf'])
         assert torch.equal(pts2, ref['pred2']['pts3d_in_other_view']) and torch.equal(conf2, ref['pred2']['conf'])
