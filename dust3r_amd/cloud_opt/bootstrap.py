@@ -278,7 +278,11 @@ def solve_pnp_batch(dev, jobs, iterations=10, reproj_err=5.0, seed=0, refine_ite
     if n == 0:
         return []
     maxh = int(lib.d3r_pnp_max_hypotheses())
-    nh = max(1, min(int(iterations), maxh))
+    # `iterations` is the reference's RANSAC budget for OpenCV's SQPnP minimal solver; a linear DLT hypothesis is cheaper and noisier,
+    # and scoring costs nothing extra on the GPU (one pass evaluates every hypothesis): always use the kernel's full set, each from
+    # NSAMPLE points (over-determined: pointmap noise averages out; DUSt3R pointmaps have few gross outliers)
+    nh = maxh
+    NSAMPLE = 12
     nv = int(lib.d3r_pnp_sum_count())
     recs = (_PnpJobRec * n)()
     for r, j in zip(recs, jobs):
@@ -302,7 +306,7 @@ def solve_pnp_batch(dev, jobs, iterations=10, reproj_err=5.0, seed=0, refine_ite
         world = pts @ G[:, :3].T + G[:, 3]
         xn = np.stack((((cand % W) - j['pp'][0]) / j['f'], ((cand // W) - j['pp'][1]) / j['f']), axis=1)
         for h in range(nh):
-            sel = np.nonzero(ok[h * 48:(h + 1) * 48])[0][:6] + h * 48
+            sel = np.nonzero(ok[h * 48:(h + 1) * 48])[0][:NSAMPLE] + h * 48
             if len(sel) < 6:
                 continue
             sol = pnp_host._dlt_pose(world[sel], xn[sel])

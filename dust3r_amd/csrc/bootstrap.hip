@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const PnpJob* jobs, cons
 }
 
 // Gauss-Newton sums over the inliers of pose[job] (reprojection error^2 < thr2, in front of the camera), unknowns = (rotation increment
-// w about the camera origin, translation increment): J^T J (21, upper triangle row-major), J^T r (6), cost, inlier count.
+// w about the camera origin, translation increment), Huber-weighted (delta = 1 px): J^T W J (21, upper triangle row-major), J^T W r (6),
+// cost, inlier count.
 // (A DLT refit of the consensus set from fp32 moments was tried first: the 12x12 normal matrix is too ill-conditioned for it.)
 static constexpr int PNP_NV = 29;
 __global__ __launch_bounds__(256) void pnp_sums_kernel(const PnpJob* jobs, const float* pose, float thr2, int nchunk, double* partial) {
@@ -295,13 +296,15 @@ __global__ __launch_bounds__(256) void pnp_sums_kernel(const PnpJob* jobs, const
             }
             Ju[3] = fx; Ju[4] = 0.f; Ju[5] = a0;
             Jv[3] = 0.f; Jv[4] = fx; Jv[5] = a1;
+            // Huber weight (delta = 1 pixel): a stray point that happens to reproject inside the consensus band pulls with a bounded force
+            const float rn = sqrtf(ru * ru + rv * rv), hw = rn > 1.f ? 1.f / rn : 1.f;
             int k = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
-                for (int b = a; b < 6; ++b) { acc[k] += (double)(Ju[a] * Ju[b] + Jv[a] * Jv[b]); ++k; }
+                for (int b = a; b < 6; ++b) { acc[k] += (double)(hw * (Ju[a] * Ju[b] + Jv[a] * Jv[b])); ++k; }
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[21 + a] += (double)(Ju[a] * ru + Jv[a] * rv);
+            for (int a = 0; a < 6; ++a) acc[21 + a] += (double)(hw * (Ju[a] * ru + Jv[a] * rv));
             acc[27] += (double)(ru * ru + rv * rv);
             acc[28] += 1.0;
         }
