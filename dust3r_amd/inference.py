@@ -75,18 +75,108 @@ def _alloc_outputs(P, H, W, out_device):
             dict(pts3d_in_other_view=torch.empty((P, H, W, 3), **kw), conf=torch.empty((P, H, W), **kw)))
 
 
+class _PredictionSink:
+    """Where the per-batch predictions go. Device outputs: a plain copy. Host outputs (the reference's format, inference.py:68): a ring
+    of two PINNED staging sets; batch k's D2H copies run on a side stream while batch k + 1 computes, and the host moves batch k - 1
+    from the ring into the (pageable) result tensors meanwhile -- the GPU never waits for PCIe or for the host memcpy, and the big
+    result tensors need no pinned allocation."""
+
+    KEYS = (('pred1', 'pts3d'), ('pred1', 'conf'), ('pred2', 'pts3d_in_other_view'), ('pred2', 'conf'))
+
+    def __init__(self, n_pairs, H, W, batch_size, out_device, compute_device):
+        self.pred1, self.pred2 = _alloc_outputs(n_pairs, H, W, out_device)
+        self.out = dict(pred1=self.pred1, pred2=self.pred2)
+        self.host = torch.device(out_device).type == 'cpu' and torch.device(compute_device).type == 'cuda'
+        self.pending = []
+        if self.host:
+            self.stream = torch.cuda.Stream(device=compute_device)
+            shapes = {('pred1', 'pts3d'): (batch_size, H, W, 3), ('pred1', 'conf'): (batch_size, H, W),
+                      ('pred2', 'pts3d_in_other_view'): (batch_size, H, W, 3), ('pred2', 'conf'): (batch_size, H, W)}
+            self.ring = [{k: torch.empty(shapes[k], dtype=torch.float32, pin_memory=True) for k in self.KEYS} for _ in range(2)]
+            self.slot = 0
+
+    def put(self, i, j, p1, p2):
+        src = {('pred1', 'pts3d'): p1['pts3d'], ('pred1', 'conf'): p1['conf'], ('pred2', 'pts3d_in_other_view'): p2['pts3d_in_other_view'],
+               ('pred2', 'conf'): p2['conf']}
+        if not self.host:
+            for (a, b), t in src.items():
+                self.out[a][b][i:j].copy_(t, non_blocking=True)
+            return
+        self._drain(keep=1)                                  # the slot about to be reused has been emptied by the host
+        ring = self.ring[self.slot]
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for k, t in src.items():
+                ring[k][:j - i].copy_(t, non_blocking=True)
+                t.record_stream(self.stream)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.pending.append((ev, self.slot, i, j))
+        self.slot ^= 1
+
+    def _drain(self, keep=0):
+        while len(self.pending) > keep:
+            ev, slot, i, j = self.pending.pop(0)
+            ev.synchronize()
+            for (a, b) in self.KEYS:
+                self.out[a][b][i:j].copy_(self.ring[slot][(a, b)][:j - i])
+
+    def finish(self):
+        if self.host:
+            self._drain(keep=0)
+        elif torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return self.pred1, self.pred2
+
+
 def _collate_views(pairs):
-    """view1 / view2 dicts of the whole pair list in the reference's collated format (tensors cat'ed on the host, lists chained)."""
-    view1, view2 = collate_with_cat(list(pairs))
-    return view1, view2
+    """view1 / view2 dicts of the whole pair list in the reference's collated format (inference.py:68-72: tensors concatenated on the
+    host, lists chained). When the pair list shares images (every `img` tensor object appears in several pairs) the big `img` tensors are
+    built by ONE multi-threaded gather from the stack of distinct images instead of a serial concatenation of 2 x len(pairs) pieces."""
+    uniq, index = {}, ([], [])
+    for side in (0, 1):
+        for p in pairs:
+            t = p[side]['img']
+            index[side].append(uniq.setdefault(id(t), (len(uniq), t))[0])
+    if len(uniq) < len(pairs) and all(t.shape[0] == 1 and not t.is_cuda for _, t in uniq.values()):
+        stack = torch.cat([t for _, t in sorted(uniq.values(), key=lambda x: x[0])], dim=0)
+        light = [tuple({k: v for k, v in view.items() if k != 'img'} for view in p) for p in pairs]
+        view1, view2 = collate_with_cat(light)
+        view1['img'] = stack.index_select(0, torch.tensor(index[0]))
+        view2['img'] = stack.index_select(0, torch.tensor(index[1]))
+        return view1, view2
+    return collate_with_cat(list(pairs))
+
+
+class _Background:
+    """Run a host-only function on a thread while the GPU loop runs (torch releases the GIL inside its kernels)."""
+
+    def __init__(self, fn, *args):
+        import threading
+        self.result, self.error = None, None
+
+        def run():
+            try:
+                self.result = fn(*args)
+            except BaseException as e:     # re-raised in join()
+                self.error = e
+        self.thread = threading.Thread(target=run, daemon=True)
+        self.thread.start()
+
+    def join(self):
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+        return self.result
 
 
 @torch.no_grad()
 def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, output_device='cpu'):
     """Same return value as `inference` (bit-identical: every engine kernel is batch-position independent), but every distinct
     image goes through the ViT-L encoder ONCE: n encoder passes instead of 2 x len(pairs) -- 20 instead of 380 for the demo's
-    complete symmetrised graph over 20 views, i.e. ~53 % fewer FLOPs end to end. Predictions are written
-    straight into preallocated outputs (one allocation per tensor, no per-batch host tensors, no final concatenation)."""
+    complete symmetrised graph over 20 views, i.e. ~53 % fewer FLOPs end to end. Predictions stream to the host
+    behind the compute (see _PredictionSink); the view dicts are collated on a host thread meanwhile."""
+    views = _Background(_collate_views, pairs)
     imgs, order = {}, []
     for v1, v2 in pairs:
         for v in (v1, v2):
@@ -101,19 +191,15 @@ def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, outp
     for i in tqdm.trange(0, len(order), enc_bs, disable=not verbose, desc='encode'):
         feats.append(model.encode_images(torch.cat([imgs[k] for k in order[i:i + enc_bs]], dim=0).to(device, non_blocking=True)))
     feats = torch.cat(feats, dim=0)
-    pred1, pred2 = _alloc_outputs(len(pairs), H, W, output_device)
+    sink = _PredictionSink(len(pairs), H, W, batch_size, output_device, feats.device)
     i1 = torch.tensor([pos[int(a['idx'])] for a, _ in pairs], device=feats.device)
     i2 = torch.tensor([pos[int(b['idx'])] for _, b in pairs], device=feats.device)
     for i in tqdm.trange(0, len(pairs), batch_size, disable=not verbose, desc='decode'):
         j = min(i + batch_size, len(pairs))
         p1, p2 = model.decode_pairs(feats.index_select(0, torch.cat((i1[i:j], i2[i:j]))), H, W)
-        pred1['pts3d'][i:j].copy_(p1['pts3d'], non_blocking=True)
-        pred1['conf'][i:j].copy_(p1['conf'], non_blocking=True)
-        pred2['pts3d_in_other_view'][i:j].copy_(p2['pts3d_in_other_view'], non_blocking=True)
-        pred2['conf'][i:j].copy_(p2['conf'], non_blocking=True)
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-    view1, view2 = _collate_views(pairs)
+        sink.put(i, j, p1, p2)
+    pred1, pred2 = sink.finish()
+    view1, view2 = views.join()
     return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)
 
 
@@ -135,16 +221,13 @@ def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None
             res = loss_of_one_batch(collate_with_cat(pairs[i:i + 1]), model, None, device)
             result.append(to_cpu(res) if str(output_device) == 'cpu' else res)
         return collate_with_cat(result, lists=True)
+    views = _Background(_collate_views, pairs)
     H, W = pairs[0][0]['img'].shape[-2:]
-    pred1, pred2 = _alloc_outputs(len(pairs), H, W, output_device)
+    sink = _PredictionSink(len(pairs), H, W, batch_size, output_device, device)
     for i in tqdm.trange(0, len(pairs), batch_size, disable=not verbose):
         j = min(i + batch_size, len(pairs))
         res = loss_of_one_batch(collate_with_cat(pairs[i:j]), model, None, device)
-        pred1['pts3d'][i:j].copy_(res['pred1']['pts3d'], non_blocking=True)
-        pred1['conf'][i:j].copy_(res['pred1']['conf'], non_blocking=True)
-        pred2['pts3d_in_other_view'][i:j].copy_(res['pred2']['pts3d_in_other_view'], non_blocking=True)
-        pred2['conf'][i:j].copy_(res['pred2']['conf'], non_blocking=True)
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-    view1, view2 = _collate_views(pairs)
+        sink.put(i, j, res['pred1'], res['pred2'])
+    pred1, pred2 = sink.finish()
+    view1, view2 = views.join()
     return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)

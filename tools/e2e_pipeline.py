@@ -32,10 +32,11 @@ def main():
     cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
     if '--align-only' in sys.argv:
         return align_stage(n, graph, H, W, dev)
-    m = AsymmetricCroCo3DStereo(precision='bf16', landscape_only=False, **MODEL_CONFIGS[cfg])
+    prec = next((a.split('=')[1] for a in sys.argv if a.startswith('--precision=')), None)      # default: the parity-grade mode (fp16x3)
+    m = AsymmetricCroCo3DStereo(precision=prec, landscape_only=False, **MODEL_CONFIGS[cfg])
     m.load_state_dict(synthetic_state_dict({k: torch.empty(v, device='meta') for k, v in m._spec.items()}, 0, OUT_GAIN[cfg], device=dev))
     m.to(dev)
-    print(f'== end to end: {n} views {H}x{W}, scene graph {graph} (symmetrised), {cfg}, bf16')
+    print(f'== end to end: {n} views {H}x{W}, scene graph {graph} (symmetrised), {cfg}, {m.precision}')
 
     imgs = synthetic_image_list(n, H, W, seed=0)
     pairs = make_pairs(imgs, scene_graph=graph, prefilter=None, symmetrize=True)
