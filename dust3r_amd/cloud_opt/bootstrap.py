@@ -174,7 +174,8 @@ def pose_params(R, T, scale=None):
     """(quat XYZW, signed-log translation[, log scale]) -- the aligner's pose parameterisation (base_opt.py:157-176)."""
     T = np.asarray(T, np.float64) / (scale if scale is not None else 1.0)
     p = np.concatenate((rotmat_to_quat_xyzw(R), np.sign(T) * np.log1p(np.abs(T))))
-    return p if scale is None else np.concatenate((p, [math.log(scale)]))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return p if scale is None else np.concatenate((p, [float(np.log(np.float64(scale)))]))
 
 
 def align_pose_sets(src, dst):
@@ -477,7 +478,8 @@ def _commit(scene, maps, anchor, G, S, pw_job, focals, poses):
         vals = scene.im_focals.data.clone()
         for k, f in enumerate(focals):
             if f is not None:
-                vals[k] = scene.focal_break * math.log(f)
+                with np.errstate(divide='ignore', invalid='ignore'):     # a degenerate focal gives -inf / nan like the reference's np.log, not an exception
+                    vals[k] = scene.focal_break * float(np.log(np.float64(f)))
         scene.im_focals.data.copy_(vals)
     if scene.verbose:
         print(' init loss =', float(scene()))
