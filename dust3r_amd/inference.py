@@ -76,24 +76,31 @@ def _alloc_outputs(P, H, W, out_device):
 
 
 class _PredictionSink:
-    """Where the per-batch predictions go. Device outputs: a plain copy. Host outputs (the reference's format, inference.py:68): a ring
-    of two PINNED staging sets; batch k's D2H copies run on a side stream while batch k + 1 computes, and the host moves batch k - 1
-    from the ring into the (pageable) result tensors meanwhile -- the GPU never waits for PCIe or for the host memcpy, and the big
-    result tensors need no pinned allocation."""
+    """Where the per-batch predictions go. Device outputs: a plain copy. Host outputs (the reference's format, inference.py:68): the
+    D2H copies of batch k are issued on a side stream AFTER batch k + 1 has been enqueued, so the blocking copy into the (pageable,
+    pre-touched) result tensors overlaps the next batch's compute. Measured on the MI355X box (profiles/r02_*/host_probe.log): a D2H
+    into touched pageable memory runs at PCIe speed (75 MB in 2 ms), into torch's pinned memory at 2.4 GB/s -- so no pinned staging."""
 
     KEYS = (('pred1', 'pts3d'), ('pred1', 'conf'), ('pred2', 'pts3d_in_other_view'), ('pred2', 'conf'))
 
-    def __init__(self, n_pairs, H, W, batch_size, out_device, compute_device):
-        self.pred1, self.pred2 = _alloc_outputs(n_pairs, H, W, out_device)
+    def __init__(self, n_pairs, H, W, out_device, compute_device, outputs=None):
+        self.pred1, self.pred2 = outputs if outputs is not None else _alloc_outputs(n_pairs, H, W, out_device)
         self.out = dict(pred1=self.pred1, pred2=self.pred2)
         self.host = torch.device(out_device).type == 'cpu' and torch.device(compute_device).type == 'cuda'
-        self.pending = []
+        self.stash = None
         if self.host:
             self.stream = torch.cuda.Stream(device=compute_device)
-            shapes = {('pred1', 'pts3d'): (batch_size, H, W, 3), ('pred1', 'conf'): (batch_size, H, W),
-                      ('pred2', 'pts3d_in_other_view'): (batch_size, H, W, 3), ('pred2', 'conf'): (batch_size, H, W)}
-            self.ring = [{k: torch.empty(shapes[k], dtype=torch.float32, pin_memory=True) for k in self.KEYS} for _ in range(2)]
-            self.slot = 0
+
+    def _flush(self):
+        if self.stash is None:
+            return
+        ev, i, j, src = self.stash
+        self.stash = None
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            for (a, b), t in src.items():
+                self.out[a][b][i:j].copy_(t)            # blocking for the host, concurrent with the main stream's kernels
+                t.record_stream(self.stream)
 
     def put(self, i, j, p1, p2):
         src = {('pred1', 'pts3d'): p1['pts3d'], ('pred1', 'conf'): p1['conf'], ('pred2', 'pts3d_in_other_view'): p2['pts3d_in_other_view'],
@@ -102,50 +109,49 @@ class _PredictionSink:
             for (a, b), t in src.items():
                 self.out[a][b][i:j].copy_(t, non_blocking=True)
             return
-        self._drain(keep=1)                                  # the slot about to be reused has been emptied by the host
-        ring = self.ring[self.slot]
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            for k, t in src.items():
-                ring[k][:j - i].copy_(t, non_blocking=True)
-                t.record_stream(self.stream)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        self.pending.append((ev, self.slot, i, j))
-        self.slot ^= 1
-
-    def _drain(self, keep=0):
-        while len(self.pending) > keep:
-            ev, slot, i, j = self.pending.pop(0)
-            ev.synchronize()
-            for (a, b) in self.KEYS:
-                self.out[a][b][i:j].copy_(self.ring[slot][(a, b)][:j - i])
+        ev = torch.cuda.Event()
+        ev.record()                                     # batch (i, j) is enqueued; now move the PREVIOUS batch while it runs
+        prev, self.stash = self.stash, None
+        if prev is not None:
+            self.stash = prev
+            self._flush()
+        self.stash = (ev, i, j, src)
 
     def finish(self):
         if self.host:
-            self._drain(keep=0)
+            self._flush()
+            self.stream.synchronize()
         elif torch.cuda.is_available():
             torch.cuda.synchronize()
         return self.pred1, self.pred2
 
 
-def _collate_views(pairs):
-    """view1 / view2 dicts of the whole pair list in the reference's collated format (inference.py:68-72: tensors concatenated on the
-    host, lists chained). When the pair list shares images (every `img` tensor object appears in several pairs) the big `img` tensors are
-    built by ONE multi-threaded gather from the stack of distinct images instead of a serial concatenation of 2 x len(pairs) pieces."""
+def _shared_images(pairs):
+    """(list of distinct `img` tensors in first-use order, index of every pair's view-1 image, of every view-2 image) when the pair list
+    shares image tensors (what make_pairs produces), else None."""
     uniq, index = {}, ([], [])
     for side in (0, 1):
         for p in pairs:
             t = p[side]['img']
             index[side].append(uniq.setdefault(id(t), (len(uniq), t))[0])
-    if len(uniq) < len(pairs) and all(t.shape[0] == 1 and not t.is_cuda for _, t in uniq.values()):
-        stack = torch.cat([t for _, t in sorted(uniq.values(), key=lambda x: x[0])], dim=0)
-        light = [tuple({k: v for k, v in view.items() if k != 'img'} for view in p) for p in pairs]
-        view1, view2 = collate_with_cat(light)
-        view1['img'] = stack.index_select(0, torch.tensor(index[0]))
-        view2['img'] = stack.index_select(0, torch.tensor(index[1]))
-        return view1, view2
-    return collate_with_cat(list(pairs))
+    if len(uniq) >= len(pairs) or not all(t.shape[0] == 1 for _, t in uniq.values()):
+        return None
+    return [t for _, t in sorted(uniq.values(), key=lambda x: x[0])], index[0], index[1]
+
+
+def _collate_views(pairs, shared=None, device_stack=None):
+    """view1 / view2 dicts of the whole pair list in the reference's collated format (inference.py:68-72: tensors concatenated on the
+    host, lists chained). When the pair list shares images, the two big `img` tensors (2 x len(pairs) images) are gathered ON THE GPU
+    from the stack of distinct images (already uploaded for the forward) and come back in one D2H each: a host-side concatenation of
+    600 pairs x 2 views ran 1.6 s per view on the GPU box (profiles/r02_*/host_probe.log), the device gather + copy ~0.1 s."""
+    if shared is None or device_stack is None:
+        return collate_with_cat(list(pairs))
+    light = [tuple({k: v for k, v in view.items() if k != 'img'} for view in p) for p in pairs]
+    view1, view2 = collate_with_cat(light)
+    dev = device_stack.device
+    view1['img'] = device_stack.index_select(0, torch.tensor(shared[1], device=dev)).cpu()
+    view2['img'] = device_stack.index_select(0, torch.tensor(shared[2], device=dev)).cpu()
+    return view1, view2
 
 
 class _Background:
@@ -175,8 +181,7 @@ def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, outp
     """Same return value as `inference` (bit-identical: every engine kernel is batch-position independent), but every distinct
     image goes through the ViT-L encoder ONCE: n encoder passes instead of 2 x len(pairs) -- 20 instead of 380 for the demo's
     complete symmetrised graph over 20 views, i.e. ~53 % fewer FLOPs end to end. Predictions stream to the host
-    behind the compute (see _PredictionSink); the view dicts are collated on a host thread meanwhile."""
-    views = _Background(_collate_views, pairs)
+    behind the compute (see _PredictionSink); the result tensors are allocated and touched on a host thread meanwhile."""
     imgs, order = {}, []
     for v1, v2 in pairs:
         for v in (v1, v2):
@@ -186,20 +191,24 @@ def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, outp
                 order.append(k)
     pos = {k: i for i, k in enumerate(order)}
     H, W = pairs[0][0]['img'].shape[-2:]
-    feats = []
+    host_out = torch.device(output_device).type == 'cpu'
+    outputs = _Background(lambda: tuple({k: torch.zeros_like(t) for k, t in d.items()} for d in _alloc_outputs(len(pairs), H, W, output_device))
+                          if host_out else _alloc_outputs(len(pairs), H, W, output_device))
+    feats, dev_imgs = [], []
     enc_bs = max(2, 2 * batch_size)
     for i in tqdm.trange(0, len(order), enc_bs, disable=not verbose, desc='encode'):
-        feats.append(model.encode_images(torch.cat([imgs[k] for k in order[i:i + enc_bs]], dim=0).to(device, non_blocking=True)))
+        dev_imgs.append(torch.cat([imgs[k] for k in order[i:i + enc_bs]], dim=0).to(device, non_blocking=True))
+        feats.append(model.encode_images(dev_imgs[-1]))
     feats = torch.cat(feats, dim=0)
-    sink = _PredictionSink(len(pairs), H, W, batch_size, output_device, feats.device)
-    i1 = torch.tensor([pos[int(a['idx'])] for a, _ in pairs], device=feats.device)
-    i2 = torch.tensor([pos[int(b['idx'])] for _, b in pairs], device=feats.device)
+    i1h, i2h = [pos[int(a['idx'])] for a, _ in pairs], [pos[int(b['idx'])] for _, b in pairs]
+    sink = _PredictionSink(len(pairs), H, W, output_device, feats.device, outputs=outputs.join())
+    i1, i2 = torch.tensor(i1h, device=feats.device), torch.tensor(i2h, device=feats.device)
     for i in tqdm.trange(0, len(pairs), batch_size, disable=not verbose, desc='decode'):
         j = min(i + batch_size, len(pairs))
         p1, p2 = model.decode_pairs(feats.index_select(0, torch.cat((i1[i:j], i2[i:j]))), H, W)
         sink.put(i, j, p1, p2)
     pred1, pred2 = sink.finish()
-    view1, view2 = views.join()
+    view1, view2 = _collate_views(pairs, shared=(None, i1h, i2h), device_stack=torch.cat(dev_imgs, dim=0))
     return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)
 
 
@@ -221,13 +230,22 @@ def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None
             res = loss_of_one_batch(collate_with_cat(pairs[i:i + 1]), model, None, device)
             result.append(to_cpu(res) if str(output_device) == 'cpu' else res)
         return collate_with_cat(result, lists=True)
-    views = _Background(_collate_views, pairs)
     H, W = pairs[0][0]['img'].shape[-2:]
-    sink = _PredictionSink(len(pairs), H, W, batch_size, output_device, device)
+    on_gpu = torch.device(device).type == 'cuda'
+    shared = _shared_images(pairs) if on_gpu else None
+    sink = _PredictionSink(len(pairs), H, W, output_device, device)
+    if shared is not None:       # the distinct images go up once; every batch is gathered on the device
+        stack = torch.cat(shared[0], dim=0).to(device, non_blocking=True)
+        i1, i2 = torch.tensor(shared[1], device=stack.device), torch.tensor(shared[2], device=stack.device)
     for i in tqdm.trange(0, len(pairs), batch_size, disable=not verbose):
         j = min(i + batch_size, len(pairs))
-        res = loss_of_one_batch(collate_with_cat(pairs[i:j]), model, None, device)
+        if shared is not None:
+            batch = collate_with_cat([tuple({k: v for k, v in view.items() if k != 'img'} for view in p) for p in pairs[i:j]])
+            batch[0]['img'], batch[1]['img'] = stack.index_select(0, i1[i:j]), stack.index_select(0, i2[i:j])
+        else:
+            batch = collate_with_cat(pairs[i:j])
+        res = loss_of_one_batch(batch, model, None, device)
         sink.put(i, j, res['pred1'], res['pred2'])
     pred1, pred2 = sink.finish()
-    view1, view2 = views.join()
+    view1, view2 = _collate_views(pairs, shared, stack if shared is not None else None)
     return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)

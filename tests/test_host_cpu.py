@@ -251,3 +251,20 @@ def test_load_images_equals_live_reference(tmp_path):
         for H1 in range(30, 140, 11):
             (W, H), box = fit_geometry(W1, H1, 96)
             assert max(W, H) == 96 and box[2] - box[0] <= W and (box[2] - box[0]) % 16 == 0
+
+
+def test_collated_views_from_shared_images_equal_plain_collation():
+    """inference()'s view dicts: the gather from the stack of distinct images (done on the GPU in production) gives exactly what the
+    reference's concatenation of every pair's views gives."""
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.inference import _collate_views, _shared_images
+    from dust3r_amd.synthetic import synthetic_image_list
+    from dust3r_amd.utils.device import collate_with_cat
+    pairs = make_pairs(synthetic_image_list(5, 16, 32, seed=2), 'swin-2', None, symmetrize=True)
+    shared = _shared_images(pairs)
+    assert shared is not None and len(shared[0]) == 5
+    v1, v2 = _collate_views(pairs, shared, torch.cat(shared[0], dim=0))
+    r1, r2 = collate_with_cat(list(pairs))
+    for a, b in ((v1, r1), (v2, r2)):
+        assert set(a) == set(b) and torch.equal(a['img'], b['img']) and a['idx'] == b['idx'] and a['instance'] == b['instance']
+        assert torch.equal(torch.as_tensor(a['true_shape']), torch.as_tensor(b['true_shape']))
