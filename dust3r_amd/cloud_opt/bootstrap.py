@@ -349,6 +349,8 @@ def solve_pnp_batch(dev, jobs, iterations=10, reproj_err=5.0, seed=0, refine_ite
             Hm = np.zeros((6, 6))
             Hm[ju] = g[a, 0:21]
             Hm = Hm + Hm.T - np.diag(np.diag(Hm)) + 1e-9 * np.eye(6)
+            if not np.isfinite(g[a]).all():
+                continue
             try:
                 d = np.linalg.solve(Hm, -g[a, 21:27])
             except np.linalg.LinAlgError:

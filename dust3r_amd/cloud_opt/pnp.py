@@ -41,12 +41,14 @@ def pose_from_dlt_normal(AtA, mean_point=None):
     """12x12 normal matrix of the DLT system (unknown = the rows of [R | T] stacked) -> (R, T) or None. The null vector is the
     eigenvector of the smallest eigenvalue, its 3x3 part is projected onto SO(3). `mean_point`: centroid of the world points,
     used for the cheirality sign when the points themselves are not at hand (the GPU path only has the moments)."""
+    if not np.isfinite(AtA).all():
+        return None
     try:
         _, V = np.linalg.eigh(AtA)
+        P = V[:, 0].reshape(3, 4)
+        U, S, Vt2 = np.linalg.svd(P[:, :3])
     except np.linalg.LinAlgError:
         return None
-    P = V[:, 0].reshape(3, 4)
-    U, S, Vt2 = np.linalg.svd(P[:, :3])
     if S.mean() < 1e-12:
         return None
     R = U @ Vt2
