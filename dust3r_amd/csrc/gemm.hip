@@ -804,17 +804,24 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             const float* rsrc = has_res ? reinterpret_cast<const float*>(p.res1) : reinterpret_cast<const float*>(p.out);
             const int rld = has_res ? p.ldr : p.ldo;
             const float* bsrc = has_bias ? p.bias : reinterpret_cast<const float*>(p.wgt);
-#pragma unroll
-            for (int g = 0; g < FI / 2; ++g) {
+            // The residual rows a lane adds in the read phase of group g are requested one group AHEAD (double buffered): the per-block
+            // trace (tools/gpu_probe.py gemmtrace) showed this epilogue as four serial HBM round trips, ~19 us per 256 x 256 tile.
+            // In place (res1 == out) is fine: a lane reads exactly the elements it stores later, and group g + 1's columns are
+            // disjoint from the columns group g is storing.
+            float4 rr[2][8];
+            auto request_rows = [&](int g, float4 (&dst)[8]) __attribute__((always_inline)) {
                 const int ig = ib + g * 32;
-                // the residual rows this lane adds in the read phase, all 8 requested now. In place (res1 == out) is fine: a lane
-                // reads exactly the elements it stores later and nobody else touches them.
-                float4 rr[8];
 #pragma unroll
                 for (int pass = 0; pass < 8; ++pass) {
                     const int m = min(jb + pass * 8 + rrow, p.M - 1), n = max(min(ig + rch * 4, p.n_store - 4), 0);
-                    rr[pass] = *reinterpret_cast<const float4*>(rsrc + (size_t)m * rld + n);
+                    dst[pass] = *reinterpret_cast<const float4*>(rsrc + (size_t)m * rld + n);
                 }
+            };
+            request_rows(0, rr[0]);
+#pragma unroll
+            for (int g = 0; g < FI / 2; ++g) {
+                const int ig = ib + g * 32;
+                if (g + 1 < FI / 2) request_rows(g + 1, rr[(g + 1) & 1]);
                 float4 bi2[2];
 #pragma unroll
                 for (int fl = 0; fl < 2; ++fl) {
@@ -836,8 +843,9 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                     const int row = pass * 8 + rrow;
                     float4 v = *reinterpret_cast<const float4*>(wreg + row * WROW + rch * 16);
                     const int m = jb + row, n = ig + rch * 4;
-                    v.x += has_res ? rr[pass].x : 0.f; v.y += has_res ? rr[pass].y : 0.f;
-                    v.z += has_res ? rr[pass].z : 0.f; v.w += has_res ? rr[pass].w : 0.f;
+                    const float4 rv = rr[g & 1][pass];
+                    v.x += has_res ? rv.x : 0.f; v.y += has_res ? rv.y : 0.f;
+                    v.z += has_res ? rv.z : 0.f; v.w += has_res ? rv.w : 0.f;
                     if (m < p.M && n < p.n_store) {
                         store16(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), nt);
                         if (p.out2) store4<DT>(p.out2, (size_t)m * p.ldo2 + n, v.x, v.y, v.z, v.w);
