@@ -1014,7 +1014,7 @@ template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hi
     const int grid = cdiv(p.M, CF::BM) * cdiv(p.n_store, CF::BN);
     GemmParams q = p;
     {   // first-round stagger (see the kernel): spread = factor x (epilogue bytes of the resident tiles / ~4.5 TB/s)
-        static const float factor = [] { const char* e = getenv("D3R_GEMM_STAGGER"); return e ? (float)atof(e) : 1.0f; }();
+        static const float factor = [] { const char* e = getenv("D3R_GEMM_STAGGER"); return e ? (float)atof(e) : 0.0f; }();   // default off: measured no gain (profiles/README.md), costs half a burst per launch
         static const int mode = [] { const char* e = getenv("D3R_GEMM_STAGGER_MODE"); return e ? atoi(e) : 0; }();
         static const DevInfo dev = dev_info();
         const int resident = dev.cus * (CF::LDS * 2 <= 160 * 1024 ? 2 : 1);

@@ -97,7 +97,8 @@ def test_demo_body_single_image_and_pair(gpu, tmp_path):
     model = _engine(gpu)
     for sizes in ([(160, 160)], [(200, 150), (180, 150)]):
         files = _write_images(tmp_path, sizes)
-        scene, loss, out = reconstruct(files, model, gpu, image_size=96, schedule='linear', niter=10, min_conf_thr=3.0, clean_depth=False,
+        # size 128: a square picture becomes 128 x 96 (the 4:3 rule), both multiples of the patch size
+        scene, loss, out = reconstruct(files, model, gpu, image_size=128, schedule='linear', niter=10, min_conf_thr=3.0, clean_depth=False,
                                        scenegraph_type='complete')
         assert loss is None and type(scene).__name__ == 'PairViewer'
         assert len(out['pts3d']) == 2 and out['cams2world'].shape == (2, 4, 4) and out['focals'].shape == (2,)
