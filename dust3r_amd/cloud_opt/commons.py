@@ -1,22 +1,12 @@
-"""Small shared pieces of the aligner -- mirror of the reference `dust3r/cloud_opt/commons.py`."""
+"""Small shared pieces of the aligner's host side (names as in the reference `dust3r/cloud_opt/commons.py`): edge keys, image shapes from
+the edge list, the confidence transform, the signed log / exp parameterisation of translations and the two learning-rate schedules.
+(Edge scores and the distance functions live in the HIP kernels.)"""
 import numpy as np
 import torch
 
 
 def edge_str(i, j):
     return f'{i}_{j}'
-
-
-def i_j_ij(ij):
-    return edge_str(*ij), ij
-
-
-def edge_conf(conf_i, conf_j, edge):
-    return float(conf_i[edge].mean() * conf_j[edge].mean())
-
-
-def compute_edge_scores(edges, conf_i, conf_j):
-    return {(i, j): edge_conf(conf_i, conf_j, e) for e, (i, j) in edges}
 
 
 def get_imshapes(edges, pred_i, pred_j):
@@ -42,17 +32,6 @@ def get_conf_trf(mode):
     if mode in ('id', 'none'):
         return lambda x: x
     raise ValueError(f'bad mode for {mode=}')
-
-
-def l2_dist(a, b, weight):
-    return (a - b).square().sum(dim=-1) * weight
-
-
-def l1_dist(a, b, weight):
-    return (a - b).norm(dim=-1) * weight
-
-
-ALL_DISTS = dict(l1=l1_dist, l2=l2_dist)
 
 
 def signed_log1p(x):

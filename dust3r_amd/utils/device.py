@@ -34,10 +34,6 @@ def to_cpu(x):
     return todevice(x, 'cpu')
 
 
-def to_cuda(x):
-    return todevice(x, 'cuda')
-
-
 def listify(elems):
     return [x for e in elems for x in e]
 

@@ -1,72 +1,44 @@
-"""Geometry helpers -- mirror of the reference `dust3r/utils/geometry.py` entries on the hot path:
-`xy_grid` (:15-37), `geotrf` (:40-101), `inv` (:104-111), `depthmap_to_camera_coordinates` /
-`depthmap_to_absolute_camera_coordinates` (:165-220), `get_med_dist_between_poses` (:364-366).
-"""
+"""Geometry helpers of the hot path. The reference's `dust3r/utils/geometry.py` offers general-purpose versions (`xy_grid` :15-37,
+`geotrf` :40-101, `inv` :104-111); this package needs three call shapes only -- a pixel grid, "apply a batch of 4x4 (or one 4x4 / 3x3) to
+points", and a matrix inverse -- plus `find_reciprocal_matches` (:345-361) on the GPU."""
 import numpy as np
 import torch
 
 
-def xy_grid(W, H, device=None, origin=(0, 0), unsqueeze=None, cat_dim=-1, homogeneous=False, **arange_kw):
-    """(H, W, 2) grid with out[j, i] = (i + origin[0], j + origin[1]); numpy when device is None."""
+def xy_grid(W, H, device=None, origin=(0, 0), **arange_kw):
+    """(H, W, 2) pixel grid, out[v, u] = (u + origin[0], v + origin[1]); a numpy array when device is None, else a tensor there."""
     if device is None:
-        tw, th = [np.arange(o, o + s, **arange_kw) for s, o in zip((W, H), origin)]
-        grid = tuple(np.meshgrid(tw, th, indexing='xy'))
-        if homogeneous:
-            grid = grid + (np.ones((H, W)),)
-        if unsqueeze is not None:
-            grid = tuple(np.expand_dims(g, unsqueeze) for g in grid)
-        return np.stack(grid, cat_dim) if cat_dim is not None else grid
-    tw, th = [torch.arange(o, o + s, device=device, **arange_kw) for s, o in zip((W, H), origin)]
-    grid = tuple(torch.meshgrid(tw, th, indexing='xy'))
-    if homogeneous:
-        grid = grid + (torch.ones((H, W), device=device),)
-    if unsqueeze is not None:
-        grid = tuple(g.unsqueeze(unsqueeze) for g in grid)
-    return torch.stack(grid, cat_dim) if cat_dim is not None else grid
+        u, v = np.meshgrid(np.arange(origin[0], origin[0] + W, **arange_kw), np.arange(origin[1], origin[1] + H, **arange_kw), indexing='xy')
+        return np.stack((u, v), axis=-1)
+    u, v = torch.meshgrid(torch.arange(origin[0], origin[0] + W, device=device, **arange_kw),
+                          torch.arange(origin[1], origin[1] + H, device=device, **arange_kw), indexing='xy')
+    return torch.stack((u, v), dim=-1)
 
 
 def geotrf(Trf, pts, ncol=None, norm=False):
-    """Apply (batched) 3x3 / 4x4 transforms to (..., 2|3) points; `norm` projects on the z=norm plane."""
-    assert Trf.ndim >= 2
-    if isinstance(Trf, np.ndarray):
-        pts = np.asarray(pts)
-    elif isinstance(Trf, torch.Tensor):
-        pts = torch.as_tensor(pts, dtype=Trf.dtype)
-    out_shape = pts.shape[:-1]
-    ncol = ncol or pts.shape[-1]
-
-    if isinstance(Trf, torch.Tensor) and isinstance(pts, torch.Tensor) and Trf.ndim == 3 and pts.ndim == 4:
-        d = pts.shape[3]
-        if Trf.shape[-1] == d:
-            pts = torch.einsum('bij, bhwj -> bhwi', Trf, pts)
-        elif Trf.shape[-1] == d + 1:
-            pts = torch.einsum('bij, bhwj -> bhwi', Trf[:, :d, :d], pts) + Trf[:, None, None, :d, d]
-        else:
-            raise ValueError(f'bad shape, not ending with 3 or 4, for {pts.shape=}')
+    """Points (..., d) through transforms of size (d+1)x(d+1) (affine part applied, homogeneous row ignored) or d x d.
+    Trf is one matrix, or a batch (B, ., .) matching the leading dimension of pts (B, ..., d). `norm` divides by the last
+    coordinate (projection) and scales by it; `ncol` keeps the first columns. numpy in -> numpy out, torch in -> torch out."""
+    is_np = isinstance(Trf, np.ndarray)
+    pts = np.asarray(pts) if is_np else torch.as_tensor(pts, dtype=Trf.dtype, device=Trf.device)
+    d = pts.shape[-1]
+    lin = Trf[..., :d, :d]
+    shift = Trf[..., :d, d] if Trf.shape[-1] == d + 1 else None
+    if Trf.ndim == 3:                                  # one transform per leading index of pts
+        flat = pts.reshape(pts.shape[0], -1, d)
+        out = flat @ (lin.swapaxes(-1, -2))
+        if shift is not None:
+            out = out + shift[:, None, :]
     else:
-        if Trf.ndim >= 3:
-            n = Trf.ndim - 2
-            assert Trf.shape[:n] == pts.shape[:n], 'batch size does not match'
-            Trf = Trf.reshape(-1, Trf.shape[-2], Trf.shape[-1])
-            if pts.ndim > Trf.ndim:
-                pts = pts.reshape(Trf.shape[0], -1, pts.shape[-1])
-            elif pts.ndim == 2:
-                pts = pts[:, None, :]
-        if pts.shape[-1] + 1 == Trf.shape[-1]:
-            Trf = Trf.swapaxes(-1, -2)
-            pts = pts @ Trf[..., :-1, :] + Trf[..., -1:, :]
-        elif pts.shape[-1] == Trf.shape[-1]:
-            Trf = Trf.swapaxes(-1, -2)
-            pts = pts @ Trf
-        else:
-            pts = Trf @ pts.T
-            if pts.ndim >= 2:
-                pts = pts.swapaxes(-1, -2)
+        out = pts.reshape(-1, d) @ (lin.T if is_np else lin.transpose(-1, -2))
+        if shift is not None:
+            out = out + shift
+    out = out.reshape(pts.shape)
     if norm:
-        pts = pts / pts[..., -1:]
+        out = out / out[..., -1:]
         if norm != 1:
-            pts *= norm
-    return pts[..., :ncol].reshape(*out_shape, ncol)
+            out = out * norm
+    return out[..., :ncol] if ncol else out
 
 
 def inv(mat):
@@ -75,39 +47,6 @@ def inv(mat):
     if isinstance(mat, np.ndarray):
         return np.linalg.inv(mat)
     raise ValueError(f'bad matrix type = {type(mat)}')
-
-
-def depthmap_to_camera_coordinates(depthmap, camera_intrinsics, pseudo_focal=None):
-    camera_intrinsics = np.float32(camera_intrinsics)
-    H, W = depthmap.shape
-    assert camera_intrinsics[0, 1] == 0.0 and camera_intrinsics[1, 0] == 0.0
-    if pseudo_focal is None:
-        fu, fv = camera_intrinsics[0, 0], camera_intrinsics[1, 1]
-    else:
-        assert pseudo_focal.shape == (H, W)
-        fu = fv = pseudo_focal
-    cu, cv = camera_intrinsics[0, 2], camera_intrinsics[1, 2]
-    u, v = np.meshgrid(np.arange(W), np.arange(H))
-    z_cam = depthmap
-    x_cam = (u - cu) * z_cam / fu
-    y_cam = (v - cv) * z_cam / fv
-    X_cam = np.stack((x_cam, y_cam, z_cam), axis=-1).astype(np.float32)
-    return X_cam, (depthmap > 0.0)
-
-
-def depthmap_to_absolute_camera_coordinates(depthmap, camera_intrinsics, camera_pose, **kw):
-    X_cam, valid_mask = depthmap_to_camera_coordinates(depthmap, camera_intrinsics)
-    X_world = X_cam
-    if camera_pose is not None:
-        R, t = camera_pose[:3, :3], camera_pose[:3, 3]
-        X_world = np.einsum('ik, vuk -> vui', R, X_cam) + t[None, None, :]
-    return X_world, valid_mask
-
-
-def get_med_dist_between_poses(poses):
-    from scipy.spatial.distance import pdist
-    from .device import to_numpy
-    return np.median(pdist([to_numpy(p[:3, 3]) for p in poses]))
 
 
 def find_reciprocal_matches(P1, P2):
