@@ -374,8 +374,9 @@ def clean_pointcloud_hip(im_confs, K, cams, depthmaps, all_pts3d, tol=0.001, bad
     pts = stack(all_pts3d, (3,))
     Kc = K.float().contiguous().reshape(n, 9)
     w2c = cams.float().contiguous().reshape(n, 16)
-    arr = lambda v: (C.c_int * len(v))(*v)  # noqa: E731
+    hs = torch.tensor([h for h, w in shapes], dtype=torch.int32).to(dev)
+    ws = torch.tensor([w for h, w in shapes], dtype=torch.int32).to(dev)
     with torch.cuda.device(dev):
-        check(lib.d3r_clean_pointcloud(n, ptr(conf), ptr(depth), ptr(pts), ptr(Kc), ptr(w2c), arr([h for h, w in shapes]),
-                                       arr([w for h, w in shapes]), maxA, float(tol), float(bad_conf), current_stream()), 'clean_pointcloud')
+        check(lib.d3r_clean_pointcloud(n, ptr(conf), ptr(depth), ptr(pts), ptr(Kc), ptr(w2c), ptr(hs), ptr(ws), maxA, float(tol), float(bad_conf),
+                                       current_stream()), 'clean_pointcloud')
     return [conf[i, :h * w].view(h, w).to(im_confs[i].dtype) for i, (h, w) in enumerate(shapes)]

@@ -733,25 +733,17 @@ __global__ __launch_bounds__(256) void clean_pointcloud_kernel(int i, int n, flo
 }  // namespace d3r
 
 extern "C" int d3r_clean_pointcloud(int n_imgs, float* conf, const float* depth, const float* pts3d, const float* intrinsics,
-                                    const float* world2cam, const int* img_h, const int* img_w, int max_area, float tol, float bad_conf,
+                                    const float* world2cam, const int* img_h_dev, const int* img_w_dev, int max_area, float tol, float bad_conf,
                                     void* stream) {
-    if (n_imgs <= 0 || !conf || !depth || !pts3d || !intrinsics || !world2cam || !img_h || !img_w || max_area <= 0 || tol < 0.f || tol >= 1.f)
+    if (n_imgs <= 0 || !conf || !depth || !pts3d || !intrinsics || !world2cam || !img_h_dev || !img_w_dev || max_area <= 0 || tol < 0.f || tol >= 1.f)
         return D3R_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    int* d_hw = nullptr;
-    if (hipMalloc((void**)&d_hw, 2 * (size_t)n_imgs * sizeof(int)) != hipSuccess) return D3R_ERR_ALLOC;
-    (void)hipMemcpyAsync(d_hw, img_h, n_imgs * sizeof(int), hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(d_hw + n_imgs, img_w, n_imgs * sizeof(int), hipMemcpyHostToDevice, st);
-    for (int i = 0; i < n_imgs; ++i) {
-        const int area = img_h[i] * img_w[i];
-        if (area <= 0 || area > max_area) { (void)hipStreamSynchronize(st); (void)hipFree(d_hw); return D3R_ERR_SHAPE; }
-        hipLaunchKernelGGL(d3r::clean_pointcloud_kernel, dim3((area + 255) / 256), dim3(256), 0, st, i, n_imgs, conf, depth, pts3d, intrinsics,
-                           world2cam, d_hw, d_hw + n_imgs, max_area, tol, bad_conf);
-    }
-    const hipError_t e = hipGetLastError();
-    (void)hipStreamSynchronize(st);   // d_hw is freed below; the call is one-shot post-processing, not a hot loop
-    (void)hipFree(d_hw);
-    return e == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
+    // one launch per image, in order (image i sees the cleaned confidences of the images before it); every launch covers max_area
+    // pixels and bounds itself by the image's own size, so nothing is allocated, copied or synchronised here
+    for (int i = 0; i < n_imgs; ++i)
+        hipLaunchKernelGGL(d3r::clean_pointcloud_kernel, dim3((max_area + 255) / 256), dim3(256), 0, st, i, n_imgs, conf, depth, pts3d, intrinsics,
+                           world2cam, img_h_dev, img_w_dev, max_area, tol, bad_conf);
+    return hipGetLastError() == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
 }
 
 // ---- brute-force 3-D nearest neighbour (find_reciprocal_matches, reference dust3r/utils/geometry.py:345-361) ---------------

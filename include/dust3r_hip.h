@@ -198,13 +198,13 @@ int d3r_aligner_run(d3r_aligner* a, int niter, int iter0, int niter_total, float
 int d3r_aligner_loss_grad(d3r_aligner* a, float* loss, float* g_pw_poses, float* g_im_poses, float* g_im_depthmaps,
                           float* g_im_focals, float* g_im_pp, float* g_pw_adaptors, void* stream);
 
-/* clean_pointcloud -- replaces the host-driven O(n^2 A) double loop of dust3r/cloud_opt/base_opt.py:369-405 (called through
- * BasePCOptimizer.clean_pointcloud, base_opt.py:234-244, by the demo's post-processing). conf [n][max_area] is updated in place with
+/* clean_pointcloud (dust3r/cloud_opt/base_opt.py:369-405): a point of image i that projects in front of image j's depth map (by more than
+ * tol) onto a pixel more confident than itself gets its confidence clipped to bad_conf. conf [n][max_area] is updated in place with
  * the reference's sequential semantics (image i sees the cleaned confidences of images j < i); depth [n][max_area],
- * pts3d [n][max_area][3] (world points), intrinsics [n][9], world2cam [n][16] are DEVICE fp32; img_h / img_w are HOST arrays.
- * Synchronises `stream` before returning. */
+ * pts3d [n][max_area][3] (world points), intrinsics [n][9], world2cam [n][16] are DEVICE fp32; img_h / img_w are DEVICE int arrays.
+ * Enqueues n launches on `stream`; no allocation, no synchronisation. */
 int d3r_clean_pointcloud(int n_imgs, float* conf, const float* depth, const float* pts3d, const float* intrinsics, const float* world2cam,
-                         const int* img_h, const int* img_w, int max_area, float tol, float bad_conf, void* stream);
+                         const int* img_h_dev, const int* img_w_dev, int max_area, float tol, float bad_conf, void* stream);
 
 /* exhaustive 3-D nearest neighbour: idx_out[q] = argmin_r |query[q] - ref[r]|^2 (lowest index on ties); query [n_query][3],
  * ref [n_ref][3] DEVICE fp32, idx_out DEVICE int32. The building block of find_reciprocal_matches (dust3r/utils/geometry.py:345-361,
