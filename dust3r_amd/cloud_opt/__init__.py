@@ -1,4 +1,5 @@
-"""`global_aligner` -- mirror of the reference `dust3r/cloud_opt/__init__.py:14-33`."""
+"""`global_aligner(dust3r_output, device, mode, **optim_kw)` -- the entry point of the alignment stage (reference
+`dust3r/cloud_opt/__init__.py:14-33`), with the reference's mode enum."""
 from enum import Enum
 
 from .optimizer import PointCloudOptimizer
@@ -11,15 +12,14 @@ class GlobalAlignerMode(Enum):
     PairViewer = "PairViewer"
 
 
+_SCENES = {GlobalAlignerMode.PointCloudOptimizer: PointCloudOptimizer, GlobalAlignerMode.PairViewer: PairViewer}
+
+
 def global_aligner(dust3r_output, device, mode=GlobalAlignerMode.PointCloudOptimizer, **optim_kw):
-    view1, view2, pred1, pred2 = [dust3r_output[k] for k in 'view1 view2 pred1 pred2'.split()]
-    if mode == GlobalAlignerMode.PointCloudOptimizer:
-        net = PointCloudOptimizer(view1, view2, pred1, pred2, **optim_kw).to(device)
-    elif mode == GlobalAlignerMode.ModularPointCloudOptimizer:
+    if mode == GlobalAlignerMode.ModularPointCloudOptimizer:
         raise NotImplementedError('ModularPointCloudOptimizer (the slow per-edge variant, unused by the demo) is out of scope: '
                                   'use GlobalAlignerMode.PointCloudOptimizer')
-    elif mode == GlobalAlignerMode.PairViewer:
-        net = PairViewer(view1, view2, pred1, pred2, **optim_kw).to(device)
-    else:
+    if mode not in _SCENES:
         raise NotImplementedError(f'Unknown mode {mode}')
-    return net
+    inputs = [dust3r_output[k] for k in ('view1', 'view2', 'pred1', 'pred2')]
+    return _SCENES[mode](*inputs, **optim_kw).to(device)

@@ -1,7 +1,8 @@
 """Small shared pieces of the aligner's host side (names as in the reference `dust3r/cloud_opt/commons.py`): edge keys, image shapes from
 the edge list, the confidence transform, the signed log / exp parameterisation of translations and the two learning-rate schedules.
 (Edge scores and the distance functions live in the HIP kernels.)"""
-import numpy as np
+import math
+
 import torch
 
 
@@ -10,28 +11,22 @@ def edge_str(i, j):
 
 
 def get_imshapes(edges, pred_i, pred_j):
-    n_imgs = max(max(e) for e in edges) + 1
-    imshapes = [None] * n_imgs
+    """(H, W) of every image, read off the pairwise predictions; an image must have one shape in all the edges that show it."""
+    shapes = {}
     for e, (i, j) in enumerate(edges):
-        shape_i, shape_j = tuple(pred_i[e].shape[0:2]), tuple(pred_j[e].shape[0:2])
-        if imshapes[i]:
-            assert imshapes[i] == shape_i, f'incorrect shape for image {i}'
-        if imshapes[j]:
-            assert imshapes[j] == shape_j, f'incorrect shape for image {j}'
-        imshapes[i], imshapes[j] = shape_i, shape_j
-    return imshapes
+        for img, pred in ((i, pred_i[e]), (j, pred_j[e])):
+            hw = tuple(pred.shape[0:2])
+            assert shapes.setdefault(img, hw) == hw, f'incorrect shape for image {img}'
+    return [shapes.get(k) for k in range(max(max(e) for e in edges) + 1)]
+
+
+_CONF_TRANSFORMS = {'log': torch.log, 'sqrt': torch.sqrt, 'm1': lambda x: x - 1, 'id': lambda x: x, 'none': lambda x: x}
 
 
 def get_conf_trf(mode):
-    if mode == 'log':
-        return lambda x: x.log()
-    if mode == 'sqrt':
-        return lambda x: x.sqrt()
-    if mode == 'm1':
-        return lambda x: x - 1
-    if mode in ('id', 'none'):
-        return lambda x: x
-    raise ValueError(f'bad mode for {mode=}')
+    if mode not in _CONF_TRANSFORMS:
+        raise ValueError(f'bad mode for {mode=}')
+    return _CONF_TRANSFORMS[mode]
 
 
 def signed_log1p(x):
@@ -44,7 +39,7 @@ def signed_expm1(x):
 
 def cosine_schedule(t, lr_start, lr_end):
     assert 0 <= t <= 1
-    return lr_end + (lr_start - lr_end) * (1 + np.cos(t * np.pi)) / 2
+    return lr_end + (lr_start - lr_end) * (1 + math.cos(t * math.pi)) / 2
 
 
 def linear_schedule(t, lr_start, lr_end):

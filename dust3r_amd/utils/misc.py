@@ -1,28 +1,25 @@
-"""Batch-shape glue -- mirror of the parts of the reference `dust3r/utils/misc.py:32-96` that the
-inference path uses."""
+"""Batch-shape helpers of the inference path (the reference's `dust3r/utils/misc.py:32-64`): recognising a symmetrised batch and
+building / swapping interleaved batches."""
 import torch
 
 
 def is_symmetrized(gt1, gt2):
-    """True when the batch is [(a,b),(b,a),(c,d),(d,c),...] (instances compared pairwise)."""
+    """True for a batch laid out [(a,b),(b,a),(c,d),(d,c),...]: every even position's pair is its successor's pair reversed."""
     x, y = gt1['instance'], gt2['instance']
-    if len(x) == len(y) and len(x) == 1:
+    if len(x) == len(y) == 1:
         return False
-    ok = True
-    for i in range(0, len(x), 2):
-        ok = ok and (x[i] == y[i + 1]) and (x[i + 1] == y[i])
-    return ok
+    return all(x[i] == y[i + 1] and x[i + 1] == y[i] for i in range(0, len(x), 2))
 
 
 def flip(tensor):
-    """tensor[0::2] <=> tensor[1::2]"""
+    """Swap the two members of every consecutive pair along dim 0."""
     return torch.stack((tensor[1::2], tensor[0::2]), dim=1).flatten(0, 1)
 
 
 def interleave(tensor1, tensor2):
-    res1 = torch.stack((tensor1, tensor2), dim=1).flatten(0, 1)
-    res2 = torch.stack((tensor2, tensor1), dim=1).flatten(0, 1)
-    return res1, res2
+    """(a0,b0,a1,b1,...) and (b0,a0,b1,a1,...)."""
+    both = torch.stack((tensor1, tensor2), dim=1)
+    return both.flatten(0, 1), both.flip(1).flatten(0, 1)
 
 
 def transposed(dic):
