@@ -299,7 +299,9 @@ def solve_pnp_batch(dev, jobs, iterations=10, reproj_err=5.0, seed=0, refine_ite
     valid = np.zeros((n, maxh), bool)
     for a, j in enumerate(jobs):
         H, W = j['H'], j['W']
-        cand = rng.randint(0, H * W, size=nh * 48)
+        cand = rng.randint(0, H * W, size=nh * 48)                    # drawn for every job: the stream does not depend on failures
+        if not (np.isfinite(j['f']) and j['f'] > 0):
+            continue                                                  # degenerate intrinsics: no hypothesis, the job fails
         cand_t = torch.from_numpy(cand).to(dev)
         pts = j['points'].reshape(-1, 3)[cand_t].double().cpu().numpy()
         ok = (j['confs'].reshape(-1)[cand_t] > j['thr']).cpu().numpy()

@@ -66,6 +66,9 @@ typedef GemmCfg<2, 4, 4, 4, 2, 128, 2, 2> Cfg256x128sw;
 typedef GemmCfg<2, 2, 4, 4, 2, 128, 2, 2> Cfg128sw;
 typedef GemmCfg<1, 8, 8, 4, 2, 128, 2, 2> Cfg512x128sw;
 typedef GemmCfg<2, 4, 8, 4, 2, 128, 2, 3> Cfg256a3;     // 256 x 256, asymmetric ring (A x 3, W x 2), 160 KiB LDS
+// (256 x 256 by FOUR waves of 128 x 128 -- 256 accumulator registers per lane, one wave per SIMD, a third less LDS read traffic per
+// MFMA -- compiles to 256 VGPR + 256 AGPR with the accumulator array in scratch: 90-105 TF/s algorithmic against 390-480, round 2.
+// With hipcc as the register allocator the 128 x 64 wave tile at two waves per SIMD is the largest that stays in registers.)
 typedef GemmCfg<1, 4, 8, 4, 2, 64, 3> Cfg256x128w4;  // M 256 x N 128, 4 waves of 128 (n) x 64 (m), 64-byte K rows: 48 KiB LDS, TWO
                                                   // blocks per CU, three stages (72 KiB)
 

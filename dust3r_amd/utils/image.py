@@ -42,7 +42,7 @@ def fit_geometry(W1, H1, size, square_ok=False, patch_size=16):
 
 def normalize_pixels(u8_hwc, device=None):
     """uint8 (H, W, 3) -> fp32 (1, 3, H, W) in [-1, 1]: (x / 255 - 0.5) / 0.5, evaluated on `device` (default: where the pixels are)."""
-    t = torch.from_numpy(np.ascontiguousarray(u8_hwc))
+    t = torch.from_numpy(np.array(u8_hwc, dtype=np.uint8, order='C'))    # a copy: PIL hands out read-only buffers
     if device is not None:
         t = t.to(device, non_blocking=True)
     t = t.permute(2, 0, 1).float().div(255)
