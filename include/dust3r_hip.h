@@ -170,7 +170,8 @@ int d3r_model_debug_read(d3r_model* m, int what, float* out_f32, size_t max_elem
  * They live in caller-owned device memory and are updated IN PLACE; the handle borrows them and the weight
  * tensors until destroy. pred_* [E][max_area][3] (read ONCE at create: the handle keeps its own planar
  * [E][3][max_area] copy so that the hot loop streams unit-stride float4s), w_* [E][max_area] = conf_trf(conf)
- * (zero in padding), fp32. ei/ej/img_h/img_w are HOST arrays.
+ * (zero in padding), fp32. ei/ej/img_h/img_w are HOST arrays. Alignment: pw_poses, im_depthmaps, pred_*, w_* 16 bytes, pw_adaptors 8
+ * (D3R_ERR_INVALID otherwise; any torch allocation satisfies it).
  */
 typedef struct d3r_aligner d3r_aligner;
 #define D3R_SCHEDULE_COSINE 0
@@ -179,6 +180,8 @@ typedef struct d3r_aligner d3r_aligner;
 #define D3R_ALIGNER_OPT_RESET_ADAM 2   /* clear the Adam moments, ordered on the stream of the next d3r_aligner_run */
 #define D3R_ALIGNER_OPT_OPTIMIZE_PP 3 /* 1: im_pp is a trainable parameter (PointCloudOptimizer(optimize_pp=True), optimizer.py:22,34) */
 #define D3R_ALIGNER_OPT_OPTIMIZE_ADAPTORS 4 /* 1: pw_adaptors are trainable (allow_pw_adaptors=True, base_opt.py:49,92) */
+#define D3R_ALIGNER_OPT_GENERIC_SMALL 5 /* 1: per-iteration pose / focal step by the strided-loop kernel (any E, n) instead of the
+                                          one-edge-per-thread kernel used for E, n <= 1024 (tests compare the two) */
 
 int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, const int* ei, const int* ej, const int* img_h, const int* img_w,
                        int max_area, const float* pred_i, const float* pred_j, const float* w_i, const float* w_j, float* pw_poses,

@@ -193,6 +193,32 @@ def test_principal_point_and_adaptor_parameters(gpu):
     assert not frozen.im_pp.requires_grad and not frozen.pw_adaptors.requires_grad
 
 
+def test_pose_step_kernels_agree(gpu):
+    """The per-iteration pose / focal step has two kernels: one edge per thread (E, n <= 1024) and the strided-loop form that takes any
+    size (D3R_ALIGNER_OPT_GENERIC_SMALL). Same gradients (fp64 sums in a different fixed order) and the same 10 Adam iterations with
+    every parameter group trainable."""
+    from dust3r_amd._lib import lib, check
+    from dust3r_amd.cloud_opt import global_aligner
+    from dust3r_amd.cloud_opt.base_opt import global_alignment_loop
+    out, init, gt = synthetic_scene(5, 32, 48, seed=3, symmetrize=True)
+    g = torch.Generator().manual_seed(9)
+    init = dict(init, im_pp=0.2 * torch.randn((5, 2), generator=g), pw_adaptors=0.3 * torch.randn((len(out['view1']['idx']), 2), generator=g))
+    results = []
+    for generic in (0, 1):
+        scene = global_aligner(out, gpu, optimize_pp=True, allow_pw_adaptors=True, verbose=False)
+        scene.load_state_dict(init)
+        check(lib.d3r_aligner_set_option(scene._ensure_engine(), 5, generic), 'set_option(generic small kernel)')
+        loss, grads = scene.loss_and_grads()
+        last = global_alignment_loop(scene, lr=0.01, niter=10, schedule='cosine', lr_min=1e-6)
+        results.append((float(loss), {k: v.clone() for k, v in grads.items()}, last, {k: getattr(scene, k).detach().clone() for k in ('pw_poses', 'im_poses', 'im_focals', 'im_pp', 'pw_adaptors', 'im_depthmaps')}))
+    (l0, g0, e0, s0), (l1, g1, e1, s1) = results
+    assert abs(l0 / l1 - 1) < 1e-6 and abs(e0 / e1 - 1) < 1e-5
+    for k in g0:
+        assert rel(g0[k], g1[k]) < 1e-5, k          # fp32 gradients formed from fp64 sums taken in two different fixed orders
+    for k in s0:
+        assert rel(s0[k], s1[k]) < 1e-5, k
+
+
 def test_noise_free_ground_truth_is_a_fixed_point(gpu):
     """With exact pairwise geometry and the ground-truth state, the loss is ~0 and stays there."""
     scene, out, init, gt = make_scene(gpu, 4, 32, 48, seed=2, noise=0.0, perturb=False)
