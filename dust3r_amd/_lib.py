@@ -64,7 +64,7 @@ def _load():
         'd3r_model_profile_read': (i, [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         'd3r_model_profile_launch': (i, [vp, i] + [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.c_double)] * 2),
         'd3r_aligner_create': (i, [C.POINTER(vp), i, i, ip, ip, ip, ip, i, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, f, f, f,
-                                   i, i, i, i, i]),
+                                   i, i, i, i, i, vp]),
         'd3r_aligner_destroy': (i, [vp]),
         'd3r_aligner_set_option': (i, [vp, i, i]),
         'd3r_aligner_run': (i, [vp, i, i, i, f, f, i, fp, vp]),

@@ -184,7 +184,7 @@ class PointCloudOptimizer(BasePCOptimizer):
                                          ptr(self.pw_adaptors.data), ptr(self.im_poses.data), ptr(self.im_depthmaps.data),
                                          ptr(self.im_focals.data), ptr(self.im_pp.data), float(self.base_scale), float(self.pw_break),
                                          float(self.focal_break), int(self.dist_name == 'l2'), int(self.norm_pw_scale),
-                                         int(self.im_poses.requires_grad), int(self.im_focals.requires_grad), 1024), 'aligner_create')
+                                         int(self.im_poses.requires_grad), int(self.im_focals.requires_grad), 1024, current_stream()), 'aligner_create')
             check(lib.d3r_aligner_set_option(h, 3, int(self.im_pp.requires_grad)), 'set_option(optimize_pp)')
             check(lib.d3r_aligner_set_option(h, 4, int(self.pw_adaptors.requires_grad)), 'set_option(allow_pw_adaptors)')
         self._engine, self._engine_sig = h, sig

@@ -709,7 +709,7 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
                                   const int* img_w, int max_area, const float* pred_i, const float* pred_j, const float* w_i,
                                   const float* w_j, float* pw_poses, float* pw_adaptors, float* im_poses, float* im_depth,
                                   float* im_focals, float* im_pp, float base_scale, float pw_break, float focal_break, int dist_l2,
-                                  int norm_pw_scale, int opt_poses, int opt_focals, int max_iters) {
+                                  int norm_pw_scale, int opt_poses, int opt_focals, int max_iters, void* stream) {
     if (!out || n_imgs <= 0 || n_edges <= 0 || max_area <= 0 || max_area % 4 != 0) return D3R_ERR_INVALID;
     // vector accesses: pw_poses rows as 2 x float4, im_depth / pred / weight rows as float4, pw_adaptors rows as float2
     if (((uintptr_t)pw_poses & 15) || ((uintptr_t)im_depth & 15) || ((uintptr_t)pw_adaptors & 7)) return D3R_ERR_INVALID;
@@ -758,7 +758,8 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     const size_t dbl = ((size_t)2 * n_edges * PW + (size_t)n_imgs * PW + (size_t)n_edges * 8 + 8);
     a->state_bytes = fl * sizeof(float) + dbl * sizeof(double) + 64;
     if (hipMalloc((void**)&a->state, a->state_bytes) != hipSuccess) { delete a; return D3R_ERR_ALLOC; }
-    (void)hipMemset(a->state, 0, a->state_bytes);
+    hipStream_t st = (hipStream_t)stream;   // the clear and the re-layout below are ordered on the caller's stream, like every later call
+    if (hipMemsetAsync(a->state, 0, a->state_bytes, st) != hipSuccess) { (void)hipFree(a->state); delete a; return D3R_ERR_LAUNCH; }
     float* b = a->state;
     a->depth_m = b + o_dm; a->depth_v = b + o_dv; a->pw_m = b + o_pwm; a->pw_v = b + o_pwv; a->imp_m = b + o_im;
     a->imp_v = b + o_iv; a->foc_m = b + o_fm; a->foc_v = b + o_fv; a->pp_m = b + o_pm; a->pp_v = b + o_pv; a->pa_m = b + o_am; a->pa_v = b + o_av; a->d_edge = b + o_de; a->d_img = b + o_di;
@@ -778,9 +779,9 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
         const size_t npix = (size_t)n_edges * max_area;
         if (hipMalloc((void**)&a->planar, 2 * npix * 3 * sizeof(float)) != hipSuccess) { (void)hipFree(a->state); (void)hipFree(a->d_w); delete a; return D3R_ERR_ALLOC; }
         const int grid = (int)((npix + 255) / 256 < 65536 ? (npix + 255) / 256 : 65536);
-        hipLaunchKernelGGL(aligner_planarize_kernel, dim3(grid), dim3(256), 0, nullptr, pred_i, a->planar, npix, max_area);
-        hipLaunchKernelGGL(aligner_planarize_kernel, dim3(grid), dim3(256), 0, nullptr, pred_j, a->planar + npix * 3, npix, max_area);
-        if (hipDeviceSynchronize() != hipSuccess) { (void)hipFree(a->planar); (void)hipFree(a->state); (void)hipFree(a->d_w); delete a; return D3R_ERR_LAUNCH; }
+        hipLaunchKernelGGL(aligner_planarize_kernel, dim3(grid), dim3(256), 0, st, pred_i, a->planar, npix, max_area);
+        hipLaunchKernelGGL(aligner_planarize_kernel, dim3(grid), dim3(256), 0, st, pred_j, a->planar + npix * 3, npix, max_area);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(a->planar); (void)hipFree(a->state); (void)hipFree(a->d_w); delete a; return D3R_ERR_LAUNCH; }
         a->pred[0] = a->planar; a->pred[1] = a->planar + npix * 3;
     }
     *out = a;

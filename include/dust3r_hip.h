@@ -171,7 +171,9 @@ int d3r_model_debug_read(d3r_model* m, int what, float* out_f32, size_t max_elem
  * tensors until destroy. pred_* [E][max_area][3] (read ONCE at create: the handle keeps its own planar
  * [E][3][max_area] copy so that the hot loop streams unit-stride float4s), w_* [E][max_area] = conf_trf(conf)
  * (zero in padding), fp32. ei/ej/img_h/img_w are HOST arrays. Alignment: pw_poses, im_depthmaps, pred_*, w_* 16 bytes, pw_adaptors 8
- * (D3R_ERR_INVALID otherwise; any torch allocation satisfies it).
+ * (D3R_ERR_INVALID otherwise; any torch allocation satisfies it). create enqueues its one-off work (clearing the Adam state, the planar
+ * copy of pred_*) on `stream` and does not synchronise the device: pred_* must be complete on that stream, and may be freed once it has
+ * drained; run / loss_grad on the same stream need no further ordering.
  */
 typedef struct d3r_aligner d3r_aligner;
 #define D3R_SCHEDULE_COSINE 0
@@ -187,7 +189,7 @@ int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, const int* ei
                        int max_area, const float* pred_i, const float* pred_j, const float* w_i, const float* w_j, float* pw_poses,
                        float* pw_adaptors, float* im_poses, float* im_depthmaps, float* im_focals, float* im_pp, float base_scale,
                        float pw_break, float focal_break, int dist_l2, int norm_pw_scale, int opt_im_poses, int opt_im_focals,
-                       int max_iters_per_run);
+                       int max_iters_per_run, void* stream);
 int d3r_aligner_destroy(d3r_aligner* a);
 int d3r_aligner_set_option(d3r_aligner* a, int option, int value);
 /* `niter` iterations of global_alignment_iter; iteration k uses lr = schedule((iter0 + k) / niter_total).
