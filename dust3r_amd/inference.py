@@ -43,6 +43,23 @@ def loss_of_one_batch(batch, model, criterion, device, symmetrize_batch=False, u
     return result[ret] if ret else result
 
 
+def _engine_step(model, batch_size):
+    """Pairs per model call. The reference runs `batch_size` pairs per call; an engine that declares `engine_batch` gets at least that
+    many (its results do not depend on how the pair list is cut into batches: bit-identical, tests/test_forward_gpu.py)."""
+    return max(int(batch_size), int(getattr(model, 'engine_batch', 0) or 0), 1)
+
+
+def _rows_of(res, r):
+    """Row r of a collated result (nested dicts of tensors / lists), as the one-pair batch the reference's per-pair loop produces."""
+    if isinstance(res, dict):
+        return {k: _rows_of(v, r) for k, v in res.items()}
+    if isinstance(res, torch.Tensor):
+        return res[r:r + 1]
+    if isinstance(res, (list, tuple)):
+        return type(res)([res[r]])
+    return res
+
+
 def check_if_same_size(pairs):
     shapes1 = [img1['img'].shape[-2:] for img1, img2 in pairs]
     shapes2 = [img2['img'].shape[-2:] for img1, img2 in pairs]
@@ -195,6 +212,7 @@ def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, outp
     outputs = _Background(lambda: tuple({k: torch.zeros_like(t) for k, t in d.items()} for d in _alloc_outputs(len(pairs), H, W, output_device))
                           if host_out else _alloc_outputs(len(pairs), H, W, output_device))
     feats, dev_imgs = [], []
+    batch_size = _engine_step(model, batch_size)
     enc_bs = max(2, 2 * batch_size)
     for i in tqdm.trange(0, len(order), enc_bs, disable=not verbose, desc='encode'):
         dev_imgs.append(torch.cat([imgs[k] for k in order[i:i + enc_bs]], dim=0).to(device, non_blocking=True))
@@ -225,12 +243,27 @@ def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None
     if encode_once and not multiple_shapes and _encode_once_ok(pairs, model):
         return inference_encode_once(pairs, model, device, batch_size=batch_size, verbose=verbose, output_device=output_device)
     if multiple_shapes:
-        result = []
-        for i in tqdm.trange(0, len(pairs), 1, disable=not verbose):
-            res = loss_of_one_batch(collate_with_cat(pairs[i:i + 1]), model, None, device)
-            result.append(to_cpu(res) if str(output_device) == 'cpu' else res)
+        # dust3r/inference.py:60-68 falls back to one pair per call. Here the pairs are grouped by their (view 1, view 2) image sizes,
+        # every group runs `engine_batch` pairs per call, and the per-pair rows go back to their positions in the list: same structure
+        # (lists, one entry per pair), bit-identical values.
+        step = int(getattr(model, 'engine_batch', 0) or 0) or 1
+        groups = {}
+        for k, (v1, v2) in enumerate(pairs):
+            groups.setdefault((tuple(v1['img'].shape[-2:]), tuple(v2['img'].shape[-2:])), []).append(k)
+        result = [None] * len(pairs)
+        bar = tqdm.tqdm(total=len(pairs), disable=not verbose)
+        for members in groups.values():
+            for i in range(0, len(members), step):
+                chunk = members[i:i + step]
+                res = loss_of_one_batch(collate_with_cat([pairs[k] for k in chunk]), model, None, device)
+                res = to_cpu(res) if str(output_device) == 'cpu' else res
+                for r, k in enumerate(chunk):
+                    result[k] = _rows_of(res, r)
+                bar.update(len(chunk))
+        bar.close()
         return collate_with_cat(result, lists=True)
     H, W = pairs[0][0]['img'].shape[-2:]
+    batch_size = _engine_step(model, batch_size)
     on_gpu = torch.device(device).type == 'cuda'
     shared = _shared_images(pairs) if on_gpu else None
     sink = _PredictionSink(len(pairs), H, W, output_device, device)

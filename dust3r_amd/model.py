@@ -138,6 +138,10 @@ class AsymmetricCroCo3DStereo(nn.Module):
                                norm_im2_in_dec=norm_im2_in_dec, pos_embed=pos_embed)
         self.precision = precision or os.environ.get('DUST3R_AMD_PRECISION', DEFAULT_PRECISION)
         self.dpt_skip_relu_inplace = bool(int(os.environ.get('DUST3R_AMD_DPT_RELU_INPLACE', '0')))
+        # pairs per engine call that `inference()` coalesces to, whatever batch_size the caller names (the reference demo passes 1):
+        # every kernel is batch-position independent, so the result is bit-identical, and the MI355X needs >= 8 pairs in flight to be
+        # throughput- rather than launch-bound (66 pairs/s at 1 pair per call, 155 at 8, 178 at 32: tools/latency_probe.py)
+        self.engine_batch = int(os.environ.get('DUST3R_AMD_ENGINE_BATCH', '32'))
         self._cfg = dict(enc_embed_dim=enc_embed_dim, enc_depth=enc_depth, dec_embed_dim=dec_embed_dim, dec_depth=dec_depth,
                          patch_size=patch_size, head_type=head_type)
         self._spec = expected_state(self._cfg)

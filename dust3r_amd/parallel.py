@@ -48,10 +48,11 @@ def inference_sharded(pairs, model, device, batch_size=8, verbose=False, group=N
     """Drop-in for `inference(pairs, model, device, batch_size)` when torch.distributed is initialised:
     identical return value on every rank. Requires all pairs to share one image size (the sharded
     path is the throughput path; mixed sizes go through `inference`)."""
-    from .inference import check_if_same_size, loss_of_one_batch
+    from .inference import _engine_step, check_if_same_size, loss_of_one_batch
     assert check_if_same_size(pairs), 'inference_sharded needs pairs of one image size'
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi, per = shard_bounds(len(pairs), rank, world)
+    batch_size = _engine_step(model, batch_size)     # at least the engine's preferred pairs per call (bit-identical results)
     gather_device = torch.device(gather_device if gather_device is not None else device)
     H, W = pairs[0][0]['img'].shape[-2:]
     local = torch.zeros((per, H, W, 8), dtype=torch.float32, device=gather_device)

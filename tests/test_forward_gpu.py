@@ -215,6 +215,35 @@ def test_inference_api_end_to_end(gpu):
     assert mx < 1e-3 and mx2 < 1e-3
 
 
+def test_inference_batching_is_output_identical(gpu):
+    """`inference()` coalesces to `model.engine_batch` pairs per engine call whatever batch_size the caller names (the reference demo
+    passes 1), and groups pairs of mixed image sizes by shape instead of running them one by one (dust3r/inference.py:60-68): both
+    must be bit-identical to the reference's schedule, on the default-precision engine."""
+    from dust3r_amd.inference import inference
+    from oracle.dust3r_ref import build_ref_model
+    eng = engine_from_oracle(build_ref_model('tiny_dpt'), 'tiny_dpt', None, gpu)
+    g = torch.Generator().manual_seed(4)
+    shapes = [(32, 48), (48, 32), (32, 48), (32, 32), (48, 32), (32, 48), (32, 48)]
+    imgs = [dict(img=torch.rand((1, 3, h, w), generator=g) * 2 - 1, true_shape=torch.tensor([[h, w]], dtype=torch.int32), idx=k, instance=str(k))
+            for k, (h, w) in enumerate(shapes)]
+    mixed = [(imgs[i], imgs[j]) for i in range(len(imgs)) for j in range(len(imgs)) if i != j]
+    same = [(imgs[i], imgs[j]) for i in (0, 2, 5, 6) for j in (0, 2, 5, 6) if i != j]
+    for pairs in (mixed, same):
+        outs = []
+        for eb in (1, 5):
+            eng.engine_batch = eb
+            outs.append(inference(pairs, eng, gpu, batch_size=1, verbose=False, encode_once=False))
+        a, b = outs
+        for view, keys in (('pred1', ('pts3d', 'conf')), ('pred2', ('pts3d_in_other_view', 'conf'))):
+            for k in keys:
+                xa, xb = a[view][k], b[view][k]
+                if isinstance(xa, list):
+                    assert len(xa) == len(xb) == len(pairs) and all(torch.equal(p, q) for p, q in zip(xa, xb)), (view, k)
+                else:
+                    assert torch.equal(xa, xb), (view, k)
+        assert a['view1']['idx'] == b['view1']['idx'] and a['view2']['instance'] == b['view2']['instance']
+
+
 def test_full_size_fp32_pair_matches_oracle(gpu):
     """BASELINE config: DUSt3R_ViTLarge_BaseDecoder_512_dpt, one 512x384 pair, fp32 engine vs CPU oracle <= 1e-3."""
     from oracle.dust3r_ref import build_ref_model

@@ -268,3 +268,52 @@ def test_collated_views_from_shared_images_equal_plain_collation():
     for a, b in ((v1, r1), (v2, r2)):
         assert set(a) == set(b) and torch.equal(a['img'], b['img']) and a['idx'] == b['idx'] and a['instance'] == b['instance']
         assert torch.equal(torch.as_tensor(a['true_shape']), torch.as_tensor(b['true_shape']))
+
+
+def test_inference_groups_mixed_shapes_and_coalesces_batches():
+    """`inference()` on a model that declares `engine_batch`: pairs of mixed image sizes are grouped by shape and batched, same-size
+    lists run `engine_batch` pairs per call whatever batch_size says -- and the returned structure and values equal the reference's
+    schedule (one pair per call for mixed sizes, batch_size per call otherwise), here on a deterministic stand-in network."""
+    import torch
+    from dust3r_amd.inference import inference
+
+    class StandIn:
+        calls = None
+
+        def __init__(self, engine_batch=None):
+            self.calls = []
+            if engine_batch:
+                self.engine_batch = engine_batch
+
+        def __call__(self, view1, view2):
+            a, b = view1['img'], view2['img']
+            self.calls.append(a.shape[0])
+            pts1 = torch.stack((a.mean((1, 2, 3)), b.mean((1, 2, 3)), (a * 2).amax((1, 2, 3))), -1)[:, None, None, :].expand(-1, a.shape[2], a.shape[3], -1) + a.permute(0, 2, 3, 1)
+            pts2 = b.permute(0, 2, 3, 1) * 3 - b.mean((1, 2, 3))[:, None, None, None]
+            return dict(pts3d=pts1.contiguous(), conf=1 + a.sum(1).abs()), dict(pts3d_in_other_view=pts2.contiguous(), conf=1 + b.sum(1).abs())
+
+    g = torch.Generator().manual_seed(0)
+    shapes = [(16, 32), (32, 16), (16, 32), (16, 16), (32, 16), (16, 32)]
+    imgs = [dict(img=torch.rand((1, 3, h, w), generator=g), true_shape=torch.tensor([[h, w]], dtype=torch.int32), idx=k, instance=str(k))
+            for k, (h, w) in enumerate(shapes)]
+    pairs = [(imgs[i], imgs[j]) for i in range(len(imgs)) for j in range(len(imgs)) if i != j]
+    plain, eng = StandIn(), StandIn(engine_batch=4)
+    ref = inference(pairs, plain, 'cpu', batch_size=1, verbose=False)
+    out = inference(pairs, eng, 'cpu', batch_size=1, verbose=False)
+    assert set(plain.calls) == {1} and max(eng.calls) == 4 and len(eng.calls) < len(plain.calls) // 2
+    for view in ('view1', 'view2', 'pred1', 'pred2'):
+        assert ref[view].keys() == out[view].keys()
+        for k in ref[view]:
+            a, b = ref[view][k], out[view][k]
+            assert type(a) is type(b) and len(a) == len(b) == len(pairs), (view, k)
+            for x, y in zip(a, b):
+                assert (torch.equal(x, y) if isinstance(x, torch.Tensor) else x == y), (view, k)
+    # same-size list: engine_batch pairs per call instead of batch_size, identical collated tensors
+    same = [(imgs[i], imgs[j]) for i in (0, 2, 5) for j in (0, 2, 5) if i != j]
+    plain, eng = StandIn(), StandIn(engine_batch=4)
+    ref = inference(same, plain, 'cpu', batch_size=1, verbose=False)
+    out = inference(same, eng, 'cpu', batch_size=1, verbose=False)
+    assert plain.calls == [1] * 6 and eng.calls == [4, 2]
+    for view in ('pred1', 'pred2'):
+        for k in ref[view]:
+            assert torch.equal(ref[view][k], out[view][k])

@@ -1,0 +1,47 @@
+"""GPU probe (not product, not a test): where is the engine launch-bound rather than throughput-bound?
+ * forward at B = 1, 2, 4, 8, 32 pairs per call (the reference demo calls inference() with batch_size = 1);
+ * aligner iterations/s on small scenes (PairViewer-size to the BASELINE scene).
+Usage (GPU box): python tools/latency_probe.py"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, '.')
+from bench import build_model, H, W  # noqa: E402
+from dust3r_amd.synthetic import synthetic_scene, synthetic_views  # noqa: E402
+
+
+def main():
+    dev = torch.device('cuda', 0)
+    model = build_model('fp16x3', dev)
+    for B in (1, 2, 4, 8, 32):
+        v1, v2 = synthetic_views(B, H, W, seed=0, device=dev)
+        for _ in range(3):
+            model(v1, v2)
+        torch.cuda.synchronize()
+        n = 20 if B <= 8 else 5
+        t = time.perf_counter()
+        for _ in range(n):
+            model(v1, v2)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / n
+        print(f'forward B={B:2d}: {dt * 1e3:8.2f} ms/call  {B / dt:7.1f} pairs/s', flush=True)
+    del model
+    from dust3r_amd.cloud_opt import global_aligner
+    from dust3r_amd.cloud_opt.base_opt import global_alignment_loop
+    for (n, h, w) in ((2, 224, 224), (4, 224, 224), (4, 384, 512), (8, 384, 512), (20, 384, 512)):
+        out, init, gt = synthetic_scene(n, h, w, seed=0, symmetrize=True)
+        scene = global_aligner(out, dev, verbose=False)
+        scene.load_state_dict(init)
+        global_alignment_loop(scene, lr=0.01, niter=50, schedule='cosine', lr_min=1e-6)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        global_alignment_loop(scene, lr=0.01, niter=300, schedule='cosine', lr_min=1e-6)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        print(f'aligner n={n:2d} E={scene.n_edges:3d} {h}x{w}: {300 / dt:8.0f} iters/s  ({dt / 300 * 1e6:6.1f} us/iter)', flush=True)
+
+
+if __name__ == '__main__':
+    main()
