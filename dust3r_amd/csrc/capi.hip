@@ -27,6 +27,8 @@ extern "C" int d3r_linear(const void* act, const void* wgt, const float* bias, v
     return rc_of(launch_gemm(dtype, p, (hipStream_t)stream));
 }
 
+extern "C" int d3r_conv_k_slice_major(void) { return d3r::conv_k_slice_major() ? 1 : 0; }
+
 extern "C" int d3r_conv2d_nhwc(const void* in, const void* wgt, const float* bias, void* out, const void* res1, const void* res2, void* out_relu_copy,
                                int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int pad, int relu, const void* zero_page, int dtype,
                                void* stream) {

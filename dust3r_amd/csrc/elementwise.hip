@@ -392,7 +392,12 @@ template <int DT> __global__ __launch_bounds__(256) void pack_weight_kernel(Pack
         const size_t co = i / ((size_t)p.cin * kk);
         const int rem = (int)(i - co * (size_t)p.cin * kk);
         const int ci = rem / kk, t = rem - ci * kk;
-        d = co * (size_t)p.dst_cols + (size_t)t * p.cin_pad + ci;
+        if (p.kslice_major) {                    // [co][(ci / KS) * (k*k*KS) + t * KS + ci % KS], KS = elements of one K step
+            constexpr int KS = 128 / Traits<DT>::EB;
+            d = co * (size_t)p.dst_cols + (size_t)(ci / KS) * ((size_t)kk * KS) + (size_t)t * KS + (ci % KS);
+        } else {
+            d = co * (size_t)p.dst_cols + (size_t)t * p.cin_pad + ci;
+        }
     } else {                                     // PACK_CONVT: [Cin][Cout][k][k] -> [(ky*k+kx)*cout_pad + co][ci]
         const int kk = p.ksize * p.ksize;
         const size_t ci = i / ((size_t)p.cols * kk);

@@ -262,7 +262,7 @@ int pack_slot(d3r_model* m, Slot& s, const float* data, int ndim, const int64_t*
             break;
         case PK_CONV:
             if (ndim != 4 || shape[0] != s.rows || shape[1] != s.cin || shape[2] != s.ksize || shape[3] != s.ksize) return D3R_ERR_SHAPE;
-            pp.kind = PACK_CONV; pp.cin = s.cin; pp.cin_pad = s.cin_pad; pp.ksize = s.ksize;
+            pp.kind = PACK_CONV; pp.cin = s.cin; pp.cin_pad = s.cin_pad; pp.ksize = s.ksize; pp.kslice_major = conv_k_slice_major() ? 1 : 0;
             break;
         case PK_CONVT:
             if (ndim != 4 || shape[0] != s.rows || shape[1] != s.cols || shape[2] != s.ksize || shape[3] != s.ksize) return D3R_ERR_SHAPE;

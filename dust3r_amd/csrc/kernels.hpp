@@ -40,6 +40,7 @@ struct GemmParams {
     // first-round start stagger (set by launch_gemm): blocks with blockIdx < first_round wait stagger_ticks * slot / 32 wall-clock
     // ticks before they start, so that the epilogue bursts of the resident tiles do not all hit HBM at the same time
     int stagger_ticks = 0, first_round = 0, stagger_mode = 0;
+    int kslice_major = 0;        // implicit-GEMM K order: 0 = (tap, channel), 1 = (channel slice of one K step, tap, channel in slice); set by launch_gemm
     // diagnostics (d3r_gemm_set_trace): 8 x uint64 per block -- wall-clock ticks at entry / K-loop start / K-loop end / epilogue
     // issued / stores drained, then HW_ID, XCC_ID, blockIdx
     unsigned long long* trace = nullptr;
@@ -89,7 +90,9 @@ struct PackParams {
     const float* src = nullptr; void* dst = nullptr;
     size_t numel = 0;
     int kind = PACK_MAT, cols = 0, row_off = 0, dst_cols = 0, cin = 0, cin_pad = 0, ksize = 1, cout_pad = 0;
+    int kslice_major = 0;        // PACK_CONV: K order of the packed rows (conv_k_slice_major())
 };
+bool conv_k_slice_major();       // process-wide K order of implicit-GEMM operands (kernel and weight packing agree on it)
 hipError_t launch_pack_weight(int dt, const PackParams& p, hipStream_t s);
 hipError_t launch_pack_convt_bias(const float* src, float* dst, int cout, int cout_pad, int taps, hipStream_t s);
 

@@ -87,9 +87,16 @@ def linear_x3(act, weight, bias=None, epilogue='store', residual=None):
     return out if epi == 1 else unpack_x3(out)
 
 
-def pack_conv_weight(w):
-    """torch (Cout, Cin, kh, kw) -> (round_up(Cout,256), kh*kw*Cin) with K index (ky, kx, cin)."""
-    return pad_rows(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
+def pack_conv_weight(w, dtype=None):
+    """torch (Cout, Cin, kh, kw) -> (round_up(Cout,256), kh*kw*Cin) in the K order d3r_conv2d_nhwc expects (include/dust3r_hip.h):
+    channel slices of one K step (128 bytes) outermost, then the taps, then the channels of the slice -- or (ky, kx, cin) when the
+    library runs with D3R_CONV_KORDER=0."""
+    Cout, Cin, kh, kw = w.shape
+    if lib.d3r_conv_k_slice_major():
+        S = 128 // torch.empty((), dtype=dtype or w.dtype).element_size()
+        assert Cin % S == 0, f'{Cin=} must be a multiple of {S}'
+        return pad_rows(w.reshape(Cout, Cin // S, S, kh * kw).permute(0, 1, 3, 2).reshape(Cout, -1))
+    return pad_rows(w.permute(0, 2, 3, 1).reshape(Cout, -1))
 
 
 _zero_pages = {}

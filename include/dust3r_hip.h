@@ -65,9 +65,14 @@ int d3r_layernorm(const float* x, const float* gamma, const float* beta, void* o
 int d3r_linear(const void* act, const void* wgt, const float* bias, void* out, const float* residual, int M, int N, int K,
                int epilogue, int dtype, void* stream);
 
-/* 2-D convolution, NHWC, as implicit GEMM: in [B][Hin][Win][Cin] dtype, wgt [round_up(Cout,256)][k*k*Cin] dtype with
- * K index (ky, kx, cin); out [B][Hout][Wout][Cout] dtype = [relu](conv + bias + res1 + res2)   (DPT head convs,
- * dust3r/heads/dpt_head.py:34-65). zero_page: >= 256 bytes of zeros. */
+/* 2-D convolution, NHWC, as implicit GEMM: in [B][Hin][Win][Cin] dtype, wgt [round_up(Cout,256)][k*k*Cin] dtype;
+ * out [B][Hout][Wout][Cout] dtype = [relu](conv + bias + res1 + res2)   (DPT head convs, dust3r/heads/dpt_head.py:34-65).
+ * K order of a weight row: with S = 128 / sizeof(dtype) channels per K step (Cin % S == 0),
+ *   d3r_conv_k_slice_major() == 1 (default): k = (cin / S) * (k*k*S) + (ky*k + kx) * S + cin % S   (all taps of one channel slice
+ *                                            back to back: the slice's input lines are re-read from L2, not from HBM)
+ *   == 0 (D3R_CONV_KORDER=0, probe)        : k = (ky*k + kx) * Cin + cin.
+ * zero_page: >= 256 bytes of zeros. */
+int d3r_conv_k_slice_major(void);
 int d3r_conv2d_nhwc(const void* in, const void* wgt, const float* bias, void* out, const void* res1, const void* res2,
                     void* out_relu_copy, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int pad, int relu,
                     const void* zero_page, int dtype, void* stream);
