@@ -32,7 +32,8 @@ template <int DT> struct AttnCfg {
     static constexpr int LDS = 2 * STAGE;
 };
 
-template <int DT>
+// ODT: layout of the output rows -- DT, or the fp16 + fp8 activation rows when the following proj GEMM runs in that mode
+template <int DT, int ODT = DT>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = AttnCfg<DT>;
@@ -243,36 +244,39 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = db * 32 + 8 * g + 4 * hh;
-                store4<DT>(p.out, obase + d, o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv,
-                           o[db][4 * g + 3] * inv);
+                store4<ODT>(p.out, obase + d, o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv,
+                            o[db][4 * g + 3] * inv);
             }
     }
 }
 
-template <int DT> static hipError_t launch_t(const AttnParams& p, hipStream_t s) {
+template <int DT, int ODT = DT> static hipError_t launch_t(const AttnParams& p, hipStream_t s) {
     // the dynamic-LDS limit is a per-device function attribute: raise it once on every device this process launches on
     static std::atomic<unsigned long long> attr_done{0};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     const unsigned long long dev_bit = 1ull << (dev_id & 63);
     if (!(attr_done.load(std::memory_order_relaxed) & dev_bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DT, ODT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   AttnCfg<DT>::LDS);
         attr_done.fetch_or(dev_bit, std::memory_order_relaxed);
     }
     const int grid = p.B * p.H * ((p.Nq + 127) / 128);
-    hipLaunchKernelGGL(attention_kernel<DT>, dim3(grid), dim3(256), AttnCfg<DT>::LDS, s, p);
+    hipLaunchKernelGGL((attention_kernel<DT, ODT>), dim3(grid), dim3(256), AttnCfg<DT>::LDS, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_attention(int dt, const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0 || p.ldv % 64 != 0 || p.ldv < ((p.Nk + 63) / 64) * 64)
         return hipErrorInvalidValue;
+    if (p.out_dt >= 0 && p.out_dt != dt && !(dt == D3R_F16X3 && p.out_dt == D3R_F16F8)) return hipErrorInvalidValue;
     switch (dt) {
         case D3R_BF16: return launch_t<D3R_BF16>(p, s);
         case D3R_F16: return launch_t<D3R_F16>(p, s);
         case D3R_F32: return launch_t<D3R_F32>(p, s);
-        case D3R_F16X3: return launch_t<D3R_F16X3>(p, s);
+        case D3R_F16X3:
+            if (p.out_dt == D3R_F16F8) return launch_t<D3R_F16X3, D3R_F16F8>(p, s);   // q, k, v^T split-fp16; output rows for an fp16 + fp8 proj GEMM
+            return launch_t<D3R_F16X3>(p, s);
     }
     return hipErrorInvalidValue;
 }

@@ -8,6 +8,10 @@
 //                        fp32-class results at 1/3 of the 16-bit MFMA rate = 5.3x the exact-f32 MFMA rate.
 //                        Storage: a row of K logical elements is K*4 bytes made of 32-byte groups
 //                        [8 x hi fp16][8 x lo fp16], i.e. the same 16-byte-chunk geometry as every other mode.
+//   D3R_F16F8          : the same split, but only hi*hi runs on the f16 MFMA; the cross terms hi*lo + lo*hi run on
+//                        v_mfma_scale_f32_16x16x128_f8f6f4 with e4m3 copies of the four factors (twice the 16-bit rate,
+//                        both cross terms K-concatenated into one instruction): 2 MFMA units per product instead of 3,
+//                        ~15-16 significand bits per operand. Storage: see Traits<D3R_F16F8>.
 // The f32 instantiation is the "reference-exact" precision mode (the reference runs fp32,
 // dust3r/inference.py:44); it shares tiles, LDS images and epilogues with the 16-bit modes
 // because all of them move operands as 16-byte chunks (8 x 16-bit or 4 x f32) and the MFMA
@@ -20,11 +24,13 @@
 #define D3R_F16 1
 #define D3R_F32 2
 #define D3R_F16X3 3   // split fp16: every value is a (hi, lo) fp16 pair, products use 3 MFMAs (hi*hi + hi*lo + lo*hi)
+#define D3R_F16F8 4   // fp16 + fp8: hi*hi on the f16 MFMA, the two cross terms hi*lo + lo*hi on ONE K-concatenated fp8 (e4m3) MFMA at twice the rate
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
 #define D3R_DEV __device__ __forceinline__
 
@@ -127,6 +133,78 @@ template <> struct Traits<D3R_F16X3> {
     D3R_DEV static size_t boff(size_t e) { return (e >> 3) * 32 + (e & 7) * 2; }
 };
 
+// fp16 + fp8 operands. A row of K logical elements (K % 64 == 0) is K*4 bytes made of 256-byte super-groups of 64 elements:
+//     [hi fp16 x64 (128 B) | a8 e4m3 x64 (64 B) | b8 e4m3 x64 (64 B)]
+//   activations:  a8 = e4m3(hi),               b8 = e4m3(lo * 2^11)        (hi = fp16(x), lo = x - hi)
+//   weights:      a8 = e4m3(lo * 2^(11 + 6)),  b8 = e4m3(hi * 2^6)         (2^6: |w| of O(0.01) sits in e4m3's normal range)
+// so that, slot by slot, a8x*a8w + b8x*b8w = (hi_x*lo_w + lo_x*hi_w) * 2^17: one fp8 MFMA over the concatenated [a8 | b8] halves
+// yields both cross terms, and its E8M0 scale operand (2^-17) undoes the factor inside the instruction. A GEMM K step (128 bytes of
+// every row) is alternately the fp16 half of a super-group (two 16x16x32 f16 MFMAs per fragment pair) and its fp8 half (one
+// 16x16x128 fp8 MFMA): per 64 logical k 64 MFMA cycles instead of the 96 of three f16 MFMAs (measured 1.47x, tools/f8_probe.hip).
+// v_cvt_pk_fp8_f32 rounds to nearest even, keeps subnormals and returns NaN above 464: the sources are clamped to +-448 first.
+template <> struct Traits<D3R_F16F8> {
+    static constexpr int EB = 4;   // bytes per LOGICAL element
+    static constexpr int CH = 4;
+    static constexpr int SCALE_P = 0x6E6E6E6E;   // E8M0 2^(110 - 127) = 2^-17 in every byte (whichever op_sel)
+    static constexpr int SCALE_Q = 0x7F7F7F7F;   // 1.0
+    D3R_DEV static void mma16_hi(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+    }
+    // a0 / b0: the lane's 16 a8 bytes, a1 / b1: its 16 b8 bytes (same 16 logical k on both operands)
+    D3R_DEV static void mma16_f8(f32x4_t& acc, const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+        // register-tuple concatenation (a shufflevector of two 4-vectors: no moves; an element-wise initialiser list compiles to shuffles)
+        typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+        const i32x8_t A = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, a0), __builtin_bit_cast(i32x4_t, a1), 0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x8_t B = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, b0), __builtin_bit_cast(i32x4_t, b1), 0, 1, 2, 3, 4, 5, 6, 7);
+        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, acc, 0, 0, 0, SCALE_P, 0, SCALE_Q);
+    }
+    D3R_DEV static float clamp8(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+    // four consecutive values -> 4 x fp16 (hi), 4 x e4m3 (a), 4 x e4m3 (b); WGT: the weight encoding
+    template <bool WGT> D3R_DEV static void enc4(float v0, float v1, float v2, float v3, uint2& hi, uint32_t& a, uint32_t& b) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+        v0 = fminf(fmaxf(v0, -65504.f), 65504.f); v1 = fminf(fmaxf(v1, -65504.f), 65504.f);
+        v2 = fminf(fmaxf(v2, -65504.f), 65504.f); v3 = fminf(fmaxf(v3, -65504.f), 65504.f);
+        const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1, h2 = (_Float16)v2, h3 = (_Float16)v3;
+        const h2_t p01 = {h0, h1}, p23 = {h2, h3};
+        hi.x = __builtin_bit_cast(uint32_t, p01);
+        hi.y = __builtin_bit_cast(uint32_t, p23);
+        const float f0 = (float)h0, f1 = (float)h1, f2 = (float)h2, f3 = (float)h3;
+        constexpr float SH = WGT ? 64.f : 1.f, SL = WGT ? 131072.f : 2048.f;
+        const float q0 = clamp8(f0 * SH), q1 = clamp8(f1 * SH), q2 = clamp8(f2 * SH), q3 = clamp8(f3 * SH);
+        const float r0 = clamp8((v0 - f0) * SL), r1 = clamp8((v1 - f1) * SL), r2 = clamp8((v2 - f2) * SL), r3 = clamp8((v3 - f3) * SL);
+        int th = __builtin_amdgcn_cvt_pk_fp8_f32(q0, q1, 0, false);
+        th = __builtin_amdgcn_cvt_pk_fp8_f32(q2, q3, th, true);
+        int tl = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r1, 0, false);
+        tl = __builtin_amdgcn_cvt_pk_fp8_f32(r2, r3, tl, true);
+        a = (uint32_t)(WGT ? tl : th);
+        b = (uint32_t)(WGT ? th : tl);
+    }
+    // byte offsets of logical element e (rows start at multiples of 64 elements)
+    D3R_DEV static size_t off_hi(size_t e) { return (e >> 6) * 256 + (e & 63) * 2; }
+    D3R_DEV static size_t off_a(size_t e) { return (e >> 6) * 256 + 128 + (e & 63); }
+    D3R_DEV static size_t off_b(size_t e) { return (e >> 6) * 256 + 192 + (e & 63); }
+    // value of an ACTIVATION element: hi + lo8 * 2^-11 (15-16 bits; device code only reads this format back in tests / fallbacks)
+    D3R_DEV static float dec(uint16_t h, uint32_t bword, int byte) {
+        float l;
+        switch (byte) {
+            case 0: l = __builtin_amdgcn_cvt_f32_fp8((int)bword, 0); break;
+            case 1: l = __builtin_amdgcn_cvt_f32_fp8((int)bword, 1); break;
+            case 2: l = __builtin_amdgcn_cvt_f32_fp8((int)bword, 2); break;
+            default: l = __builtin_amdgcn_cvt_f32_fp8((int)bword, 3); break;
+        }
+        return (float)__builtin_bit_cast(_Float16, h) + l * (1.0f / 2048.f);
+    }
+    // one WEIGHT element (load-time packing: one thread per source element)
+    D3R_DEV static void store1_wgt(void* base, size_t e, float v) {
+        uint2 hi; uint32_t a, b;
+        enc4<true>(v, 0.f, 0.f, 0.f, hi, a, b);
+        char* p = reinterpret_cast<char*>(base);
+        *reinterpret_cast<uint16_t*>(p + off_hi(e)) = (uint16_t)(hi.x & 0xFFFFu);
+        *reinterpret_cast<uint8_t*>(p + off_a(e)) = (uint8_t)(a & 0xFFu);
+        *reinterpret_cast<uint8_t*>(p + off_b(e)) = (uint8_t)(b & 0xFFu);
+    }
+};
+
 // ---- typed 4-element (row-contiguous) loads / stores used by every epilogue -----------------
 template <int DT> D3R_DEV void store4(void* base, size_t elem_off, float a, float b, float c, float d) {
     if constexpr (DT == D3R_F32) {
@@ -139,6 +217,14 @@ template <int DT> D3R_DEV void store4(void* base, size_t elem_off, float a, floa
         char* p = reinterpret_cast<char*>(base) + TX::boff(elem_off);
         *reinterpret_cast<uint2*>(p) = h;
         *reinterpret_cast<uint2*>(p + 16) = l;
+    } else if constexpr (DT == D3R_F16F8) {   // activation encoding; elem_off % 4 == 0
+        using TF = Traits<D3R_F16F8>;
+        uint2 h; uint32_t a8, b8;
+        TF::enc4<false>(a, b, c, d, h, a8, b8);
+        char* p = reinterpret_cast<char*>(base);
+        *reinterpret_cast<uint2*>(p + TF::off_hi(elem_off)) = h;
+        *reinterpret_cast<uint32_t*>(p + TF::off_a(elem_off)) = a8;
+        *reinterpret_cast<uint32_t*>(p + TF::off_b(elem_off)) = b8;
     } else {
         uint2 v;
         v.x = Traits<DT>::pack2(a, b);
@@ -154,6 +240,13 @@ template <int DT> D3R_DEV float4 load4(const void* base, size_t elem_off) {
         const char* p = reinterpret_cast<const char*>(base) + TX::boff(elem_off);
         const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + 16);
         return make_float4(TX::join_lo(h.x, l.x), TX::join_hi(h.x, l.x), TX::join_lo(h.y, l.y), TX::join_hi(h.y, l.y));
+    } else if constexpr (DT == D3R_F16F8) {
+        using TF = Traits<D3R_F16F8>;
+        const char* p = reinterpret_cast<const char*>(base);
+        const uint2 h = *reinterpret_cast<const uint2*>(p + TF::off_hi(elem_off));
+        const uint32_t b8 = *reinterpret_cast<const uint32_t*>(p + TF::off_b(elem_off));
+        return make_float4(TF::dec((uint16_t)(h.x & 0xFFFFu), b8, 0), TF::dec((uint16_t)(h.x >> 16), b8, 1), TF::dec((uint16_t)(h.y & 0xFFFFu), b8, 2),
+                           TF::dec((uint16_t)(h.y >> 16), b8, 3));
     } else {
         uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem_off);
         return make_float4(Traits<DT>::unpack_lo(v.x), Traits<DT>::unpack_hi(v.x), Traits<DT>::unpack_lo(v.y),
@@ -205,6 +298,14 @@ template <int DT> D3R_DEV void store1(void* base, size_t elem_off, float a) {
         char* p = reinterpret_cast<char*>(base) + TX::boff(elem_off);
         *reinterpret_cast<uint16_t*>(p) = (uint16_t)(h & 0xFFFFu);
         *reinterpret_cast<uint16_t*>(p + 16) = (uint16_t)(l & 0xFFFFu);
+    } else if constexpr (DT == D3R_F16F8) {
+        using TF = Traits<D3R_F16F8>;
+        uint2 h; uint32_t a8, b8;
+        TF::enc4<false>(a, 0.f, 0.f, 0.f, h, a8, b8);
+        char* p = reinterpret_cast<char*>(base);
+        *reinterpret_cast<uint16_t*>(p + TF::off_hi(elem_off)) = (uint16_t)(h.x & 0xFFFFu);
+        *reinterpret_cast<uint8_t*>(p + TF::off_a(elem_off)) = (uint8_t)(a8 & 0xFFu);
+        *reinterpret_cast<uint8_t*>(p + TF::off_b(elem_off)) = (uint8_t)(b8 & 0xFFu);
     } else reinterpret_cast<uint16_t*>(base)[elem_off] = (uint16_t)(Traits<DT>::pack2(a, 0.f) & 0xFFFFu);
 }
 template <int DT> D3R_DEV float load1(const void* base, size_t elem_off) {
@@ -212,6 +313,10 @@ template <int DT> D3R_DEV float load1(const void* base, size_t elem_off) {
     else if constexpr (DT == D3R_F16X3) {
         const char* p = reinterpret_cast<const char*>(base) + Traits<D3R_F16X3>::boff(elem_off);
         return (float)*reinterpret_cast<const _Float16*>(p) + (float)*reinterpret_cast<const _Float16*>(p + 16);
+    } else if constexpr (DT == D3R_F16F8) {
+        using TF = Traits<D3R_F16F8>;
+        const char* p = reinterpret_cast<const char*>(base);
+        return TF::dec(*reinterpret_cast<const uint16_t*>(p + TF::off_hi(elem_off)), (uint32_t)*reinterpret_cast<const uint8_t*>(p + TF::off_b(elem_off)), 0);
     } else return Traits<DT>::unpack_lo((uint32_t)reinterpret_cast<const uint16_t*>(base)[elem_off]);
 }
 
@@ -227,6 +332,15 @@ D3R_DEV void glds16(const void* gsrc, uint32_t lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+// The same DMA with a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit unsigned byte offset: half the address registers
+// of glds16 (a 256 x 256 tile keeps 16 row addresses per lane alive through its K loop).
+D3R_DEV void glds16_so(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
 }
 D3R_DEV void d3r_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -259,4 +373,4 @@ D3R_DEV int xcd_remap(int bid, int nwg) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-static inline size_t dt_bytes(int dt) { return (dt == D3R_F32 || dt == D3R_F16X3) ? 4 : 2; }
+static inline size_t dt_bytes(int dt) { return (dt == D3R_F32 || dt == D3R_F16X3 || dt == D3R_F16F8) ? 4 : 2; }

@@ -66,6 +66,9 @@ hipError_t launch_layernorm(int dt, const float* x, const float* gamma, const fl
         case D3R_F16: hipLaunchKernelGGL(layernorm_kernel<D3R_F16>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
         case D3R_F32: hipLaunchKernelGGL(layernorm_kernel<D3R_F32>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
         case D3R_F16X3: hipLaunchKernelGGL(layernorm_kernel<D3R_F16X3>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
+        case D3R_F16F8:     // rows of 256-byte super-groups
+            if (C % 64 != 0) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(layernorm_kernel<D3R_F16F8>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -87,6 +90,9 @@ hipError_t launch_convert(int dt, const float* x, void* out, size_t n, hipStream
         case D3R_F16: hipLaunchKernelGGL(convert_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, x, out, n4); break;
         case D3R_F32: hipLaunchKernelGGL(convert_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, x, out, n4); break;
         case D3R_F16X3: hipLaunchKernelGGL(convert_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, x, out, n4); break;
+        case D3R_F16F8:
+            if (n % 64 != 0) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(convert_kernel<D3R_F16F8>, dim3(grid), dim3(256), 0, s, x, out, n4); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -405,7 +411,8 @@ template <int DT> __global__ __launch_bounds__(256) void pack_weight_kernel(Pack
         const int co = rem / kk, t = rem - co * kk;
         d = ((size_t)t * p.cout_pad + co) * (size_t)p.dst_cols + ci;
     }
-    store1<DT>(p.dst, d, v);
+    if constexpr (DT == D3R_F16F8) Traits<D3R_F16F8>::store1_wgt(p.dst, d, v);   // the weight encoding of the fp16 + fp8 rows
+    else store1<DT>(p.dst, d, v);
 }
 hipError_t launch_pack_weight(int dt, const PackParams& p, hipStream_t s) {
     if (p.numel == 0) return hipSuccess;
@@ -415,6 +422,9 @@ hipError_t launch_pack_weight(int dt, const PackParams& p, hipStream_t s) {
         case D3R_F16: hipLaunchKernelGGL(pack_weight_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, p); break;
         case D3R_F32: hipLaunchKernelGGL(pack_weight_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, p); break;
         case D3R_F16X3: hipLaunchKernelGGL(pack_weight_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, p); break;
+        case D3R_F16F8:     // nn.Linear matrices only (the convolutions of the DPT head stay split-fp16)
+            if (p.kind != PACK_MAT || p.dst_cols % 64 != 0) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(pack_weight_kernel<D3R_F16F8>, dim3(grid), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -36,11 +36,12 @@ struct Slot {
     int row_off = 0;          // first destination row (concatenated matrices / biases)
     int dst_cols = 0;         // destination row length (K, possibly padded)
     int cin = 0, cin_pad = 0, ksize = 1, cout_pad = 0;
+    int dt = -1;              // layout of a packed matrix (-1: the model's dtype; the transformer blocks' matrices may be fp16 + fp8 rows)
     bool loaded = false, explicit_loaded = false;
     std::string mirror;       // dec_blocks.* -> dec_blocks2.* duplication
 };
 
-struct Lin { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, n_pad = 0, n_rows = 0; };
+struct Lin { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, n_pad = 0, n_rows = 0, dt = 0; };   // dt: operand layout of this GEMM
 struct LNp { float* g = nullptr; float* b = nullptr; };
 struct EncBlk { LNp n1, n2; Lin qkv, proj, fc1, fc2; };
 struct DecBlk { LNp n1, n2, n3, ny; Lin qkv, proj, cq, ckv, cproj, fc1, fc2; };
@@ -63,6 +64,7 @@ struct DptHead {
 struct d3r_model {
     d3r_model_config cfg;
     int dt = 0, ktile = 64;
+    int bdt = 0;              // operand layout of the transformer blocks' linears (= dt, or D3R_F16F8 on top of dt = D3R_F16X3)
     std::unordered_map<std::string, Slot> slots;
     std::vector<void*> allocs;
     size_t weight_bytes = 0;
@@ -117,18 +119,19 @@ bool reg_vec_at(d3r_model* m, const std::string& key, float* base, int off, int 
     m->slots[key] = s;
     return true;
 }
-bool alloc_lin(d3r_model* m, Lin& L, int N, int K, bool bias = true) {
+bool alloc_lin(d3r_model* m, Lin& L, int N, int K, bool bias = true, int dt = -1) {
     L.N = N; L.K = K; L.n_pad = rup(N, 128); L.n_rows = rup(N, 256);   // rows up to a 256-wide tile stay zero
-    L.w = m->dalloc((size_t)L.n_rows * K * dt_bytes(m->dt));
+    L.dt = dt < 0 ? m->dt : dt;
+    L.w = m->dalloc((size_t)L.n_rows * K * dt_bytes(L.dt));
     L.b = bias ? (float*)m->dalloc((size_t)L.n_rows * sizeof(float)) : nullptr;
     return L.w && (!bias || L.b);
 }
 void reg_mat(d3r_model* m, const std::string& key, const Lin& L, int rows, int row_off) {
-    Slot s; s.kind = PK_MAT; s.dst = L.w; s.rows = rows; s.cols = L.K; s.row_off = row_off; s.dst_cols = L.K;
+    Slot s; s.kind = PK_MAT; s.dst = L.w; s.rows = rows; s.cols = L.K; s.row_off = row_off; s.dst_cols = L.K; s.dt = L.dt;
     m->slots[key] = s;
 }
-bool reg_linear(d3r_model* m, const std::string& prefix, Lin& L, int N, int K) {
-    if (!alloc_lin(m, L, N, K)) return false;
+bool reg_linear(d3r_model* m, const std::string& prefix, Lin& L, int N, int K, int dt = -1) {
+    if (!alloc_lin(m, L, N, K, true, dt)) return false;
     reg_mat(m, prefix + ".weight", L, N, 0);
     reg_vec_at(m, prefix + ".bias", L.b, 0, N);
     return true;
@@ -150,7 +153,7 @@ bool reg_conv(d3r_model* m, const std::string& prefix, ConvW& c, int Cout, int C
     return true;
 }
 bool reg_convt(d3r_model* m, const std::string& prefix, Lin& L, int Cin, int Cout, int k, int cin_pad, int cout_pad) {
-    L.N = k * k * cout_pad; L.K = cin_pad; L.n_pad = rup(L.N, 128); L.n_rows = rup(L.N, 256);
+    L.N = k * k * cout_pad; L.K = cin_pad; L.n_pad = rup(L.N, 128); L.n_rows = rup(L.N, 256); L.dt = m->dt;
     L.w = m->dalloc((size_t)L.n_rows * L.K * dt_bytes(m->dt));
     L.b = (float*)m->dalloc((size_t)L.n_rows * sizeof(float));
     if (!L.w || !L.b) return false;
@@ -165,15 +168,16 @@ void reg_ignore(d3r_model* m, const std::string& key) { Slot s; s.kind = PK_IGNO
 bool build_slots(d3r_model* m) {
     const d3r_model_config& c = m->cfg;
     const int Ce = c.enc_embed_dim, Cd = c.dec_embed_dim, ps = c.patch_size;
+    const int bd = m->bdt;    // the 24 + 2 x 12 transformer blocks' matrices; patch embedding, decoder_embed and the heads keep m->dt
     if (!reg_linear(m, "patch_embed.proj", m->patch, Ce, 3 * ps * ps)) return false;
     reg_ignore(m, "mask_token");
     m->enc.resize(c.enc_depth);
     for (int l = 0; l < c.enc_depth; ++l) {
         const std::string p = "enc_blocks." + std::to_string(l);
         EncBlk& b = m->enc[l];
-        if (!reg_ln(m, p + ".norm1", b.n1, Ce) || !reg_ln(m, p + ".norm2", b.n2, Ce) || !reg_linear(m, p + ".attn.qkv", b.qkv, 3 * Ce, Ce) ||
-            !reg_linear(m, p + ".attn.proj", b.proj, Ce, Ce) || !reg_linear(m, p + ".mlp.fc1", b.fc1, 4 * Ce, Ce) ||
-            !reg_linear(m, p + ".mlp.fc2", b.fc2, Ce, 4 * Ce))
+        if (!reg_ln(m, p + ".norm1", b.n1, Ce) || !reg_ln(m, p + ".norm2", b.n2, Ce) || !reg_linear(m, p + ".attn.qkv", b.qkv, 3 * Ce, Ce, bd) ||
+            !reg_linear(m, p + ".attn.proj", b.proj, Ce, Ce, bd) || !reg_linear(m, p + ".mlp.fc1", b.fc1, 4 * Ce, Ce, bd) ||
+            !reg_linear(m, p + ".mlp.fc2", b.fc2, Ce, 4 * Ce, bd))
             return false;
     }
     if (!reg_ln(m, "enc_norm", m->enc_norm, Ce) || !reg_ln(m, "dec_norm", m->dec_norm, Cd) || !reg_linear(m, "decoder_embed", m->dec_embed, Cd, Ce))
@@ -184,13 +188,13 @@ bool build_slots(d3r_model* m) {
             const std::string p = std::string(side ? "dec_blocks2." : "dec_blocks.") + std::to_string(l);
             DecBlk& b = m->dec[side][l];
             if (!reg_ln(m, p + ".norm1", b.n1, Cd) || !reg_ln(m, p + ".norm2", b.n2, Cd) || !reg_ln(m, p + ".norm3", b.n3, Cd) ||
-                !reg_ln(m, p + ".norm_y", b.ny, Cd) || !reg_linear(m, p + ".attn.qkv", b.qkv, 3 * Cd, Cd) ||
-                !reg_linear(m, p + ".attn.proj", b.proj, Cd, Cd) || !reg_linear(m, p + ".cross_attn.projq", b.cq, Cd, Cd) ||
-                !reg_linear(m, p + ".cross_attn.proj", b.cproj, Cd, Cd) || !reg_linear(m, p + ".mlp.fc1", b.fc1, 4 * Cd, Cd) ||
-                !reg_linear(m, p + ".mlp.fc2", b.fc2, Cd, 4 * Cd))
+                !reg_ln(m, p + ".norm_y", b.ny, Cd) || !reg_linear(m, p + ".attn.qkv", b.qkv, 3 * Cd, Cd, bd) ||
+                !reg_linear(m, p + ".attn.proj", b.proj, Cd, Cd, bd) || !reg_linear(m, p + ".cross_attn.projq", b.cq, Cd, Cd, bd) ||
+                !reg_linear(m, p + ".cross_attn.proj", b.cproj, Cd, Cd, bd) || !reg_linear(m, p + ".mlp.fc1", b.fc1, 4 * Cd, Cd, bd) ||
+                !reg_linear(m, p + ".mlp.fc2", b.fc2, Cd, 4 * Cd, bd))
                 return false;
             // projk and projv share their input: packed as one (2 Cd, Cd) matrix
-            if (!alloc_lin(m, b.ckv, 2 * Cd, Cd)) return false;
+            if (!alloc_lin(m, b.ckv, 2 * Cd, Cd, true, bd)) return false;
             reg_mat(m, p + ".cross_attn.projk.weight", b.ckv, Cd, 0);
             reg_mat(m, p + ".cross_attn.projv.weight", b.ckv, Cd, Cd);
             reg_vec_at(m, p + ".cross_attn.projk.bias", b.ckv.b, 0, Cd);
@@ -273,7 +277,7 @@ int pack_slot(d3r_model* m, Slot& s, const float* data, int ndim, const int64_t*
             return launch_pack_convt_bias(data, (float*)s.dst, s.rows, s.cout_pad, s.ksize * s.ksize, nullptr) == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
     }
     (void)eb;
-    return launch_pack_weight(m->dt, pp, nullptr) == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
+    return launch_pack_weight(s.dt < 0 ? m->dt : s.dt, pp, nullptr) == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------------------
@@ -305,8 +309,8 @@ void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi,
     p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_rows = L.n_rows;
     p.n_store = n_store >= 0 ? n_store : L.N;
     p.epi = epi; p.out = out; p.ldo = ldo; p.res1 = res1; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo2; p.flags = flags;
-    c.mark(PRF_GEMM + gemm_pick_config(p, c.m->dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
-    c.chk(launch_gemm(c.m->dt, p, c.st));
+    c.mark(PRF_GEMM + gemm_pick_config(p, L.dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
+    c.chk(launch_gemm(L.dt, p, c.st));
 }
 
 void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_c, int nreg, const int* kinds, void* const* dsts, int heads,
@@ -316,8 +320,8 @@ void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_
     p.epi = EPI_HEADS; p.head_c = head_c;
     for (int i = 0; i < nreg; ++i) { p.head_kind[i] = kinds[i]; p.head_dst[i] = dsts[i]; }
     p.heads = heads; p.ntok = ntok; p.tok_w = tok_w; p.ldv = ldv; p.rope_table = c.m->rope_table;
-    c.mark(PRF_GEMM + gemm_pick_config(p, c.m->dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
-    c.chk(launch_gemm(c.m->dt, p, c.st));
+    c.mark(PRF_GEMM + gemm_pick_config(p, L.dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
+    c.chk(launch_gemm(L.dt, p, c.st));
 }
 
 void conv(Ctx& c, const void* in, int B, int Hin, int Win, int cstride, const ConvW& w, int stride, int pad, void* out, int ldo,
@@ -361,11 +365,14 @@ extern "C" int d3r_device_check(void) {
 
 extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     if (!out || !cfg) return D3R_ERR_INVALID;
-    if (cfg->dtype < 0 || cfg->dtype > 3 || cfg->patch_size % 4 != 0) return D3R_ERR_INVALID;
+    if (cfg->dtype < 0 || cfg->dtype > 4 || cfg->patch_size % 4 != 0) return D3R_ERR_INVALID;
     if (cfg->enc_embed_dim != cfg->enc_num_heads * 64 || cfg->dec_embed_dim != cfg->dec_num_heads * 64) return D3R_ERR_INVALID;  // head dim 64
     d3r_model* m = new (std::nothrow) d3r_model();
     if (!m) return D3R_ERR_ALLOC;
-    m->cfg = *cfg; m->dt = cfg->dtype; m->ktile = 128 / (int)dt_bytes(cfg->dtype);
+    // D3R_DTYPE_F16F8: the transformer blocks' linears on fp16 + fp8 operand rows, everything else (patch embedding, decoder_embed,
+    // attention operands, DPT / linear heads) in split-fp16
+    m->cfg = *cfg; m->dt = cfg->dtype == D3R_F16F8 ? D3R_F16X3 : cfg->dtype; m->bdt = cfg->dtype == D3R_F16F8 ? D3R_F16F8 : m->dt;
+    m->ktile = 128 / (int)dt_bytes(m->dt);
     if (cfg->enc_embed_dim % m->ktile || cfg->dec_embed_dim % m->ktile || (3 * cfg->patch_size * cfg->patch_size) % m->ktile ||
         (cfg->head_type == 1 && (cfg->dec_depth <= 9 || cfg->patch_size != 16))) { delete m; return D3R_ERR_INVALID; }   // run_dpt assumes 16 x th == H
     if (!build_slots(m)) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
@@ -508,6 +515,7 @@ void self_attention(Ctx& c, const void* xn, const Lin& qkv, int M, int C, int he
     gemm_heads(c, xn, C, qkv, M, C, 3, kinds, dsts, heads, ntok, tok_w, ldv);
     AttnParams a;
     a.q = q; a.k = k; a.vt = vt; a.out = ao; a.B = nimg; a.H = heads; a.Nq = ntok; a.Nk = ntok; a.ldv = ldv; a.scale = 0.125f;
+    a.out_dt = c.m->bdt;      // rows for the proj GEMM
     c.mark(PRF_ATTN, 4.0 * nimg * heads * (double)ntok * ntok * 64, nimg * heads, ntok, ntok);
     c.chk(launch_attention(c.m->dt, a, c.st));
 }
@@ -700,10 +708,10 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                 gemm_linear(c, hb, (int)pk, m->patch, Mp, EPI_F32, xp, Ce);
                 for (int l = 0; l < cf.enc_depth; ++l) {
                     const EncBlk& b = m->enc[l];
-                    D3R_OTHER(launch_layernorm(m->dt, xp, b.n1.g, b.n1.b, xn, Mp, Ce, 1e-6f, st));
+                    D3R_OTHER(launch_layernorm(m->bdt, xp, b.n1.g, b.n1.b, xn, Mp, Ce, 1e-6f, st));
                     self_attention(c, xn, b.qkv, Mp, Ce, He, n_img, dd.N, dd.tw, dd.ldv, q, k, vt, ao);
                     gemm_linear(c, ao, Ce, b.proj, Mp, EPI_F32, xp, Ce, xp);
-                    D3R_OTHER(launch_layernorm(m->dt, xp, b.n2.g, b.n2.b, xn, Mp, Ce, 1e-6f, st));
+                    D3R_OTHER(launch_layernorm(m->bdt, xp, b.n2.g, b.n2.b, xn, Mp, Ce, 1e-6f, st));
                     gemm_linear(c, xn, Ce, b.fc1, Mp, EPI_GELU, hb, 4 * Ce);
                     gemm_linear(c, hb, 4 * Ce, b.fc2, Mp, EPI_F32, xp, Ce, xp);
                 }
@@ -737,12 +745,12 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                 const float* xo = f[cur] + (size_t)Roff[s] * Cd;         // own stream (old)
                 const float* yo = f[cur] + (size_t)Roff[1 - s] * Cd;     // other view (old)
                 float* xw = f[cur ^ 1] + (size_t)Roff[s] * Cd;           // own stream (new)
-                D3R_OTHER(launch_layernorm(m->dt, xo, b.n1.g, b.n1.b, sxn, Ms[s], Cd, 1e-6f, c.st));
+                D3R_OTHER(launch_layernorm(m->bdt, xo, b.n1.g, b.n1.b, sxn, Ms[s], Cd, 1e-6f, c.st));
                 self_attention(c, sxn, b.qkv, Ms[s], Cd, Hd, B, own.N, own.tw, own.ldv, sq, sk, svt, sao);
                 gemm_linear(c, sao, Cd, b.proj, Ms[s], EPI_F32, xw, Cd, xo);
                 // cross attention: q from norm2(x), k/v from norm_y(y): Nk = the other view's token count
-                D3R_OTHER(launch_layernorm(m->dt, yo, b.ny.g, b.ny.b, syn, Ms[1 - s], Cd, 1e-6f, c.st));
-                D3R_OTHER(launch_layernorm(m->dt, xw, b.n2.g, b.n2.b, sxn, Ms[s], Cd, 1e-6f, c.st));
+                D3R_OTHER(launch_layernorm(m->bdt, yo, b.ny.g, b.ny.b, syn, Ms[1 - s], Cd, 1e-6f, c.st));
+                D3R_OTHER(launch_layernorm(m->bdt, xw, b.n2.g, b.n2.b, sxn, Ms[s], Cd, 1e-6f, c.st));
                 {
                     const int kq[1] = {HEAD_ROPE};
                     void* dq[1] = {sq};
@@ -752,11 +760,12 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                     gemm_heads(c, syn, Cd, b.ckv, Ms[1 - s], Cd, 2, kkv, dkv, Hd, oth.N, oth.tw, oth.ldv);
                     AttnParams a;
                     a.q = sq; a.k = sk; a.vt = svt; a.out = sao; a.B = B; a.H = Hd; a.Nq = own.N; a.Nk = oth.N; a.ldv = oth.ldv; a.scale = 0.125f;
+                    a.out_dt = m->bdt;
                     c.mark(PRF_ATTN, 4.0 * B * Hd * (double)own.N * oth.N * 64, B * Hd, own.N, oth.N);
                     c.chk(launch_attention(m->dt, a, c.st));
                 }
                 gemm_linear(c, sao, Cd, b.cproj, Ms[s], EPI_F32, xw, Cd, xw);
-                D3R_OTHER(launch_layernorm(m->dt, xw, b.n3.g, b.n3.b, sxn, Ms[s], Cd, 1e-6f, c.st));
+                D3R_OTHER(launch_layernorm(m->bdt, xw, b.n3.g, b.n3.b, sxn, Ms[s], Cd, 1e-6f, c.st));
                 gemm_linear(c, sxn, Cd, b.fc1, Ms[s], EPI_GELU, shb, 4 * Cd);
                 const int layer_no = l + 1;
                 void* hcopy = (cf.head_type == 1 && (layer_no == hk6 || layer_no == hk9)) ? hook[s][layer_no == hk6 ? 0 : 1] : nullptr;

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
 #pragma unroll
                     for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], pf, pl, qf[fj], ql[fj]);
                 }
-            } else {
+            } else if constexpr (DT != D3R_F16F8) {
 #pragma unroll
                 for (int ks = 0; ks < KTB / 64; ++ks) {
                     const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
@@ -490,6 +490,80 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!trailing) __builtin_amdgcn_s_barrier();
+    } else if constexpr (DT == D3R_F16F8) {
+        // ---- fp16 + fp8 rows: the K loop walks 256-byte super-groups [hi fp16 x64 | a8 x64 | b8 x64] (64 logical k) in two K steps --------
+        // Step 2t stages the fp16 half into stage 0: two f16 MFMA k-steps, lane group g on chunks g and 4 + g. Step 2t + 1 stages the fp8
+        // half into stage 1: lane group g reads chunk g (a8 of its 16 logical k) and chunk 4 + g (b8 of the same k) and ONE 16x16x128
+        // fp8 MFMA adds both cross terms (its E8M0 scale undoes the 2^17 of the encodings). nk is even (K % 64 == 0).
+        static_assert(KTB == 128 && NS == 2, "fp16 + fp8 rows: 128-byte K steps, two stages");
+        // nn.Linear operands only. The rows a lane stages are PASS_ROWS apart: ONE 32-bit byte offset per operand in a VGPR, the row
+        // stride added to the wave-uniform 64-bit base in SGPRs (launch_gemm checks the operands are < 4 GiB). With one 64-bit address
+        // per staged row (16 per lane) this loop spilled, and a scratch reload's vmcnt wait also drains the DMA in flight: load and
+        // math serialised. Only a tile that hangs over the last row (rows clamped to M - 1) computes its offsets per piece.
+        const bool edge = __builtin_amdgcn_readfirstlane(m0 + BM > p.M ? 1 : 0) != 0;   // wave-uniform, and told so (a scalar branch, not an exec mask)
+        const uint32_t a0 = (uint32_t)(((size_t)min(m0 + lrow, p.M - 1) * p.lda) * EB + lchunk * 16);
+        const uint32_t w0 = (uint32_t)(((size_t)(n0 + lrow) * p.K) * EB + lchunk * 16);
+        const size_t stride_a = (size_t)CF::PASS_ROWS * p.lda * EB, stride_w = (size_t)CF::PASS_ROWS * p.K * EB;
+        auto stage8 = [&](int kt, int buf) __attribute__((always_inline)) {
+            const uint32_t sb = lds0 + buf * STAGE_BYTES;
+            const char* ab = reinterpret_cast<const char*>(p.act) + (size_t)kt * KTB;
+            const char* wb = reinterpret_cast<const char*>(p.wgt) + (size_t)kt * KTB;
+            if (!edge) {
+#pragma unroll
+                for (int q = 0; q < CF::APASS; ++q) glds16_so(ab + q * stride_a, a0, sb + q * (CF::NW * 1024));
+            } else {
+#pragma unroll
+                for (int q = 0; q < CF::APASS; ++q) {
+                    const int m = min(m0 + q * CF::PASS_ROWS + lrow, p.M - 1);
+                    glds16_so(ab, (uint32_t)(((size_t)m * p.lda) * EB + lchunk * 16), sb + q * (CF::NW * 1024));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CF::WPASS; ++q) glds16_so(wb + q * stride_w, w0, sb + BM * KTB + q * (CF::NW * 1024));
+        };
+        stage8(0, 0);
+        for (int kt = 0; kt < nk; kt += 2) {
+            d3r_wait_vm0();
+            __syncthreads();
+            stage8(kt + 1, 1);
+            {
+                const char* sb = smem;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
+                    uint4 qf[FJ];
+#pragma unroll
+                    for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (q_row0 + f * 16) * KTB + coff);
+#pragma unroll
+                    for (int fi = 0; fi < FI; ++fi) {
+                        const uint4 pf = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + fi * 16) * KTB + coff);
+#pragma unroll
+                        for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], pf, qf[fj]);
+                    }
+                }
+            }
+            d3r_wait_vm0();
+            __syncthreads();
+            if (kt + 2 < nk) stage8(kt + 2, 0);
+            {
+                const char* sb = smem + STAGE_BYTES;
+                const int ca = (fgrp ^ fsw) * 16, cb = ((4 + fgrp) ^ fsw) * 16;
+                uint4 qa[FJ], qb[FJ];
+#pragma unroll
+                for (int f = 0; f < FJ; ++f) {
+                    const char* qr = sb + q_off + (q_row0 + f * 16) * KTB;
+                    qa[f] = *reinterpret_cast<const uint4*>(qr + ca);
+                    qb[f] = *reinterpret_cast<const uint4*>(qr + cb);
+                }
+#pragma unroll
+                for (int fi = 0; fi < FI; ++fi) {
+                    const char* pr = sb + p_off + (p_row0 + fi * 16) * KTB;
+                    const uint4 pa = *reinterpret_cast<const uint4*>(pr + ca), pb = *reinterpret_cast<const uint4*>(pr + cb);
+#pragma unroll
+                    for (int fj = 0; fj < FJ; ++fj) TR::mma16_f8(acc[fi][fj], pa, pb, qa[fj], qb[fj]);
+                }
+            }
+        }
     } else {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -525,7 +599,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], pf, pl, qf[fj], ql[fj]);
             }
-        } else {
+        } else if constexpr (DT != D3R_F16F8) {
 #pragma unroll
             for (int ks = 0; ks < KTB / 64; ++ks) {
                 const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
@@ -584,10 +658,16 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     // split-fp16 outputs: the same [64 rows j][32 columns i] staging tile as the fp32 epilogue (a 32-column piece of an x3 row
     // is 128 bytes: 4 groups [hi x8][lo x8]), written in the final byte layout so that the read phase stores whole lines
     constexpr bool DTX3 = (DT == D3R_F16X3);
-    const bool widex3 = DTX3 && !(p.flags & GF_NOWIDE) &&
-                        (((p.epi == EPI_GELU || (p.epi == EPI_T && !p.res1 && !p.res2 && !p.out2)) && (p.ldo & 7) == 0) ||
+    // fp16 + fp8 GEMMs: the attention projections hand q / k / v^T to the attention kernel in the split-fp16 layout (HDT), the typed
+    // copy of an fp32-residual launch (out2: the DPT hooks) is split-fp16 too (O2DT); GELU / plain outputs are fp16 + fp8 activation rows
+    constexpr bool DTF8 = (DT == D3R_F16F8);
+    constexpr int HDT = DTF8 ? D3R_F16X3 : DT, O2DT = DTF8 ? D3R_F16X3 : DT;
+    const bool widex3 = (DTX3 || DTF8) && !(p.flags & GF_NOWIDE) &&
+                        ((DTX3 && (p.epi == EPI_GELU || (p.epi == EPI_T && !p.res1 && !p.res2 && !p.out2)) && (p.ldo & 7) == 0) ||
                          (p.epi == EPI_HEADS && (p.ntok & 31) == 0 && (p.ldv & 7) == 0));
-    if (wide16 || wide32 || widex3) {
+    const bool widef8 = DTF8 && !(p.flags & GF_NOWIDE) && (p.epi == EPI_GELU || (p.epi == EPI_T && !p.res1 && !p.res2 && !p.out2)) &&
+                        (p.ldo & 63) == 0 && (p.n_store & 63) == 0;
+    if (wide16 || wide32 || widex3 || widef8) {
         __syncthreads();   // every wave is done with the K loop's LDS stages
         char* wreg = smem + wave * (64 * WROW);
         // P side (i, 4 consecutive per lane) base / Q side (j) base in global coordinates
@@ -717,7 +797,60 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                 return;
             }
         }
-        if constexpr (DTX3) {
+        if constexpr (DTF8) {
+            if (widef8) {
+                // fp16 + fp8 activation rows: a wave's 64-column group of a row is one 256-byte super-group [hi x64 | a8 x64 | b8 x64].
+                // Staged 32 rows at a time ([32][256 + 16] bytes per wave), read back 16 lanes per row: whole 256-byte lines to HBM.
+                using TF = Traits<D3R_F16F8>;
+                constexpr int RW = 272;
+                char* freg = smem + wave * (32 * RW);
+                const float* bsrc = p.bias ? p.bias : reinterpret_cast<const float*>(p.wgt);
+                const bool has_bias = p.bias != nullptr;
+                const int r16 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+                for (int g = 0; g < FI / 4; ++g) {
+                    const int ig = ib + g * 64;                 // first column n of this 64-wide group (64-aligned)
+                    float4 bq[4];
+#pragma unroll
+                    for (int fl = 0; fl < 4; ++fl) {
+                        const float4 t = *reinterpret_cast<const float4*>(bsrc + max(min(ig + fl * 16 + i4, p.n_store - 4), 0));
+                        bq[fl] = make_float4(has_bias ? t.x : 0.f, has_bias ? t.y : 0.f, has_bias ? t.z : 0.f, has_bias ? t.w : 0.f);
+                    }
+#pragma unroll
+                    for (int half = 0; half < FJ / 2; ++half) {
+#pragma unroll
+                        for (int fjj = 0; fjj < 2; ++fjj) {
+                            const int fj = half * 2 + fjj;
+                            char* w = freg + (fjj * 16 + jl) * RW;
+#pragma unroll
+                            for (int fl = 0; fl < 4; ++fl) {
+                                const f32x4_t a = acc[g * 4 + fl][fj];
+                                float v0 = a[0] + bq[fl].x, v1 = a[1] + bq[fl].y, v2 = a[2] + bq[fl].z, v3 = a[3] + bq[fl].w;
+                                if (p.epi == EPI_GELU) { v0 = gelu<DT>(v0); v1 = gelu<DT>(v1); v2 = gelu<DT>(v2); v3 = gelu<DT>(v3); }
+                                if (p.flags & GF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                                uint2 hh; uint32_t a8, b8;
+                                TF::enc4<false>(v0, v1, v2, v3, hh, a8, b8);
+                                const int c0 = fl * 16 + i4;       // 4 consecutive logical columns of the group
+                                *reinterpret_cast<uint2*>(w + c0 * 2) = hh;
+                                *reinterpret_cast<uint32_t*>(w + 128 + c0) = a8;
+                                *reinterpret_cast<uint32_t*>(w + 192 + c0) = b8;
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int pass = 0; pass < 8; ++pass) {
+                            const int row = pass * 4 + r16;
+                            const uint4 v = *reinterpret_cast<const uint4*>(freg + row * RW + c16 * 16);
+                            const int j = jb + half * 32 + row;
+                            if (j < p.M && ig < p.n_store) store16(reinterpret_cast<char*>(p.out) + ((size_t)j * p.ldo + ig) * 4 + c16 * 16, v, nt);
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                }
+                return;
+            }
+        }
+        if constexpr (DTX3 || DTF8) {
             if (widex3) {
                 using TX = Traits<D3R_F16X3>;
                 const bool bias_i = !swap && p.bias != nullptr, bias_j = swap && p.bias != nullptr;
@@ -866,7 +999,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                     v.z += has_res ? rv.z : 0.f; v.w += has_res ? rv.w : 0.f;
                     if (m < p.M && n < p.n_store) {
                         store16(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), nt);
-                        if (p.out2) store4<DT>(p.out2, (size_t)m * p.ldo2 + n, v.x, v.y, v.z, v.w);
+                        if (p.out2) store4<O2DT>(p.out2, (size_t)m * p.ldo2 + n, v.x, v.y, v.z, v.w);
                     }
                 }
                 asm volatile("" ::: "memory");
@@ -916,8 +1049,8 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                                 vv[r] = bq * cc[r] + a * ss[r];
                             }
                         }
-                        store4<DT>(dst, obase + half * 32 + i4, uu[0], uu[1], uu[2], uu[3]);
-                        store4<DT>(dst, obase + half * 32 + 16 + i4, vv[0], vv[1], vv[2], vv[3]);
+                        store4<HDT>(dst, obase + half * 32 + i4, uu[0], uu[1], uu[2], uu[3]);
+                        store4<HDT>(dst, obase + half * 32 + 16 + i4, vv[0], vv[1], vv[2], vv[3]);
                     }
                 }
             }
@@ -934,6 +1067,25 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                 if (m >= p.M) continue;
                 const f32x4_t a = acc[fi][fj];
                 float v0 = a[0] + bias.x, v1 = a[1] + bias.y, v2 = a[2] + bias.z, v3 = a[3] + bias.w;
+                if constexpr (DTF8) {
+                    // fp16 + fp8 launches come with EPI_F32 (+ residual, + split-fp16 typed copy) or GELU / plain activation rows only
+                    // (launch_gemm checks); a lean body keeps these fully unrolled loops under the unroller's size cap -- past it the
+                    // loops stay rolled, acc is indexed dynamically and the whole accumulator array moves to scratch
+                    if (p.epi == EPI_F32) {
+                        float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+                        if (p.res1) {
+                            const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res1) + (size_t)m * p.ldr + n);
+                            v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+                        }
+                        *reinterpret_cast<float4*>(o) = make_float4(v0, v1, v2, v3);
+                        if (p.out2) store4<O2DT>(p.out2, (size_t)m * p.ldo2 + n, v0, v1, v2, v3);
+                    } else {
+                        if (p.epi == EPI_GELU) { v0 = gelu<DT>(v0); v1 = gelu<DT>(v1); v2 = gelu<DT>(v2); v3 = gelu<DT>(v3); }
+                        if (p.flags & GF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        store4<DT>(p.out, (size_t)m * p.ldo + n, v0, v1, v2, v3);
+                    }
+                    continue;
+                }
                 switch (p.epi) {
                     case EPI_F32: {
                         float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
@@ -942,7 +1094,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                             v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
                         }
                         *reinterpret_cast<float4*>(o) = make_float4(v0, v1, v2, v3);
-                        if (p.out2) store4<DT>(p.out2, (size_t)m * p.ldo2 + n, v0, v1, v2, v3);
+                        if (p.out2) store4<O2DT>(p.out2, (size_t)m * p.ldo2 + n, v0, v1, v2, v3);
                     } break;
                     case EPI_GELU:
                         store4<DT>(p.out, (size_t)m * p.ldo + n, gelu<DT>(v0), gelu<DT>(v1), gelu<DT>(v2), gelu<DT>(v3));
@@ -992,14 +1144,14 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                 const int b = m / p.ntok, t = m - b * p.ntok;
                 const size_t rowbase = ((size_t)(b * p.heads + h) * 64 + dd) * p.ldv;
                 if (t + 3 < p.ntok && ((p.ldv | t) & 3) == 0) {
-                    store4<DT>(dst, rowbase + t, a[0] + bias, a[1] + bias, a[2] + bias, a[3] + bias);
+                    store4<HDT>(dst, rowbase + t, a[0] + bias, a[1] + bias, a[2] + bias, a[3] + bias);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int mm = m + r;
                         if (mm >= p.M) break;
                         const int bb = mm / p.ntok, tt = mm - bb * p.ntok;
-                        store1<DT>(dst, ((size_t)(bb * p.heads + h) * 64 + dd) * p.ldv + tt, a[r] + bias);
+                        store1<HDT>(dst, ((size_t)(bb * p.heads + h) * 64 + dd) * p.ldv + tt, a[r] + bias);
                     }
                 }
             }
@@ -1096,16 +1248,17 @@ int gemm_pick_config(const GemmParams& p, int dt) {
 
 template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     int cfg = gemm_pick_config(p, DT);
-    if (cfg == GEMM_CFG_256x128W4 && DT == D3R_F16X3) cfg = GEMM_CFG_256x128;   // split-fp16 rows need 128-byte K rows
-    if ((cfg == GEMM_CFG_256S4 || cfg == GEMM_CFG_256PP) && DT == D3R_F16X3) cfg = GEMM_CFG_256;
+    constexpr bool SPLIT = (DT == D3R_F16X3 || DT == D3R_F16F8);   // split-fp16 and fp16 + fp8 rows need 128-byte K rows, two stages
+    if (cfg == GEMM_CFG_256x128W4 && SPLIT) cfg = GEMM_CFG_256x128;
+    if ((cfg == GEMM_CFG_256S4 || cfg == GEMM_CFG_256PP) && SPLIT) cfg = GEMM_CFG_256;
     // the ping-pong schedule has no operand-role swap: attention projections only through the wide V^T route
     if (cfg == GEMM_CFG_256PP && p.epi == EPI_HEADS && !((DT == D3R_BF16 || DT == D3R_F16) && (p.ntok & 63) == 0 && !(p.flags & GF_NOWIDE))) cfg = GEMM_CFG_256;
-    if constexpr (DT != D3R_F16X3) {
+    if constexpr (!SPLIT) {
         if (cfg == GEMM_CFG_256x128W4) return launch_cfg<DT, Cfg256x128w4>(p, s);
         if (cfg == GEMM_CFG_256S4) return launch_cfg<DT, Cfg256s4>(p, s);
         if (cfg == GEMM_CFG_256PP) return launch_cfg<DT, Cfg256pp>(p, s);
     }
-    {
+    if constexpr (DT != D3R_F16F8) {
         const char* e_a3 = getenv("D3R_GEMM_A3");
         const bool a3 = e_a3 ? e_a3[0] != '0' : false;
         if (a3 && cfg == GEMM_CFG_256) return launch_cfg<DT, Cfg256a3>(p, s);
@@ -1154,12 +1307,22 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     if (p.amode == AMODE_CONV && (p.Cin % kt != 0 || p.zero_page == nullptr)) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV) p.kslice_major = conv_k_slice_major() ? 1 : 0;
     if (p.epi == EPI_HEADS && p.head_c % 128 != 0 && p.head_c < (1 << 29)) return hipErrorInvalidValue;
+    // fp16 + fp8 rows: nn.Linear operands only, whole 64-element super-groups; outputs: fp32 (+ residual), GELU / plain activation rows, heads
+    if (dt == D3R_F16F8 && ((size_t)p.M * p.lda * 4 >= (1ull << 32) || (size_t)(p.n_rows > 0 ? p.n_rows : p.n_pad) * p.K * 4 >= (1ull << 32))) return hipErrorInvalidValue;
+    if (dt == D3R_F16F8 && (p.amode != AMODE_LINEAR || p.K % 64 != 0 || p.lda % 64 != 0 || p.epi == EPI_CONVT || p.res2 ||
+                            (p.epi == EPI_T && (p.res1 || p.out2)) || ((p.epi == EPI_T || p.epi == EPI_GELU) && (p.ldo % 64 != 0 || p.n_store % 4 != 0))))
+        return hipErrorInvalidValue;
+#ifdef D3R_GEMM_ONLY_DT      // development builds (-DD3R_GEMM_ONLY_DT=4): one precision mode only, a tenth of the compile time
+    if (dt == D3R_GEMM_ONLY_DT) return launch_t<D3R_GEMM_ONLY_DT>(p, s);
+#else
     switch (dt) {
         case D3R_BF16: return launch_t<D3R_BF16>(p, s);
         case D3R_F16: return launch_t<D3R_F16>(p, s);
         case D3R_F32: return launch_t<D3R_F32>(p, s);
         case D3R_F16X3: return launch_t<D3R_F16X3>(p, s);
+        case D3R_F16F8: return launch_t<D3R_F16F8>(p, s);
     }
+#endif
     return hipErrorInvalidValue;
 }
 

@@ -58,6 +58,7 @@ struct AttnParams {
     void* out = nullptr;       // [B][Nq][H*64]
     int B = 0, H = 0, Nq = 0, Nk = 0, ldv = 0;
     float scale = 0.125f;
+    int out_dt = -1;           // layout of `out` when it differs from the operands' (D3R_F16F8 rows out of a split-fp16 attention); -1: same
 };
 hipError_t launch_attention(int dt, const AttnParams& p, hipStream_t s);
 

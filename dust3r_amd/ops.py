@@ -87,6 +87,74 @@ def linear_x3(act, weight, bias=None, epilogue='store', residual=None):
     return out if epi == 1 else unpack_x3(out)
 
 
+def _e4m3(x):
+    """Round to OCP e4m3 (the encoding v_cvt_pk_fp8_f32 produces on gfx950: nearest even, subnormals kept), saturating at +-448
+    as the kernels clamp before converting. Returns the bytes (uint8)."""
+    return x.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def pack_f8(x, weight=False):
+    """fp32 (..., K), K % 64 == 0 -> the fp16 + fp8 row layout as uint8 (..., 4K): per 64 logical elements a 256-byte super-group
+    [hi fp16 x64 | a8 e4m3 x64 | b8 e4m3 x64]; activations a8 = e4m3(hi), b8 = e4m3(lo 2^11); weights a8 = e4m3(lo 2^17),
+    b8 = e4m3(hi 2^6)  (hi = fp16(x), lo = x - hi; csrc/common.hpp, Traits<D3R_F16F8>)."""
+    x = x.float().clamp(-65504.0, 65504.0)
+    sh = x.shape
+    assert sh[-1] % 64 == 0
+    hi = x.half()
+    lo = x - hi.float()
+    h8 = _e4m3(hi.float() * (64.0 if weight else 1.0))
+    l8 = _e4m3(lo * (131072.0 if weight else 2048.0))
+    a8, b8 = (l8, h8) if weight else (h8, l8)
+    g = lambda t: t.reshape(*sh[:-1], sh[-1] // 64, -1)
+    out = torch.cat((g(hi.view(torch.uint8)), g(a8), g(b8)), dim=-1)
+    return out.reshape(*sh[:-1], sh[-1] * 4).contiguous()
+
+
+def unpack_f8(t, weight=False, parts=False):
+    """Inverse of pack_f8 (uint8 (..., 4K) -> fp32 (..., K)): the value an element stands for, hi + lo8 2^-11 (activations) or
+    hi + lo8 2^-17 (weights). parts=True returns (hi fp32, a8 bytes, b8 bytes)."""
+    sh = t.shape
+    g = t.reshape(*sh[:-1], sh[-1] // 256, 256)
+    hi = g[..., :128].contiguous().view(torch.float16).float().reshape(*sh[:-1], sh[-1] // 4)
+    a8 = g[..., 128:192].reshape(*sh[:-1], sh[-1] // 4)
+    b8 = g[..., 192:].reshape(*sh[:-1], sh[-1] // 4)
+    if parts:
+        return hi, a8, b8
+    lo8 = (a8 if weight else b8).contiguous().view(torch.float8_e4m3fn).float()
+    return hi + lo8 / (131072.0 if weight else 2048.0)
+
+
+def linear_f8(act, weight, bias=None, epilogue='store', residual=None):
+    """`linear` in the fp16 + fp8 mode: act (M,K), weight (N,K) fp32 (K % 64 == 0; N % 64 == 0 for 'store' / 'gelu') are packed to the
+    activation / weight row layouts; 'f32' returns the fp32 result, the others the decoded activation rows."""
+    _lib.require_device()
+    M, K = act.shape
+    N = weight.shape[0]
+    ap, wp = pack_f8(act), pad_rows(pack_f8(weight, weight=True))
+    bp = None if bias is None else pad_rows(bias.float())
+    epi = {'store': 0, 'f32': 1, 'gelu': 2}[epilogue]
+    out = torch.empty((M, N), dtype=torch.float32, device=act.device) if epi == 1 else torch.empty((M, 4 * N), dtype=torch.uint8, device=act.device)
+    check(lib.d3r_linear(ptr(ap), ptr(wp), ptr(bp), ptr(out), ptr(residual), M, N, K, epi, _lib.DTYPE_F16F8, current_stream()), 'linear(f16f8)')
+    return out if epi == 1 else unpack_f8(out)
+
+
+def emulate_f8(act, weight):
+    """What the fp16 + fp8 contraction computes, in fp64 on the caller's device: hi.hi + (e4m3(hi_x) e4m3(lo_w 2^17) + e4m3(lo_x 2^11) e4m3(hi_w 2^6)) 2^-17."""
+    xh, xa, xb = unpack_f8(pack_f8(act), parts=True)
+    wh, wa, wb = unpack_f8(pack_f8(weight, weight=True), parts=True)
+    f8 = lambda t: t.contiguous().view(torch.float8_e4m3fn).double()
+    return xh.double() @ wh.double().T + (f8(xa) @ f8(wa).T + f8(xb) @ f8(wb).T) / 131072.0
+
+
+def layernorm_f8(x, gamma, beta, eps=1e-6):
+    """LayerNorm into fp16 + fp8 activation rows (uint8 (rows, 4C))."""
+    _lib.require_device()
+    rows, Cc = x.shape
+    out = torch.empty((rows, 4 * Cc), dtype=torch.uint8, device=x.device)
+    check(lib.d3r_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out), rows, Cc, eps, _lib.DTYPE_F16F8, current_stream()), 'layernorm(f16f8)')
+    return out
+
+
 def pack_conv_weight(w, dtype=None):
     """torch (Cout, Cin, kh, kw) -> (round_up(Cout,256), kh*kw*Cin) in the K order d3r_conv2d_nhwc expects (include/dust3r_hip.h):
     channel slices of one K step (128 bytes) outermost, then the taps, then the channels of the slice -- or (ky, kx, cin) when the

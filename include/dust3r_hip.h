@@ -37,7 +37,14 @@ extern "C" {
 #define D3R_DTYPE_F16 1  /* v_mfma_*_f16: same rate, 3 more mantissa bits */
 #define D3R_DTYPE_F32 2  /* v_mfma_f32_*_f32: exact fp32 like the reference (dust3r/inference.py:44), 1/16 rate */
 #define D3R_DTYPE_F16X3 3 /* split fp16 (hi + lo pairs, 3 f16 MFMAs per product): fp32-class accuracy at 1/3 of the 16-bit rate.
-                           * Model engine only: the building-block entry points take D3R_DTYPE_BF16 / F16 / F32 tensors. */
+                           * Rows: 32-byte groups [hi fp16 x8][lo fp16 x8] (4 bytes per logical element). */
+#define D3R_DTYPE_F16F8 4 /* fp16 + fp8: hi.hi on the f16 MFMA, the cross terms hi.lo + lo.hi on ONE K-concatenated e4m3 MFMA
+                           * (v_mfma_scale_f32_16x16x128_f8f6f4, twice the 16-bit rate): 2 MFMA units per product instead of 3.
+                           * Model engine: the transformer blocks' nn.Linear layers run in this layout, everything else in D3R_DTYPE_F16X3.
+                           * Rows (K % 64 == 0): 256-byte super-groups [hi fp16 x64 | a8 e4m3 x64 | b8 e4m3 x64];
+                           * activations a8 = e4m3(hi), b8 = e4m3(lo 2^11); weights a8 = e4m3(lo 2^17), b8 = e4m3(hi 2^6).
+                           * d3r_layernorm writes activation rows; d3r_linear takes activation rows x weight rows (epilogue 0 / 2 write
+                           * activation rows, N % 64 == 0; epilogue 1 fp32). */
 
 const char* d3r_version(void);
 /* 0 when a gfx950 device is visible to the HIP runtime, else an error code (used to fail loudly) */

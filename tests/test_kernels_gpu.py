@@ -80,6 +80,57 @@ def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize('cfg', ['0', '1', '2', '3'])
+@pytest.mark.parametrize('M,N,K', [(300, 192, 256), (1000, 3072, 1024), (77, 128, 768), (2100, 1024, 64), (515, 320, 128)])
+def test_linear_fp16_fp8(gpu, M, N, K, cfg, monkeypatch):
+    """The fp16 + fp8 operand mode at kernel level (hi.hi on the f16 MFMA, both cross terms on one K-concatenated e4m3 MFMA with an E8M0
+    scale of 2^-17): every tile configuration, wide and direct epilogues. The comparator is the SAME arithmetic in fp64 on the host-packed
+    operands (ops.emulate_f8): the kernel must reproduce it to fp32 accumulation noise, i.e. the row layouts, the k-slot pairing of the
+    two operands and the scale are all pinned; the distance to the exact product is checked too (an fp16-only product is ~30x worse).
+    Activation-row outputs ('store' / 'gelu') are compared after decoding (hi + lo8 2^-11: one output rounding of 2^-15)."""
+    from dust3r_amd import ops
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg)
+    g = torch.Generator(device='cpu').manual_seed(M * 7 + N)
+    a = torch.randn((M, K), generator=g).to(gpu)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(gpu)
+    b = torch.randn(N, generator=g).to(gpu)
+    res = torch.randn((M, N), generator=g).to(gpu)
+    emu = (ops.emulate_f8(a, w) + b.double()).float()
+    exact = (a.double() @ w.double().T + b.double()).float()
+    assert relerr(emu, exact) < 4e-5          # the scheme itself: ~15-16 bits per operand
+    got = {}
+    for wide in ('0', '1'):
+        monkeypatch.setenv('D3R_GEMM_NOWIDE', wide)
+        o_res = ops.linear_f8(a, w, b, 'f32', residual=res)
+        assert relerr(o_res, emu + res) < 3e-6, 'fp32 + residual epilogue'
+        assert relerr(ops.linear_f8(a, w, None, 'f32'), emu - b) < 3e-6, 'no bias'
+        if N % 64 == 0:
+            o_store, o_gelu = ops.linear_f8(a, w, b, 'store'), ops.linear_f8(a, w, b, 'gelu')
+            assert relerr(o_store, emu) < 4e-5, 'activation-row store'
+            assert relerr(o_gelu, F.gelu(emu)) < 4e-5, 'gelu epilogue'
+            got[wide] = (o_res, o_store, o_gelu)
+        else:
+            got[wide] = (o_res,)
+    for x, y in zip(got['0'], got['1']):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('rows,C', [(7, 128), (1000, 768), (513, 1024)])
+def test_layernorm_fp16_fp8_rows(gpu, rows, C):
+    """LayerNorm into fp16 + fp8 activation rows: hi is the fp16 rounding of the fp32 LayerNorm, a8 = e4m3(hi) exactly, and
+    b8 = e4m3((x - hi) 2^11) up to a half-step of its own rounding (the kernel's fp32 LayerNorm may differ from torch's by an ulp)."""
+    from dust3r_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(rows + C)
+    x = (torch.randn((rows, C), generator=g) * 3 + 0.5).to(gpu)
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(gpu), (0.1 * torch.randn(C, generator=g)).to(gpu)
+    out = ops.layernorm_f8(x, gamma, beta, eps=1e-6)
+    ref = F.layer_norm(x, (C,), gamma, beta, eps=1e-6)
+    hi, a8, b8 = ops.unpack_f8(out, parts=True)
+    assert relerr(hi, ref) < 8e-4
+    assert torch.equal(a8, ops._e4m3(hi))
+    assert relerr(ops.unpack_f8(out), ref) < 4e-5
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,H,W,Cin,Cout,k,stride,pad', [(2, 12, 16, 128, 256, 3, 1, 1), (1, 24, 32, 256, 128, 3, 2, 1), (3, 6, 8, 256, 96, 1, 1, 0),
                                                        (1, 7, 5, 64, 128, 3, 1, 1), (2, 21, 32, 128, 128, 3, 2, 1)])

@@ -1,0 +1,155 @@
+"""Build-container experiment (not product, not a test): can the two CROSS terms of the split-fp16 product run on the fp8 MFMA path?
+
+The default engine mode (fp16x3) evaluates x.w as  xh.wh + xh.wl + xl.wh  with three f16 MFMAs per product (h = fp16(v), l = fp16(v - h)).
+gfx950's f8f6f4 MFMAs run at twice the 16-bit rate, so  xh.wh (f16)  +  q8(xh).q8(wl) + q8(xl).q8(wh)  (one K-concatenated fp8 MFMA)
+would cost 2 units instead of 3.  This script measures what that does to the pointmaps: full 512x384 forward on the oracle (unmodified
+reference model files + oracle/shims, seeded random weights, CPU, fp32 accumulation), every nn.Linear / convolution of the chosen groups
+evaluated by the emulated scheme, per-pixel relative pointmap error against the all-fp32 run.  Attention products stay exact here (the
+engine keeps them in fp16x3).
+
+q8 = OCP e4m3 (torch.float8_e4m3fn), with an MX-style shared power-of-two scale per 32 consecutive K elements ('mx') or per tensor row
+('row') or none ('raw': lo parts pre-scaled by 2^11 only).
+
+Usage: python tools/precision_fp8cross.py [H W [npairs]]
+"""
+import sys
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, '.')
+from oracle.ref_import import import_reference  # noqa
+import_reference()
+from dust3r.model import AsymmetricCroCo3DStereo  # noqa
+
+SCHEME = {}      # group -> scheme name
+F8 = torch.float8_e4m3fn
+
+
+def q8(t, kdim, how):
+    """e4m3 rounding of t with a shared power-of-two scale per block along kdim."""
+    if how == 'raw':
+        return t.clamp(-448, 448).to(F8).float()
+    tt = t.movedim(kdim, -1)
+    shp = tt.shape
+    K = shp[-1]
+    blk = 32 if how == 'mx' else K
+    pad = (-K) % blk
+    if pad:
+        tt = F.pad(tt, (0, pad))
+    b = tt.reshape(*tt.shape[:-1], -1, blk)
+    amax = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    scale = torch.exp2(torch.floor(torch.log2(amax)) - 8)          # block max lands in [256, 512): e4m3 saturates at 448
+    q = (b / scale).clamp(-448, 448).to(F8).float() * scale
+    q = q.reshape(*tt.shape)[..., :K].reshape(shp)
+    return q.movedim(-1, kdim)
+
+
+def split(v):
+    h = v.half().float()
+    return h, (v - h).half().float()
+
+
+def contract(op, x, w, kx, kw, scheme):
+    """op(x, w) is bilinear.  kx / kw: the contraction dimension of x / w (for the block scales)."""
+    if scheme is None:
+        return op(x, w)
+    if scheme == 'fp16':
+        return op(x.half().float(), w.half().float())
+    xh, xl = split(x)
+    wh, wl = split(w)
+    if scheme == 'x3':
+        return op(xh, wh) + op(xh, wl) + op(xl, wh)
+    if scheme == 'x2w':          # two f16 MFMAs: weights carried exactly, activations fp16
+        return op(xh, wh) + op(xh, wl)
+    kind, how = scheme.split(':')
+    S = 2048.0
+    if kind == 'f8x':            # 2 units: f16 hi.hi + fp8 (xh.wl + xl.wh)
+        return op(xh, wh) + (op(q8(xh, kx, how), q8(wl * S, kw, how)) + op(q8(xl * S, kx, how), q8(wh, kw, how))) / S
+    if kind == 'f8a':            # 2.5 units: f16 hi.hi + f16 xh.wl + fp8 xl.wh
+        return op(xh, wh) + op(xh, wl) + op(q8(xl * S, kx, how), q8(wh, kw, how)) / S
+    if kind == 'f8w':            # 2.5 units: f16 hi.hi + f16 xl.wh + fp8 xh.wl
+        return op(xh, wh) + op(xl, wh) + op(q8(xh, kx, how), q8(wl * S, kw, how)) / S
+    if kind == 'f8xx':           # 2.5 units: the cross factors carried as TWO fp8 pieces (8 bits), lo parts as one
+        xh8 = q8(xh, kx, how); xh8b = q8(xh - xh8, kx, how)
+        wh8 = q8(wh, kw, how); wh8b = q8(wh - wh8, kw, how)
+        xl8, wl8 = q8(xl * S, kx, how), q8(wl * S, kw, how)
+        return op(xh, wh) + (op(xh8, wl8) + op(xh8b, wl8) + op(xl8, wh8) + op(xl8, wh8b)) / S
+    raise ValueError(scheme)
+
+
+def lin_fwd(self, x):
+    y = contract(lambda a, b: F.linear(a, b), x, self.weight, -1, -1, SCHEME.get(self._pgroup))
+    return y + self.bias if self.bias is not None else y
+
+
+def conv_fwd(self, x):
+    y = contract(lambda a, b: F.conv2d(a, b, None, self.stride, self.padding), x, self.weight, 1, 1, SCHEME.get(self._pgroup))
+    return y + self.bias.view(1, -1, 1, 1) if self.bias is not None else y
+
+
+def convt_fwd(self, x):
+    y = contract(lambda a, b: F.conv_transpose2d(a, b, None, self.stride, self.padding), x, self.weight, 1, 0, SCHEME.get(self._pgroup))
+    return y + self.bias.view(1, -1, 1, 1) if self.bias is not None else y
+
+
+nn.Linear.forward = lin_fwd
+nn.Conv2d.forward = conv_fwd
+nn.ConvTranspose2d.forward = convt_fwd
+
+inf = float('inf')
+H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (384, 512)
+NP = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+torch.manual_seed(0)
+m = AsymmetricCroCo3DStereo(pos_embed='RoPE100', img_size=(512, 512), head_type='dpt', output_mode='pts3d',
+                            depth_mode=('exp', -inf, inf), conf_mode=('exp', 1, inf), enc_embed_dim=1024, enc_depth=24,
+                            enc_num_heads=16, dec_embed_dim=768, dec_depth=12, dec_num_heads=12,
+                            landscape_only=False).eval()
+for hd in (m.downstream_head1, m.downstream_head2):      # |xyz| of O(1), as oracle/dust3r_ref.py does
+    hd.dpt.head[4].weight.data *= 40
+
+
+def group_of(name):
+    if name.startswith(('patch_embed', 'enc_blocks')):
+        return 'enc'
+    if name.startswith(('decoder_embed', 'dec_blocks')):
+        return 'dec'
+    if 'downstream_head' in name:
+        return 'head'
+    return None
+
+
+for name, mod in m.named_modules():
+    if isinstance(mod, (nn.Linear, nn.Conv2d, nn.ConvTranspose2d)):
+        mod._pgroup = group_of(name)
+torch.manual_seed(1)
+v1 = dict(img=torch.rand(NP, 3, H, W) * 2 - 1, true_shape=torch.tensor([[H, W]] * NP), idx=list(range(NP)), instance=['0'] * NP)
+v2 = dict(img=torch.rand(NP, 3, H, W) * 2 - 1, true_shape=torch.tensor([[H, W]] * NP), idx=list(range(NP)), instance=['1'] * NP)
+
+
+def run(active):
+    SCHEME.clear()
+    SCHEME.update(active)
+    with torch.no_grad():
+        r1, r2 = m(v1, v2)
+    return torch.cat((r1['pts3d'], r2['pts3d_in_other_view']))
+
+
+ref = run({})
+print(f'|pts| mean {ref.norm(dim=-1).mean():.3f} min {ref.norm(dim=-1).min():.3e}   ({NP} pair(s) {H}x{W})')
+ALL = ['enc', 'dec', 'head']
+cases = [('fp16 operands everywhere (1 unit)', {g: 'fp16' for g in ALL}),
+         ('fp16x3 everywhere (3 units, the default mode)', {g: 'x3' for g in ALL}),
+         ('hi.hi + xh.wl everywhere (2 units, f16 only)', {g: 'x2w' for g in ALL})]
+for how in ('mx', 'row', 'raw'):
+    cases += [(f'f8x:{how} everywhere (2 units)', {g: f'f8x:{how}' for g in ALL})]
+cases += [('f8x:mx encoder only', {'enc': 'f8x:mx', 'dec': 'x3', 'head': 'x3'}),
+          ('f8x:mx decoder only', {'enc': 'x3', 'dec': 'f8x:mx', 'head': 'x3'}),
+          ('f8x:mx head only', {'enc': 'x3', 'dec': 'x3', 'head': 'f8x:mx'}),
+          ('f8a:mx everywhere (2.5 units: only xl.wh on fp8)', {g: 'f8a:mx' for g in ALL}),
+          ('f8w:mx everywhere (2.5 units: only xh.wl on fp8)', {g: 'f8w:mx' for g in ALL}),
+          ('f8xx:mx everywhere (two-piece cross factors)', {g: 'f8xx:mx' for g in ALL})]
+print(f'{"scheme":52s} {"max":>9s} {"p99":>9s} {"mean":>9s}')
+for label, active in cases:
+    e = ((run(active) - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-12)).flatten()
+    print(f'{label:52s} {e.max():9.2e} {e.quantile(0.99):9.2e} {e.mean():9.2e}', flush=True)
