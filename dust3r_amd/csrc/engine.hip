@@ -300,7 +300,7 @@ struct Ctx {
     }
 };
 // profile record kinds: GEMM-kernel launches carry their tile configuration: kind = cfg (0..7) + 8 for implicit-GEMM convolution
-enum { PRF_GEMM = 0, PRF_CONV = 8, PRF_ATTN = 16, PRF_OTHER = 17, PRF_END = 18 };
+enum { PRF_GEMM = 0, PRF_CONV = 8, PRF_ATTN = 16, PRF_OTHER = 17, PRF_END = 18, PRF_GEMM_F8 = 24 };   // 24..31: fp16 + fp8 linear launches by tile configuration
 #define D3R_OTHER(call) do { c.mark(PRF_OTHER, 0.0); c.chk(call); } while (0)
 
 void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi, void* out, int ldo, const void* res1 = nullptr,
@@ -309,7 +309,7 @@ void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi,
     p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_rows = L.n_rows;
     p.n_store = n_store >= 0 ? n_store : L.N;
     p.epi = epi; p.out = out; p.ldo = ldo; p.res1 = res1; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo2; p.flags = flags;
-    c.mark(PRF_GEMM + gemm_pick_config(p, L.dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
+    c.mark((L.dt == D3R_F16F8 ? PRF_GEMM_F8 : PRF_GEMM) + gemm_pick_config(p, L.dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(L.dt, p, c.st));
 }
 
@@ -320,7 +320,7 @@ void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_
     p.epi = EPI_HEADS; p.head_c = head_c;
     for (int i = 0; i < nreg; ++i) { p.head_kind[i] = kinds[i]; p.head_dst[i] = dsts[i]; }
     p.heads = heads; p.ntok = ntok; p.tok_w = tok_w; p.ldv = ldv; p.rope_table = c.m->rope_table;
-    c.mark(PRF_GEMM + gemm_pick_config(p, L.dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
+    c.mark((L.dt == D3R_F16F8 ? PRF_GEMM_F8 : PRF_GEMM) + gemm_pick_config(p, L.dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(L.dt, p, c.st));
 }
 
@@ -473,7 +473,7 @@ extern "C" int d3r_model_set_option(d3r_model* m, int option, int value) {
 
 // Per-class totals of the LAST forward run with profiling on (kinds: include/dust3r_hip.h). Synchronises on the recorded events.
 extern "C" int d3r_model_profile_read(d3r_model* m, int kind, int* launches, double* ms, double* work) {
-    if (!m || kind < 0 || kind > 17 || m->prof_rec.size() < 2) return D3R_ERR_STATE;
+    if (!m || kind < 0 || kind > 31 || m->prof_rec.size() < 2) return D3R_ERR_STATE;
     int n = 0; double t = 0.0, w = 0.0;
     if (hipEventSynchronize(m->prof_ev[m->prof_rec.size() - 1]) != hipSuccess) return D3R_ERR_LAUNCH;
     for (size_t i = 0; i + 1 < m->prof_rec.size(); ++i) {

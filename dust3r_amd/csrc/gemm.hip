@@ -65,6 +65,11 @@ typedef GemmCfg<2, 4, 8, 4, 2, 128, 2, 2> Cfg256sw;
 typedef GemmCfg<2, 4, 4, 4, 2, 128, 2, 2> Cfg256x128sw;
 typedef GemmCfg<2, 2, 4, 4, 2, 128, 2, 2> Cfg128sw;
 typedef GemmCfg<1, 8, 8, 4, 2, 128, 2, 2> Cfg512x128sw;
+// fp16 + fp8 rows, DMA pieces interleaved with the MFMA rows (PP = 4; see the K loop)
+typedef GemmCfg<2, 4, 8, 4, 2, 128, 2, 4> Cfg256il;
+typedef GemmCfg<2, 4, 4, 4, 2, 128, 2, 4> Cfg256x128il;
+typedef GemmCfg<2, 2, 4, 4, 2, 128, 2, 4> Cfg128il;
+typedef GemmCfg<1, 8, 8, 4, 2, 128, 2, 4> Cfg512x128il;
 typedef GemmCfg<2, 4, 8, 4, 2, 128, 2, 3> Cfg256a3;     // 256 x 256, asymmetric ring (A x 3, W x 2), 160 KiB LDS
 // (256 x 256 by FOUR waves of 128 x 128 -- 256 accumulator registers per lane, one wave per SIMD, a third less LDS read traffic per
 // MFMA -- compiles to 256 VGPR + 256 AGPR with the accumulator array in scratch: 90-105 TF/s algorithmic against 390-480, round 2.
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         }
         if (kt < nk) kstep(kt, ha, hb);
         d3r_wait_vm0();   // nothing of this block's DMA is in flight when the epilogue reuses the stages
-    } else if constexpr (CF::PP) {
+    } else if constexpr (CF::PP == 1) {
         // ---- ping-pong schedule (non-swapped 16-bit / fp32 operands; KTB = 64: one MFMA k-step per K step) -----------------
         // A K step is two phases, each [L: issue half of the DMA of step kt+2, ds_read this phase's fragments] | s_barrier |
         // [C: 16 MFMAs] | s_barrier. Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in C while its
@@ -504,28 +509,39 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         const uint32_t a0 = (uint32_t)(((size_t)min(m0 + lrow, p.M - 1) * p.lda) * EB + lchunk * 16);
         const uint32_t w0 = (uint32_t)(((size_t)(n0 + lrow) * p.K) * EB + lchunk * 16);
         const size_t stride_a = (size_t)CF::PASS_ROWS * p.lda * EB, stride_w = (size_t)CF::PASS_ROWS * p.K * EB;
-        auto stage8 = [&](int kt, int buf) __attribute__((always_inline)) {
+        // one of the LPS DMA pieces of K step kt (activation rows first, then weight rows); idx is a compile-time constant after unrolling
+        auto piece8 = [&](int idx, int kt, int buf) __attribute__((always_inline)) {
             const uint32_t sb = lds0 + buf * STAGE_BYTES;
-            const char* ab = reinterpret_cast<const char*>(p.act) + (size_t)kt * KTB;
-            const char* wb = reinterpret_cast<const char*>(p.wgt) + (size_t)kt * KTB;
-            if (!edge) {
-#pragma unroll
-                for (int q = 0; q < CF::APASS; ++q) glds16_so(ab + q * stride_a, a0, sb + q * (CF::NW * 1024));
-            } else {
-#pragma unroll
-                for (int q = 0; q < CF::APASS; ++q) {
+            if (idx < CF::APASS) {
+                const int q = idx;
+                const char* ab = reinterpret_cast<const char*>(p.act) + (size_t)kt * KTB;
+                if (!edge) {
+                    glds16_so(ab + q * stride_a, a0, sb + q * (CF::NW * 1024));
+                } else {
                     const int m = min(m0 + q * CF::PASS_ROWS + lrow, p.M - 1);
                     glds16_so(ab, (uint32_t)(((size_t)m * p.lda) * EB + lchunk * 16), sb + q * (CF::NW * 1024));
                 }
+            } else {
+                const int q = idx - CF::APASS;
+                const char* wb = reinterpret_cast<const char*>(p.wgt) + (size_t)kt * KTB;
+                glds16_so(wb + q * stride_w, w0, sb + BM * KTB + q * (CF::NW * 1024));
             }
-#pragma unroll
-            for (int q = 0; q < CF::WPASS; ++q) glds16_so(wb + q * stride_w, w0, sb + BM * KTB + q * (CF::NW * 1024));
         };
+        auto stage8 = [&](int kt, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < LPS; ++i) piece8(i, kt, buf);
+        };
+        // IL (PP == 4): the DMA of the next K step is not issued in one burst behind the barrier -- where neither wave of a SIMD has an
+        // MFMA to issue yet -- but a few pieces at a time behind the MFMAs of the first fragment rows of the step (fragment reads one row
+        // ahead of their use, rows pinned with sched_barrier), so that the matrix pipe always has work from one of the two waves.
+        constexpr bool IL = CF::PP == 4;
+        constexpr int PPR_HI = (LPS + FI - 1) / FI;               // pieces per fragment row, fp16 step: over the FI rows of its first k-step
+        constexpr int PPR_F8 = (LPS + FI / 2 - 1) / (FI / 2);     // fp8 step: over the first half of its rows
         stage8(0, 0);
         for (int kt = 0; kt < nk; kt += 2) {
             d3r_wait_vm0();
             __syncthreads();
-            stage8(kt + 1, 1);
+            if (!IL) stage8(kt + 1, 1);
             {
                 const char* sb = smem;
 #pragma unroll
@@ -534,17 +550,35 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                     uint4 qf[FJ];
 #pragma unroll
                     for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (q_row0 + f * 16) * KTB + coff);
+                    if constexpr (!IL) {
 #pragma unroll
-                    for (int fi = 0; fi < FI; ++fi) {
-                        const uint4 pf = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + fi * 16) * KTB + coff);
+                        for (int fi = 0; fi < FI; ++fi) {
+                            const uint4 pf = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + fi * 16) * KTB + coff);
 #pragma unroll
-                        for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], pf, qf[fj]);
+                            for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], pf, qf[fj]);
+                        }
+                    } else {
+                        uint4 cur = *reinterpret_cast<const uint4*>(sb + p_off + p_row0 * KTB + coff);
+#pragma unroll
+                        for (int fi = 0; fi < FI; ++fi) {
+                            uint4 nxt = cur;
+                            if (fi + 1 < FI) nxt = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + (fi + 1) * 16) * KTB + coff);
+#pragma unroll
+                            for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], cur, qf[fj]);
+                            if (ks == 0) {
+#pragma unroll
+                                for (int i = fi * PPR_HI; i < (fi + 1) * PPR_HI && i < LPS; ++i) piece8(i, kt + 1, 1);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            cur = nxt;
+                        }
                     }
                 }
             }
             d3r_wait_vm0();
             __syncthreads();
-            if (kt + 2 < nk) stage8(kt + 2, 0);
+            const bool more = kt + 2 < nk;
+            if (!IL && more) stage8(kt + 2, 0);
             {
                 const char* sb = smem + STAGE_BYTES;
                 const int ca = (fgrp ^ fsw) * 16, cb = ((4 + fgrp) ^ fsw) * 16;
@@ -555,12 +589,34 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                     qa[f] = *reinterpret_cast<const uint4*>(qr + ca);
                     qb[f] = *reinterpret_cast<const uint4*>(qr + cb);
                 }
+                if constexpr (!IL) {
 #pragma unroll
-                for (int fi = 0; fi < FI; ++fi) {
-                    const char* pr = sb + p_off + (p_row0 + fi * 16) * KTB;
-                    const uint4 pa = *reinterpret_cast<const uint4*>(pr + ca), pb = *reinterpret_cast<const uint4*>(pr + cb);
+                    for (int fi = 0; fi < FI; ++fi) {
+                        const char* pr = sb + p_off + (p_row0 + fi * 16) * KTB;
+                        const uint4 pa = *reinterpret_cast<const uint4*>(pr + ca), pb = *reinterpret_cast<const uint4*>(pr + cb);
 #pragma unroll
-                    for (int fj = 0; fj < FJ; ++fj) TR::mma16_f8(acc[fi][fj], pa, pb, qa[fj], qb[fj]);
+                        for (int fj = 0; fj < FJ; ++fj) TR::mma16_f8(acc[fi][fj], pa, pb, qa[fj], qb[fj]);
+                    }
+                } else {
+                    const char* pr0 = sb + p_off + p_row0 * KTB;
+                    uint4 ca0 = *reinterpret_cast<const uint4*>(pr0 + ca), cb0 = *reinterpret_cast<const uint4*>(pr0 + cb);
+#pragma unroll
+                    for (int fi = 0; fi < FI; ++fi) {
+                        uint4 na = ca0, nb = cb0;
+                        if (fi + 1 < FI) {
+                            const char* pr = sb + p_off + (p_row0 + (fi + 1) * 16) * KTB;
+                            na = *reinterpret_cast<const uint4*>(pr + ca);
+                            nb = *reinterpret_cast<const uint4*>(pr + cb);
+                        }
+#pragma unroll
+                        for (int fj = 0; fj < FJ; ++fj) TR::mma16_f8(acc[fi][fj], ca0, cb0, qa[fj], qb[fj]);
+                        if (more && fi < FI / 2) {
+#pragma unroll
+                            for (int i = fi * PPR_F8; i < (fi + 1) * PPR_F8 && i < LPS; ++i) piece8(i, kt + 2, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        ca0 = na; cb0 = nb;
+                    }
                 }
             }
         }
@@ -1275,6 +1331,20 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
                 case GEMM_CFG_256x128: return launch_cfg<DT, Cfg256x128sw>(p, s);
                 case GEMM_CFG_512x128: return launch_cfg<DT, Cfg512x128sw>(p, s);
                 default: return launch_cfg<DT, Cfg128sw>(p, s);
+            }
+        }
+    }
+    if constexpr (DT == D3R_F16F8) {
+        // DMA pieces interleaved with the MFMA rows (PP = 4). Measured on MI355X (profiles/r02_f8/bench_f8_il.log): +3 % on the 256-wide
+        // tiles (one block per CU: behind the barrier neither wave of a SIMD has MFMAs to issue), -2.5 % on the 128 x 128 tile (the
+        // CU's second block already fills that gap). D3R_GEMM_F8IL=0 / 1 forces the burst / interleaved loop everywhere.
+        static const int il = [] { const char* e = getenv("D3R_GEMM_F8IL"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+        if (il == 1 || (il < 0 && cfg != GEMM_CFG_128)) {
+            switch (cfg) {
+                case GEMM_CFG_256: return launch_cfg<DT, Cfg256il>(p, s);
+                case GEMM_CFG_256x128: return launch_cfg<DT, Cfg256x128il>(p, s);
+                case GEMM_CFG_512x128: return launch_cfg<DT, Cfg512x128il>(p, s);
+                default: return launch_cfg<DT, Cfg128il>(p, s);
             }
         }
     }
