@@ -1290,7 +1290,10 @@ int gemm_pick_config(const GemmParams& p, int dt) {
         return GEMM_CFG_128;
     }
     const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.n_store, 256);
-    long t256 = 700;     // probes: D3R_GEMM_T256 moves the 256x256 / 128x128 crossover, D3R_GEMM_MID=2 sends the shapes below it to 256x128
+    // fp16 + fp8 rows: the 256-wide tile is 1.3-1.6x ahead of the 128 x 128 one per tile (its K loop lost a third of its MFMA work, the small
+    // tile's LDS read traffic per MFMA is twice as high), so it pays from a single round of resident blocks on: measured +1.5 % on the
+    // forward with the decoder's 24576 x 768 GEMMs (288 tiles, two such launches side by side on the two streams) on it
+    long t256 = dt == D3R_F16F8 ? 250 : 700;     // probes: D3R_GEMM_T256 moves the 256x256 / 128x128 crossover, D3R_GEMM_MID=2 sends the shapes below it to 256x128
     if (const char* e = getenv("D3R_GEMM_T256")) t256 = atol(e);
     if (ok256 && tiles256 >= t256) {
         // nn.Linear operands: the ping-pong schedule measured 1-8 % ahead of the plain 2-stage loop (profiles/r01_call13);

@@ -278,6 +278,48 @@ def test_full_size_fp32_pair_matches_oracle(gpu):
         assert mean < bound
 
 
+@pytest.mark.parametrize('big', [40.0, 150.0])
+def test_full_size_default_mode_under_sharp_attention_and_outlier_channels(gpu, big):
+    """Robustness of the default engine (fp16f8: e4m3 copies of the operands carry the cross terms of the blocks' linears) on weights
+    with two traits of TRAINED ViTs that a seeded random network lacks: sharp attention (q / k projections x2: logit std ~2 instead of
+    ~0.5) and outlier channels in the MLP inputs (LayerNorm gains of norm2 / norm3: every 97th channel x8, one channel x40 or x150 --
+    activations in the hundreds; at x150 the e4m3 copies saturate at 448). (Outliers in the ATTENTION inputs turn the softmax into an
+    argmax and the network into a discontinuous function that no arithmetic reproduces, fp32 engine vs fp32 oracle included.)
+    These weights also push pointmaps through the origin (min |pts| 0.02), so the per-pixel RELATIVE error is ill-conditioned in every
+    mode: measured max 6e-4 / 2.6e-3 for the exact-fp32 engine against the fp32 oracle. What is pinned here is that outliers and
+    saturation do not change the character of the mode: its error stays a fixed multiple (measured 15-27x, as on the plain weights) of
+    the fp32 engine's own accumulation-order noise, with a mean below 1e-3."""
+    from oracle.dust3r_ref import build_ref_model_fast
+    cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
+    oracle = build_ref_model_fast(cfg)
+    with torch.no_grad():
+        for name, p in oracle.named_parameters():
+            if name.endswith('attn.qkv.weight'):
+                p[:2 * p.shape[1]] *= 2.0
+            elif name.endswith('cross_attn.projq.weight') or name.endswith('cross_attn.projk.weight'):
+                p *= 2.0
+            elif 'blocks' in name and (name.endswith('.norm2.weight') and 'enc_blocks' in name or name.endswith('.norm3.weight')):
+                p[5::97] *= 8.0
+                p[3] *= big
+    eng = engine_from_oracle(oracle, cfg, None, gpu)
+    assert eng.precision == 'fp16f8'
+    v1, v2 = synthetic_views(1, 384, 512, seed=3)
+    with torch.no_grad():
+        r1, r2 = oracle(v1, v2)
+    worst = {}
+    for prec in ('fp16f8', 'fp16x3', 'fp32'):
+        eng.set_precision(prec)
+        e1, e2 = eng(v1, v2)
+        for name, a, b in (('pts1', e1['pts3d'], r1['pts3d']), ('pts2', e2['pts3d_in_other_view'], r2['pts3d_in_other_view'])):
+            mx, mean = pix_rel(a, b)
+            print(f'[512_dpt {prec}, sharp attention + outlier channels x{big:g}] {name} rel err max {mx:.3e} p99 {pix_rel_p99(a, b):.3e} mean {mean:.3e}   |pts| min {float(b.norm(dim=-1).min()):.3e}')
+            worst[prec] = max(worst.get(prec, 0.0), mx)
+        if prec == 'fp16f8':
+            assert mean < 1.5e-3
+    assert worst['fp16f8'] < 50 * worst['fp32'], worst
+    assert worst['fp16x3'] < 5 * worst['fp32'], worst
+
+
 def test_config1_pairviewer_pipeline(gpu):
     """BASELINE configs[0] plumbing on the engine: a 224x224 linear-head model, 2 images -> 1 symmetrised pair ->
     inference() -> GlobalAlignerMode.PairViewer -> getters, with demo.py's call sequence and the reference's shapes."""

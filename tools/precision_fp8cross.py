@@ -109,11 +109,14 @@ for hd in (m.downstream_head1, m.downstream_head2):      # |xyz| of O(1), as ora
     hd.dpt.head[4].weight.data *= 40
 
 
+FINE = len(sys.argv) > 4 and sys.argv[4] == 'fine'      # per kind of linear layer inside the transformer blocks
+
+
 def group_of(name):
     if name.startswith(('patch_embed', 'enc_blocks')):
-        return 'enc'
+        return 'enc.' + name.split('.')[-1] if FINE and name.startswith('enc_blocks') else 'enc'
     if name.startswith(('decoder_embed', 'dec_blocks')):
-        return 'dec'
+        return 'dec.' + name.split('.')[-1] if FINE and name.startswith('dec_blocks') else 'dec'
     if 'downstream_head' in name:
         return 'head'
     return None
@@ -149,6 +152,13 @@ cases += [('f8x:mx encoder only', {'enc': 'f8x:mx', 'dec': 'x3', 'head': 'x3'}),
           ('f8a:mx everywhere (2.5 units: only xl.wh on fp8)', {g: 'f8a:mx' for g in ALL}),
           ('f8w:mx everywhere (2.5 units: only xh.wl on fp8)', {g: 'f8w:mx' for g in ALL}),
           ('f8xx:mx everywhere (two-piece cross factors)', {g: 'f8xx:mx' for g in ALL})]
+if FINE:
+    kinds = sorted({mod._pgroup for _, mod in m.named_modules() if getattr(mod, '_pgroup', None) and '.' in mod._pgroup})
+    base = {g: 'x3' for g in ['enc', 'dec', 'head'] + kinds}
+    cases = [('fp16x3 everywhere', dict(base)), ('f8x:raw in every block linear (the fp16f8 engine)', dict(base, **{k: 'f8x:raw' for k in kinds}))]
+    cases += [(f'f8x:raw only in {k}', dict(base, **{k: 'f8x:raw'})) for k in kinds]
+    cases += [('f8x:raw in the blocks except qkv / projq / projk / projv', dict(base, **{k: 'f8x:raw' for k in kinds if k.split('.')[1] not in ('qkv', 'projq', 'projk', 'projv')})),
+              ('f8x:raw in the MLPs only (fc1, fc2)', dict(base, **{k: 'f8x:raw' for k in kinds if k.split('.')[1] in ('fc1', 'fc2')}))]
 print(f'{"scheme":52s} {"max":>9s} {"p99":>9s} {"mean":>9s}')
 for label, active in cases:
     e = ((run(active) - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-12)).flatten()

@@ -79,7 +79,9 @@ import json  # noqa: E402
 CFG_OF = {(2, 2, 4, 4, 2, 128, 2, 0): 0, (2, 4, 8, 4, 2, 128, 2, 0): 1, (2, 4, 4, 4, 2, 128, 2, 0): 2, (1, 8, 8, 4, 2, 128, 2, 0): 3,
           (1, 4, 8, 4, 2, 64, 3, 0): 4, (2, 4, 8, 4, 2, 64, 4, 0): 5,
           (2, 2, 4, 4, 2, 128, 2): 0, (2, 4, 8, 4, 2, 128, 2): 1, (2, 4, 4, 4, 2, 128, 2): 2, (1, 8, 8, 4, 2, 128, 2): 3,
-          (1, 4, 8, 4, 2, 64, 3): 4, (2, 4, 8, 4, 2, 64, 4): 5, (2, 4, 8, 4, 2, 64, 4, 1): 6}
+          (1, 4, 8, 4, 2, 64, 3): 4, (2, 4, 8, 4, 2, 64, 4): 5, (2, 4, 8, 4, 2, 64, 4, 1): 6,
+          # fp16 + fp8 rows, DMA pieces interleaved with the MFMA rows (PP = 4)
+          (2, 2, 4, 4, 2, 128, 2, 4): 0, (2, 4, 8, 4, 2, 128, 2, 4): 1, (2, 4, 4, 4, 2, 128, 2, 4): 2, (1, 8, 8, 4, 2, 128, 2, 4): 3}
 
 
 def pmc_means(tag, counter):
@@ -123,7 +125,7 @@ for name in names:
             digest['gemm_cfg'][str(cfg)] = entry
     elif 'aligner_main_kernel' in name:
         digest['aligner_main_kernel'] = entry
-    elif f'attention_kernel<{run_dt}>' in name:
+    elif 'attention_kernel<' in name:
         digest['attention_kernel'] = entry
 if fetch or write:
     with open(os.path.join(out, 'pmc_latest.json'), 'w') as f:
