@@ -204,10 +204,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
                 } else if constexpr (DT == D3R_F16X3) {
                     // keys kbase..+3 sit in 8-group kbase/8 at element offset 4*hh, keys kbase+8..+11 in the next group
                     uint4 ph, pl;
-                    TR::split2(s[rb][8 * sh + 0], s[rb][8 * sh + 1], ph.x, pl.x);
-                    TR::split2(s[rb][8 * sh + 2], s[rb][8 * sh + 3], ph.y, pl.y);
-                    TR::split2(s[rb][8 * sh + 4], s[rb][8 * sh + 5], ph.z, pl.z);
-                    TR::split2(s[rb][8 * sh + 6], s[rb][8 * sh + 7], ph.w, pl.w);
+                    // p = exp2(s c - m c) with m the running maximum: 0 <= p <= 1, no range clamp in front of the fp16 conversions
+                    TR::split2_inrange(s[rb][8 * sh + 0], s[rb][8 * sh + 1], ph.x, pl.x);
+                    TR::split2_inrange(s[rb][8 * sh + 2], s[rb][8 * sh + 3], ph.y, pl.y);
+                    TR::split2_inrange(s[rb][8 * sh + 4], s[rb][8 * sh + 5], ph.z, pl.z);
+                    TR::split2_inrange(s[rb][8 * sh + 6], s[rb][8 * sh + 7], ph.w, pl.w);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
                         const char* vrow = vb + (db * 32 + l31) * C::VROW + (kbase >> 3) * 32 + hh * 8;

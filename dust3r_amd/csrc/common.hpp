@@ -123,6 +123,15 @@ template <> struct Traits<D3R_F16X3> {
         hi = __builtin_bit_cast(uint32_t, h);
         lo = __builtin_bit_cast(uint32_t, l);
     }
+    // the same without the range clamps, for values known to lie inside the fp16 range (softmax probabilities)
+    D3R_DEV static void split2_inrange(float x, float y, uint32_t& hi, uint32_t& lo) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+        const _Float16 hx = (_Float16)x, hy = (_Float16)y;
+        v2 h = {hx, hy};
+        v2 l = {(_Float16)(x - (float)hx), (_Float16)(y - (float)hy)};
+        hi = __builtin_bit_cast(uint32_t, h);
+        lo = __builtin_bit_cast(uint32_t, l);
+    }
     D3R_DEV static float join_lo(uint32_t hi, uint32_t lo) {
         return (float)__builtin_bit_cast(_Float16, (uint16_t)(hi & 0xFFFFu)) + (float)__builtin_bit_cast(_Float16, (uint16_t)(lo & 0xFFFFu));
     }
@@ -328,20 +337,14 @@ template <int DT> D3R_DEV float load1(const void* base, size_t elem_off) {
 // (d3r_wait_vm0) in front of the barrier that publishes the tile. lds_dst: wave-uniform LDS byte address (the DMA
 // writes lane l's 16 bytes at lds_dst + 16 l); gsrc: this lane's source address.
 D3R_DEV void glds16(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+    // M0 declared clobbered (not saved / restored around the load: two scalar instructions per piece, 16 pieces per K step)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 // The same DMA with a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit unsigned byte offset: half the address registers
 // of glds16 (a 256 x 256 tile keeps 16 row addresses per lane alive through its K loop).
 D3R_DEV void glds16_so(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
+    // M0 is declared clobbered instead of saved and restored around the load: two scalar instructions less per piece (16 pieces per K step)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 D3R_DEV void d3r_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 D3R_DEV uint32_t lds_addr(const void* p) {

@@ -317,3 +317,30 @@ def test_inference_groups_mixed_shapes_and_coalesces_batches():
     for view in ('pred1', 'pred2'):
         for k in ref[view]:
             assert torch.equal(ref[view][k], out[view][k])
+
+
+def test_fp16_fp8_row_layout_on_the_host():
+    """The host-side packers of the fp16 + fp8 operand rows (dust3r_amd/ops.py: the layout csrc/common.hpp documents for
+    Traits<D3R_F16F8>) and the fp64 emulation of the contraction the GPU tests compare the kernel with: byte layout of a 256-byte
+    super-group, the activation / weight encodings, the decoded value (15-16 bits), saturation of the e4m3 copies at 448, and the
+    accuracy class of the scheme (an fp16-only product is ~30x worse)."""
+    from dust3r_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 128, generator=g) * 3
+    w = torch.randn(7, 128, generator=g) * 0.03
+    px, pw = ops.pack_f8(x), ops.pack_f8(w, weight=True)
+    assert px.dtype == torch.uint8 and px.shape == (5, 512) and pw.shape == (7, 512)
+    hi, a8, b8 = ops.unpack_f8(px, parts=True)
+    assert torch.equal(hi, x.half().float())                                       # bytes 0..127 of a super-group: 64 fp16 values
+    assert torch.equal(a8, ops._e4m3(hi)) and torch.equal(b8, ops._e4m3((x - hi) * 2048))   # then a8 x64, then b8 x64
+    assert torch.equal(px[0, :4], x[0, :2].half().view(torch.uint8)) and px[0, 128] == a8[0, 0] and px[0, 192] == b8[0, 0]
+    whi, wa8, wb8 = ops.unpack_f8(pw, weight=True, parts=True)
+    assert torch.equal(wa8, ops._e4m3((w - whi) * 131072)) and torch.equal(wb8, ops._e4m3(whi * 64))    # weights: [lo | hi] with the 2^6 shift
+    assert float((ops.unpack_f8(px) - x).abs().max() / x.abs().max()) < 2e-5
+    assert float((ops.unpack_f8(pw, weight=True) - w).abs().max() / w.abs().max()) < 2e-5
+    big = torch.full((1, 64), 1000.0)
+    assert int(ops.unpack_f8(ops.pack_f8(big), parts=True)[1][0, 0]) == 0x7E        # e4m3(1000) saturates at 448, never NaN
+    exact = x.double() @ w.double().T
+    err = float((ops.emulate_f8(x, w) - exact).abs().max() / exact.abs().max())
+    err16 = float((x.half().double() @ w.half().double().T - exact).abs().max() / exact.abs().max())
+    assert err < 3e-5 and err16 > 10 * err
