@@ -70,6 +70,7 @@ typedef GemmCfg<2, 4, 8, 4, 2, 128, 2, 4> Cfg256il;
 typedef GemmCfg<2, 4, 4, 4, 2, 128, 2, 4> Cfg256x128il;
 typedef GemmCfg<2, 2, 4, 4, 2, 128, 2, 4> Cfg128il;
 typedef GemmCfg<1, 8, 8, 4, 2, 128, 2, 4> Cfg512x128il;
+typedef GemmCfg<1, 4, 8, 4, 2, 64, 3, 5> Cfg256x128f8;   // fp16 + fp8 rows: M 256 x N 128 by four waves of 128 (n) x 64 (m), 64-byte K steps, 3 x 24 KiB: TWO blocks per CU
 typedef GemmCfg<2, 4, 8, 4, 2, 128, 2, 3> Cfg256a3;     // 256 x 256, asymmetric ring (A x 3, W x 2), 160 KiB LDS
 // (256 x 256 by FOUR waves of 128 x 128 -- 256 accumulator registers per lane, one wave per SIMD, a third less LDS read traffic per
 // MFMA -- compiles to 256 VGPR + 256 AGPR with the accumulator array in scratch: 90-105 TF/s algorithmic against 390-480, round 2.
@@ -495,6 +496,90 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!trailing) __builtin_amdgcn_s_barrier();
+    } else if constexpr (DT == D3R_F16F8 && KTB == 64) {
+        // ---- fp16 + fp8 rows, 64-byte K steps, three LDS slots of 24 KiB: a 256 (m) x 128 (n) tile by FOUR waves of 128 (n) x 64 (m) --------
+        // Why: one 8-wave 256 x 256 block per CU spends a quarter of a K = 1024 tile's life in its epilogue with the MFMA pipes idle (the
+        // same forward with the epilogues removed runs 282 instead of 213 pairs/s). This shape keeps the per-wave tile (the LDS read
+        // traffic per MFMA) and halves the block, so that TWO blocks are resident per CU (2 x 72 KiB of LDS, 256 VGPRs per wave at two
+        // waves per SIMD) and one block's K loop runs under the other's epilogue.
+        // A 256-byte super-group [hi fp16 x64 | a8 x64 | b8 x64] is four steps h0, h1, fa, fb; step s lives in slot s % 3 = (j + i) % 3
+        // for step i of super-group j. Per super-group three phases, each [wait | barrier | issue loads | math]:
+        //   B0: math on h0 (one 16x16x32 k-step, lane group g on chunk g);   loads issued: h1(j), fa(j)
+        //   B1: math on h1;                                                  loads issued: fb(j)      -> the slot h0(j) just left
+        //   B2: math on (fa, fb): ONE fp8 MFMA per fragment pair, a8 from fa's slot and b8 from fb's;   loads issued: h0(j + 1)
+        // A load goes out behind the barrier that follows the last read of its slot's previous tenant (three steps earlier); loads
+        // complete in order, so B1 waits with vmcnt(LPS) (fa's pieces may still fly) and B0 / B2 with vmcnt(0).
+        static_assert(NS == 3 && CF::NWI == 1, "fp16 + fp8 rows on 64-byte K steps: three slots, waves stacked along m");
+        const bool edge = __builtin_amdgcn_readfirstlane(m0 + BM > p.M ? 1 : 0) != 0;
+        const uint32_t a0 = (uint32_t)(((size_t)min(m0 + lrow, p.M - 1) * p.lda) * EB + lchunk * 16);
+        const uint32_t w0 = (uint32_t)(((size_t)(n0 + lrow) * p.K) * EB + lchunk * 16);
+        const size_t stride_a = (size_t)CF::PASS_ROWS * p.lda * EB, stride_w = (size_t)CF::PASS_ROWS * p.K * EB;
+        auto load_step = [&](int step, int slot) __attribute__((always_inline)) {   // 64-byte K step `step` of every row -> LDS slot
+            const uint32_t sb = lds0 + slot * STAGE_BYTES;
+            const char* ab = reinterpret_cast<const char*>(p.act) + (size_t)step * KTB;
+            const char* wb = reinterpret_cast<const char*>(p.wgt) + (size_t)step * KTB;
+#pragma unroll
+            for (int q = 0; q < CF::APASS; ++q) {
+                if (!edge) {
+                    glds16_so(ab + q * stride_a, a0, sb + q * (CF::NW * 1024));
+                } else {
+                    const int m = min(m0 + q * CF::PASS_ROWS + lrow, p.M - 1);
+                    glds16_so(ab, (uint32_t)(((size_t)m * p.lda) * EB + lchunk * 16), sb + q * (CF::NW * 1024));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CF::WPASS; ++q) glds16_so(wb + q * stride_w, w0, sb + BM * KTB + q * (CF::NW * 1024));
+        };
+        const int coff = (fgrp ^ fsw) * 16;
+        auto math_hi = [&](int slot) __attribute__((always_inline)) {
+            const char* sb = smem + slot * STAGE_BYTES;
+            uint4 qf[FJ];
+#pragma unroll
+            for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (q_row0 + f * 16) * KTB + coff);
+#pragma unroll
+            for (int fi = 0; fi < FI; ++fi) {
+                const uint4 pf = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + fi * 16) * KTB + coff);
+#pragma unroll
+                for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], pf, qf[fj]);
+            }
+        };
+        const int nsg = nk / 4;
+        load_step(0, 0);
+        int b = 0;
+        for (int j = 0; j < nsg; ++j) {
+            const int b1 = b == 2 ? 0 : b + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+            d3r_wait_vm0();
+            __syncthreads();
+            load_step(4 * j + 1, b1);
+            load_step(4 * j + 2, b2);
+            math_hi(b);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            __syncthreads();
+            load_step(4 * j + 3, b);
+            math_hi(b1);
+            d3r_wait_vm0();
+            __syncthreads();
+            if (j + 1 < nsg) load_step(4 * j + 4, b1);
+            {
+                const char* sa = smem + b2 * STAGE_BYTES;
+                const char* sbb = smem + b * STAGE_BYTES;
+                uint4 qa[FJ], qb[FJ];
+#pragma unroll
+                for (int f = 0; f < FJ; ++f) {
+                    const int ro = q_off + (q_row0 + f * 16) * KTB + coff;
+                    qa[f] = *reinterpret_cast<const uint4*>(sa + ro);
+                    qb[f] = *reinterpret_cast<const uint4*>(sbb + ro);
+                }
+#pragma unroll
+                for (int fi = 0; fi < FI; ++fi) {
+                    const int ro = p_off + (p_row0 + fi * 16) * KTB + coff;
+                    const uint4 pa = *reinterpret_cast<const uint4*>(sa + ro), pb = *reinterpret_cast<const uint4*>(sbb + ro);
+#pragma unroll
+                    for (int fj = 0; fj < FJ; ++fj) TR::mma16_f8(acc[fi][fj], pa, pb, qa[fj], qb[fj]);
+                }
+            }
+            b = b1;
+        }
     } else if constexpr (DT == D3R_F16F8) {
         // ---- fp16 + fp8 rows: the K loop walks 256-byte super-groups [hi fp16 x64 | a8 x64 | b8 x64] (64 logical k) in two K steps --------
         // Step 2t stages the fp16 half into stage 0: two f16 MFMA k-steps, lane group g on chunks g and 4 + g. Step 2t + 1 stages the fp8
@@ -1338,6 +1423,11 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
         }
     }
     if constexpr (DT == D3R_F16F8) {
+        // two blocks per CU (256 x 128 tile, four waves, 64-byte K steps): one block's K loop under the other's epilogue. The attention
+        // projections keep the square tile (their V^T regions swap the MFMA operand roles). D3R_GEMM_F8W4=1 / 0.
+        const char* e_w4 = getenv("D3R_GEMM_F8W4");
+        const int w4 = e_w4 ? (e_w4[0] == '1' ? 1 : 0) : 0;
+        if (w4 == 1 && cfg == GEMM_CFG_256 && p.epi != EPI_HEADS && p.n_store % 128 == 0) return launch_cfg<DT, Cfg256x128f8>(p, s);
         // DMA pieces interleaved with the MFMA rows (PP = 4). Measured on MI355X (profiles/r02_f8/bench_f8_il.log): +3 % on the 256-wide
         // tiles (one block per CU: behind the barrier neither wave of a SIMD has MFMAs to issue), -2.5 % on the 128 x 128 tile (the
         // CU's second block already fills that gap). D3R_GEMM_F8IL=0 / 1 forces the burst / interleaved loop everywhere.

@@ -80,7 +80,7 @@ def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize('cfg', ['0', '1', '2', '3'])
+@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '1w4'])
 @pytest.mark.parametrize('M,N,K', [(300, 192, 256), (1000, 3072, 1024), (77, 128, 768), (2100, 1024, 64), (515, 320, 128)])
 def test_linear_fp16_fp8(gpu, M, N, K, cfg, monkeypatch):
     """The fp16 + fp8 operand mode at kernel level (hi.hi on the f16 MFMA, both cross terms on one K-concatenated e4m3 MFMA with an E8M0
@@ -89,7 +89,9 @@ def test_linear_fp16_fp8(gpu, M, N, K, cfg, monkeypatch):
     two operands and the scale are all pinned; the distance to the exact product is checked too (an fp16-only product is ~30x worse).
     Activation-row outputs ('store' / 'gelu') are compared after decoding (hi + lo8 2^-11: one output rounding of 2^-15)."""
     from dust3r_amd import ops
-    monkeypatch.setenv('D3R_GEMM_CFG', cfg)
+    # '1w4': the two-blocks-per-CU shape of the 256-wide configuration (256 x 128 tile by four waves, 64-byte K steps, three LDS slots)
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg[0])
+    monkeypatch.setenv('D3R_GEMM_F8W4', '1' if cfg.endswith('w4') else '0')
     g = torch.Generator(device='cpu').manual_seed(M * 7 + N)
     a = torch.randn((M, K), generator=g).to(gpu)
     w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(gpu)

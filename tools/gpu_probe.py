@@ -72,21 +72,28 @@ def gemmtrace_probe():
     network's epilogues: entry -> K-loop start (prologue), K loop, epilogue until its last store is issued, store drain; and the gap
     between a block's end and the start of the next block on the same CU (dispatch + launch overhead)."""
     import numpy as np
-    from dust3r_amd._lib import lib, ptr, current_stream, check, DTYPE_F16X3
-    print('== GEMM phase trace (fp16x3; wall-clock ticks converted to us)')
+    import os
+    from dust3r_amd._lib import lib, ptr, current_stream, check, DTYPE_F16X3, DTYPE_F16F8
+    f8 = os.environ.get('D3R_PROBE_DT', 'fp16x3') == 'fp16f8'     # D3R_PROBE_DT=fp16f8: the fp16 + fp8 operand rows of the default engine's block linears
+    print(f"== GEMM phase trace ({'fp16f8' if f8 else 'fp16x3'}; wall-clock ticks converted to us)")
     rate = 100e6
     for (M, N, K, epi, name) in [(49152, 1024, 1024, 1, 'proj + fp32 residual'), (49152, 4096, 1024, 2, 'fc1 + GELU'), (49152, 1024, 4096, 1, 'fc2 + fp32 residual'),
-                                 (49152, 3072, 1024, 0, 'plain x3 store'), (24576, 768, 768, 1, 'decoder 768 + fp32 residual')]:
-        a = ops.pack_x3(torch.randn((M, K), device=dev))
-        w = ops.pad_rows(ops.pack_x3(torch.randn((N, K), device=dev) / math.sqrt(K)))
+                                 (49152, 3072, 1024, 0, 'plain typed store'), (24576, 768, 768, 1, 'decoder 768 + fp32 residual')]:
+        if f8:
+            a = ops.pack_f8(torch.randn((M, K), device=dev))
+            w = ops.pad_rows(ops.pack_f8(torch.randn((N, K), device=dev) / math.sqrt(K), weight=True))
+        else:
+            a = ops.pack_x3(torch.randn((M, K), device=dev))
+            w = ops.pad_rows(ops.pack_x3(torch.randn((N, K), device=dev) / math.sqrt(K)))
         b = ops.pad_rows(torch.randn(N, device=dev))
         res = torch.randn((M, N), device=dev) if epi == 1 else None
         out = torch.empty((M, N), dtype=torch.float32, device=dev) if epi == 1 else torch.empty((M, 2 * N), dtype=torch.float16, device=dev)
         nblk = ((M + 127) // 128) * ((N + 127) // 128)
         buf = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
+        dtc = DTYPE_F16F8 if f8 else DTYPE_F16X3
 
         def run():
-            check(lib.d3r_linear(ptr(a), ptr(w), ptr(b), ptr(out), ptr(res), M, N, K, epi, DTYPE_F16X3, current_stream()))
+            check(lib.d3r_linear(ptr(a), ptr(w), ptr(b), ptr(out), ptr(res), M, N, K, epi, dtc, current_stream()))
         for _ in range(2):
             run()
         ms = timeit(run, warm=1, reps=5)
