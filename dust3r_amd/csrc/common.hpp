@@ -115,8 +115,8 @@ template <> struct Traits<D3R_F16X3> {
     // split two floats into packed (hi, hi) and (lo, lo) fp16 pairs; inputs saturate at the fp16 range
     D3R_DEV static void split2(float x, float y, uint32_t& hi, uint32_t& lo) {
         typedef __attribute__((ext_vector_type(2))) _Float16 v2;
-        x = fminf(fmaxf(x, -65504.f), 65504.f);
-        y = fminf(fmaxf(y, -65504.f), 65504.f);
+        x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);   // one v_med3_f32 (fminf(fmaxf()) costs two canonicalising v_max on top)
+        y = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
         const _Float16 hx = (_Float16)x, hy = (_Float16)y;
         v2 h = {hx, hy};
         v2 l = {(_Float16)(x - (float)hx), (_Float16)(y - (float)hy)};
@@ -167,12 +167,12 @@ template <> struct Traits<D3R_F16F8> {
         const i32x8_t B = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, b0), __builtin_bit_cast(i32x4_t, b1), 0, 1, 2, 3, 4, 5, 6, 7);
         acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, acc, 0, 0, 0, SCALE_P, 0, SCALE_Q);
     }
-    D3R_DEV static float clamp8(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+    D3R_DEV static float clamp8(float x) { return __builtin_amdgcn_fmed3f(x, -448.f, 448.f); }
     // four consecutive values -> 4 x fp16 (hi), 4 x e4m3 (a), 4 x e4m3 (b); WGT: the weight encoding
     template <bool WGT> D3R_DEV static void enc4(float v0, float v1, float v2, float v3, uint2& hi, uint32_t& a, uint32_t& b) {
         typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
-        v0 = fminf(fmaxf(v0, -65504.f), 65504.f); v1 = fminf(fmaxf(v1, -65504.f), 65504.f);
-        v2 = fminf(fmaxf(v2, -65504.f), 65504.f); v3 = fminf(fmaxf(v3, -65504.f), 65504.f);
+        v0 = __builtin_amdgcn_fmed3f(v0, -65504.f, 65504.f); v1 = __builtin_amdgcn_fmed3f(v1, -65504.f, 65504.f);
+        v2 = __builtin_amdgcn_fmed3f(v2, -65504.f, 65504.f); v3 = __builtin_amdgcn_fmed3f(v3, -65504.f, 65504.f);
         const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1, h2 = (_Float16)v2, h3 = (_Float16)v3;
         const h2_t p01 = {h0, h1}, p23 = {h2, h3};
         hi.x = __builtin_bit_cast(uint32_t, p01);
