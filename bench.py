@@ -344,8 +344,11 @@ def main():
             # MFMA work per logical product in units of one 16-bit MFMA: split-fp16 issues three f16 MFMAs; fp16 + fp8 one f16 MFMA plus
             # both cross terms on the fp8 pipe at twice the 16-bit rate (2 x 2 M N K flops at 5 PFLOP/s = one more 16-bit unit)
             mfma_per_product = {'fp16x3': 3, 'fp16f8': 2}.get(dom_dt, 1)
+            cfg_name = GEMM_CFG_NAMES.get(dom, dom)
+            if dom_dt == 'fp16f8' and dom in (1, 2, 3):      # rocprofv3 symbol: gemm_kernel<4, GemmCfg<...,128,2,4>> (DMA pieces interleaved with the MFMA rows)
+                cfg_name = cfg_name.replace(',128,2>', ',128,2,4>')
             result['roofline'] = {
-                'bound': 'mfma', 'kernel': f'd3r::gemm_kernel<{dom_dt}, {GEMM_CFG_NAMES.get(dom, dom)}>',
+                'bound': 'mfma', 'kernel': f'd3r::gemm_kernel<{dom_dt}, {cfg_name}>',
                 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                 'achieved_executed_mfma': ach * mfma_per_product, 'frac_executed_mfma': ach * mfma_per_product / PEAK_BF16_TFLOPS,
                 'mfma_per_product': mfma_per_product,

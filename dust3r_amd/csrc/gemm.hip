@@ -511,20 +511,23 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         // complete in order, so B1 waits with vmcnt(LPS) (fa's pieces may still fly) and B0 / B2 with vmcnt(0).
         static_assert(NS == 3 && CF::NWI == 1, "fp16 + fp8 rows on 64-byte K steps: three slots, waves stacked along m");
         const bool edge = __builtin_amdgcn_readfirstlane(m0 + BM > p.M ? 1 : 0) != 0;
-        const uint32_t a0 = (uint32_t)(((size_t)min(m0 + lrow, p.M - 1) * p.lda) * EB + lchunk * 16);
-        const uint32_t w0 = (uint32_t)(((size_t)(n0 + lrow) * p.K) * EB + lchunk * 16);
+        // offsets are relative to the TILE's first row (its 64-bit address is wave-uniform: SGPRs), so they fit 32 bits whatever the operand size
+        const char* const tile_a = reinterpret_cast<const char*>(p.act) + (size_t)__builtin_amdgcn_readfirstlane(m0) * p.lda * EB;
+        const char* const tile_w = reinterpret_cast<const char*>(p.wgt) + (size_t)__builtin_amdgcn_readfirstlane(n0) * p.K * EB;
+        const uint32_t a0 = (uint32_t)(((size_t)(min(m0 + lrow, p.M - 1) - m0) * p.lda) * EB + lchunk * 16);
+        const uint32_t w0 = (uint32_t)(((size_t)lrow * p.K) * EB + lchunk * 16);
         const size_t stride_a = (size_t)CF::PASS_ROWS * p.lda * EB, stride_w = (size_t)CF::PASS_ROWS * p.K * EB;
         auto load_step = [&](int step, int slot) __attribute__((always_inline)) {   // 64-byte K step `step` of every row -> LDS slot
             const uint32_t sb = lds0 + slot * STAGE_BYTES;
-            const char* ab = reinterpret_cast<const char*>(p.act) + (size_t)step * KTB;
-            const char* wb = reinterpret_cast<const char*>(p.wgt) + (size_t)step * KTB;
+            const char* ab = tile_a + (size_t)step * KTB;
+            const char* wb = tile_w + (size_t)step * KTB;
 #pragma unroll
             for (int q = 0; q < CF::APASS; ++q) {
                 if (!edge) {
                     glds16_so(ab + q * stride_a, a0, sb + q * (CF::NW * 1024));
                 } else {
                     const int m = min(m0 + q * CF::PASS_ROWS + lrow, p.M - 1);
-                    glds16_so(ab, (uint32_t)(((size_t)m * p.lda) * EB + lchunk * 16), sb + q * (CF::NW * 1024));
+                    glds16_so(ab, (uint32_t)(((size_t)(m - m0) * p.lda) * EB + lchunk * 16), sb + q * (CF::NW * 1024));
                 }
             }
 #pragma unroll
@@ -587,28 +590,31 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         // fp8 MFMA adds both cross terms (its E8M0 scale undoes the 2^17 of the encodings). nk is even (K % 64 == 0).
         static_assert(KTB == 128 && NS == 2, "fp16 + fp8 rows: 128-byte K steps, two stages");
         // nn.Linear operands only. The rows a lane stages are PASS_ROWS apart: ONE 32-bit byte offset per operand in a VGPR, the row
-        // stride added to the wave-uniform 64-bit base in SGPRs (launch_gemm checks the operands are < 4 GiB). With one 64-bit address
+        // stride added to the wave-uniform 64-bit address of the tile's first row in SGPRs. With one 64-bit address
         // per staged row (16 per lane) this loop spilled, and a scratch reload's vmcnt wait also drains the DMA in flight: load and
         // math serialised. Only a tile that hangs over the last row (rows clamped to M - 1) computes its offsets per piece.
         const bool edge = __builtin_amdgcn_readfirstlane(m0 + BM > p.M ? 1 : 0) != 0;   // wave-uniform, and told so (a scalar branch, not an exec mask)
-        const uint32_t a0 = (uint32_t)(((size_t)min(m0 + lrow, p.M - 1) * p.lda) * EB + lchunk * 16);
-        const uint32_t w0 = (uint32_t)(((size_t)(n0 + lrow) * p.K) * EB + lchunk * 16);
+        // offsets are relative to the TILE's first row (its 64-bit address is wave-uniform: SGPRs), so they fit 32 bits whatever the operand size
+        const char* const tile_a = reinterpret_cast<const char*>(p.act) + (size_t)__builtin_amdgcn_readfirstlane(m0) * p.lda * EB;
+        const char* const tile_w = reinterpret_cast<const char*>(p.wgt) + (size_t)__builtin_amdgcn_readfirstlane(n0) * p.K * EB;
+        const uint32_t a0 = (uint32_t)(((size_t)(min(m0 + lrow, p.M - 1) - m0) * p.lda) * EB + lchunk * 16);
+        const uint32_t w0 = (uint32_t)(((size_t)lrow * p.K) * EB + lchunk * 16);
         const size_t stride_a = (size_t)CF::PASS_ROWS * p.lda * EB, stride_w = (size_t)CF::PASS_ROWS * p.K * EB;
         // one of the LPS DMA pieces of K step kt (activation rows first, then weight rows); idx is a compile-time constant after unrolling
         auto piece8 = [&](int idx, int kt, int buf) __attribute__((always_inline)) {
             const uint32_t sb = lds0 + buf * STAGE_BYTES;
             if (idx < CF::APASS) {
                 const int q = idx;
-                const char* ab = reinterpret_cast<const char*>(p.act) + (size_t)kt * KTB;
+                const char* ab = tile_a + (size_t)kt * KTB;
                 if (!edge) {
                     glds16_so(ab + q * stride_a, a0, sb + q * (CF::NW * 1024));
                 } else {
                     const int m = min(m0 + q * CF::PASS_ROWS + lrow, p.M - 1);
-                    glds16_so(ab, (uint32_t)(((size_t)m * p.lda) * EB + lchunk * 16), sb + q * (CF::NW * 1024));
+                    glds16_so(ab, (uint32_t)(((size_t)(m - m0) * p.lda) * EB + lchunk * 16), sb + q * (CF::NW * 1024));
                 }
             } else {
                 const int q = idx - CF::APASS;
-                const char* wb = reinterpret_cast<const char*>(p.wgt) + (size_t)kt * KTB;
+                const char* wb = tile_w + (size_t)kt * KTB;
                 glds16_so(wb + q * stride_w, w0, sb + BM * KTB + q * (CF::NW * 1024));
             }
         };
@@ -1471,7 +1477,7 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     if (p.amode == AMODE_CONV) p.kslice_major = conv_k_slice_major() ? 1 : 0;
     if (p.epi == EPI_HEADS && p.head_c % 128 != 0 && p.head_c < (1 << 29)) return hipErrorInvalidValue;
     // fp16 + fp8 rows: nn.Linear operands only, whole 64-element super-groups; outputs: fp32 (+ residual), GELU / plain activation rows, heads
-    if (dt == D3R_F16F8 && ((size_t)p.M * p.lda * 4 >= (1ull << 32) || (size_t)(p.n_rows > 0 ? p.n_rows : p.n_pad) * p.K * 4 >= (1ull << 32))) return hipErrorInvalidValue;
+    if (dt == D3R_F16F8 && ((size_t)512 * p.lda * 4 >= (1ull << 32) || (size_t)512 * p.K * 4 >= (1ull << 32))) return hipErrorInvalidValue;   // 32-bit offsets inside a tile
     if (dt == D3R_F16F8 && (p.amode != AMODE_LINEAR || p.K % 64 != 0 || p.lda % 64 != 0 || p.epi == EPI_CONVT || p.res2 ||
                             (p.epi == EPI_T && (p.res1 || p.out2)) || ((p.epi == EPI_T || p.epi == EPI_GELU) && (p.ldo % 64 != 0 || p.n_store % 4 != 0))))
         return hipErrorInvalidValue;

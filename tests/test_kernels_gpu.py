@@ -117,6 +117,20 @@ def test_linear_fp16_fp8(gpu, M, N, K, cfg, monkeypatch):
         assert torch.equal(x, y)
 
 
+def test_linear_fp16_fp8_operand_beyond_4_gib(gpu):
+    """The fp16 + fp8 K loop addresses its DMA sources as a wave-uniform 64-bit tile base (SGPRs) plus ONE 32-bit offset per lane: the
+    offsets are relative to the tile's first row, so an activation operand larger than 4 GiB (here 280 000 x 4096 x 4 B = 4.6 GB: the
+    MLP hidden of ~180 pairs at 512x384 in one engine call) is fine. First and last rows against the fp64 emulation."""
+    from dust3r_amd import ops
+    M, N, K = 280000, 128, 4096
+    g = torch.Generator(device=gpu).manual_seed(5)
+    a = torch.randn((M, K), generator=g, device=gpu)
+    w = torch.randn((N, K), generator=g, device=gpu) / math.sqrt(K)
+    out = ops.linear_f8(a, w, None, 'f32')
+    for sl in (slice(0, 512), slice(M - 777, M)):
+        assert relerr(out[sl], ops.emulate_f8(a[sl], w).float()) < 3e-6
+
+
 @pytest.mark.parametrize('rows,C', [(7, 128), (1000, 768), (513, 1024)])
 def test_layernorm_fp16_fp8_rows(gpu, rows, C):
     """LayerNorm into fp16 + fp8 activation rows: hi is the fp16 rounding of the fp32 LayerNorm, a8 = e4m3(hi) exactly, and
