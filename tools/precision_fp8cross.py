@@ -110,9 +110,15 @@ for hd in (m.downstream_head1, m.downstream_head2):      # |xyz| of O(1), as ora
 
 
 FINE = len(sys.argv) > 4 and sys.argv[4] == 'fine'      # per kind of linear layer inside the transformer blocks
+DEPTH = len(sys.argv) > 4 and sys.argv[4] == 'depth'    # per quarter of the encoder / third of the decoder
 
 
 def group_of(name):
+    if DEPTH and name.startswith('enc_blocks'):
+        b = int(name.split('.')[1])
+        return 'enc.b%d' % b if b < 6 and len(sys.argv) > 5 else 'enc.q%d' % (b // 6)
+    if DEPTH and name.startswith('dec_blocks'):
+        return 'dec.t%d' % (int(name.split('.')[1]) // 4)
     if name.startswith(('patch_embed', 'enc_blocks')):
         return 'enc.' + name.split('.')[-1] if FINE and name.startswith('enc_blocks') else 'enc'
     if name.startswith(('decoder_embed', 'dec_blocks')):
@@ -152,12 +158,19 @@ cases += [('f8x:mx encoder only', {'enc': 'f8x:mx', 'dec': 'x3', 'head': 'x3'}),
           ('f8a:mx everywhere (2.5 units: only xl.wh on fp8)', {g: 'f8a:mx' for g in ALL}),
           ('f8w:mx everywhere (2.5 units: only xh.wl on fp8)', {g: 'f8w:mx' for g in ALL}),
           ('f8xx:mx everywhere (two-piece cross factors)', {g: 'f8xx:mx' for g in ALL})]
-if FINE:
+if FINE or DEPTH:
     kinds = sorted({mod._pgroup for _, mod in m.named_modules() if getattr(mod, '_pgroup', None) and '.' in mod._pgroup})
     base = {g: 'x3' for g in ['enc', 'dec', 'head'] + kinds}
     cases = [('fp16x3 everywhere', dict(base)), ('f8x:raw in every block linear (the fp16f8 engine)', dict(base, **{k: 'f8x:raw' for k in kinds}))]
     cases += [(f'f8x:raw only in {k}', dict(base, **{k: 'f8x:raw'})) for k in kinds]
-    cases += [('f8x:raw in the blocks except qkv / projq / projk / projv', dict(base, **{k: 'f8x:raw' for k in kinds if k.split('.')[1] not in ('qkv', 'projq', 'projk', 'projv')})),
+    if DEPTH and len(sys.argv) > 5:      # which leading encoder blocks to keep on split-fp16
+        allf8 = dict(base, **{k: 'f8x:raw' for k in kinds})
+        cases = [('f8x:raw in every block linear (the fp16f8 engine)', allf8)]
+        for n in (1, 2, 3, 4, 6):
+            cases += [(f'... except encoder blocks 0..{n - 1} (fp16x3)', dict(allf8, **{f'enc.b{i}': 'x3' for i in range(n)}))]
+        cases += [('f8x:raw only in encoder block 0', dict(base, **{'enc.b0': 'f8x:raw'})), ('f8x:raw only in encoder block 1', dict(base, **{'enc.b1': 'f8x:raw'}))]
+    if FINE:
+        cases += [('f8x:raw in the blocks except qkv / projq / projk / projv', dict(base, **{k: 'f8x:raw' for k in kinds if k.split('.')[1] not in ('qkv', 'projq', 'projk', 'projv')})),
               ('f8x:raw in the MLPs only (fc1, fc2)', dict(base, **{k: 'f8x:raw' for k in kinds if k.split('.')[1] in ('fc1', 'fc2')}))]
 print(f'{"scheme":52s} {"max":>9s} {"p99":>9s} {"mean":>9s}')
 for label, active in cases:
