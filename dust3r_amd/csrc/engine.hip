@@ -6,7 +6,8 @@
 // kernel launches -- from C++ on the caller's stream, so the Python host makes ONE ctypes call
 // per batch. Data layout in HBM:
 //   residual streams  fp32  [tokens][C]           (LayerNorm, residual adds stay fp32)
-//   GEMM operands     dtype [tokens][C]           (bf16 / f16 / f32 per d3r_model_config.dtype)
+//   GEMM operands     dtype [tokens][C]           (bf16 / f16 / f32 / split-fp16 per d3r_model_config.dtype; with D3R_DTYPE_F16F8 the
+//                                                  inputs and weights of the transformer blocks' linears are fp16 + fp8 rows, the rest split-fp16)
 //   q, k              dtype [B][H][N][64]  (RoPE applied), v^T dtype [B][H][64][ldv]
 //   DPT feature maps  dtype NHWC, channel stride padded to the next K-tile multiple
 //   outputs           fp32  pts3d [B][H][W][3], conf [B][H][W]   (the reference's output layout)

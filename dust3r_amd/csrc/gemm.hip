@@ -18,6 +18,11 @@
 // on the per-lane SOURCE address and again on the fragment read.
 // Block -> tile map: XCD-aware (each XCD owns a contiguous range of tile ids) and panel-rasterised (8 n-tiles wide)
 // so the tiles an XCD works on concurrently share A rows and W rows inside its 4 MiB L2.
+// Precision modes share the tiles, the LDS image and the epilogues (common.hpp, Traits<DT>): one 16-bit or exact-f32 MFMA per product;
+// split-fp16 (hi + lo rows, three f16 MFMAs per product); fp16 + fp8 rows (the default engine's transformer-block linears: 128-byte K
+// steps alternate between the fp16 half and the e4m3 half of a 256-byte super-group -- two f16 MFMAs, then ONE 16x16x128 fp8 MFMA that
+// adds both cross terms, its E8M0 scale undoing the 2^17 of the encodings; DMA row addresses as one 32-bit offset per operand plus
+// scalar strides, DMA pieces interleaved with the MFMA rows on the 256-wide tiles).
 // MFMA operand roles: D[i][j] with 4 consecutive i per lane. Normally i = n (weights) so each
 // lane owns 4 consecutive output columns of one row -> 8/16-byte stores; for V^T tiles of the
 // attention projections the roles are swapped (i = m) so 4 consecutive TOKENS land together.
