@@ -138,14 +138,6 @@ def linear_f8(act, weight, bias=None, epilogue='store', residual=None):
     return out if epi == 1 else unpack_f8(out)
 
 
-def emulate_f8(act, weight):
-    """What the fp16 + fp8 contraction computes, in fp64 on the caller's device: hi.hi + (e4m3(hi_x) e4m3(lo_w 2^17) + e4m3(lo_x 2^11) e4m3(hi_w 2^6)) 2^-17."""
-    xh, xa, xb = unpack_f8(pack_f8(act), parts=True)
-    wh, wa, wb = unpack_f8(pack_f8(weight, weight=True), parts=True)
-    f8 = lambda t: t.contiguous().view(torch.float8_e4m3fn).double()
-    return xh.double() @ wh.double().T + (f8(xa) @ f8(wa).T + f8(xb) @ f8(wb).T) / 131072.0
-
-
 def layernorm_f8(x, gamma, beta, eps=1e-6):
     """LayerNorm into fp16 + fp8 activation rows (uint8 (rows, 4C))."""
     _lib.require_device()

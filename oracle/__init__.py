@@ -5,6 +5,7 @@ CPU restatement of the reference's hot path (naver/dust3r @ /root/reference):
   roma_ref.py          restated `roma` subset           (dependency absent -> PARITY UNPINNED)
   dust3r_ref.py        restated dust3r glue: model.py / heads / postprocess / inference
   aligner_ref.py       restated cloud_opt PointCloudOptimizer forward + Adam loop
+  f8_ref.py            the arithmetic of the engine's fp16 + fp8 contraction in fp64 (no reference counterpart: pins the mode's kernels)
   ref_import.py        (build container only) imports the UNMODIFIED reference files from
                        /root/reference on top of the restated croco/roma shims, to pin the
                        restatements above and to generate tests/golden/* (make_golden.py)

@@ -325,6 +325,7 @@ def test_fp16_fp8_row_layout_on_the_host():
     super-group, the activation / weight encodings, the decoded value (15-16 bits), saturation of the e4m3 copies at 448, and the
     accuracy class of the scheme (an fp16-only product is ~30x worse)."""
     from dust3r_amd import ops
+    from oracle.f8_ref import e4m3, f16f8_matmul
     g = torch.Generator().manual_seed(0)
     x = torch.randn(5, 128, generator=g) * 3
     w = torch.randn(7, 128, generator=g) * 0.03
@@ -340,7 +341,12 @@ def test_fp16_fp8_row_layout_on_the_host():
     assert float((ops.unpack_f8(pw, weight=True) - w).abs().max() / w.abs().max()) < 2e-5
     big = torch.full((1, 64), 1000.0)
     assert int(ops.unpack_f8(ops.pack_f8(big), parts=True)[1][0, 0]) == 0x7E        # e4m3(1000) saturates at 448, never NaN
+    # the product's packers against the oracle's independent restatement of the encodings: decode the packed bytes and contract them
+    f8v = lambda t: t.contiguous().view(torch.float8_e4m3fn).double()      # noqa: E731
+    from_bytes = hi.double() @ whi.double().T + (f8v(a8) @ f8v(wa8).T + f8v(b8) @ f8v(wb8).T) / 131072.0
+    assert torch.equal(from_bytes, f16f8_matmul(x, w))
+    assert torch.equal(f8v(a8), e4m3(hi))
     exact = x.double() @ w.double().T
-    err = float((ops.emulate_f8(x, w) - exact).abs().max() / exact.abs().max())
+    err = float((f16f8_matmul(x, w) - exact).abs().max() / exact.abs().max())
     err16 = float((x.half().double() @ w.half().double().T - exact).abs().max() / exact.abs().max())
     assert err < 3e-5 and err16 > 10 * err

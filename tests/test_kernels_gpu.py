@@ -85,10 +85,11 @@ def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
 def test_linear_fp16_fp8(gpu, M, N, K, cfg, monkeypatch):
     """The fp16 + fp8 operand mode at kernel level (hi.hi on the f16 MFMA, both cross terms on one K-concatenated e4m3 MFMA with an E8M0
     scale of 2^-17): every tile configuration, wide and direct epilogues. The comparator is the SAME arithmetic in fp64 on the host-packed
-    operands (ops.emulate_f8): the kernel must reproduce it to fp32 accumulation noise, i.e. the row layouts, the k-slot pairing of the
+    operands (oracle/f8_ref.py, an independent restatement of the encodings): the kernel must reproduce it to fp32 accumulation noise, i.e. the row layouts, the k-slot pairing of the
     two operands and the scale are all pinned; the distance to the exact product is checked too (an fp16-only product is ~30x worse).
     Activation-row outputs ('store' / 'gelu') are compared after decoding (hi + lo8 2^-11: one output rounding of 2^-15)."""
     from dust3r_amd import ops
+    from oracle.f8_ref import f16f8_matmul
     # '1w4': the two-blocks-per-CU shape of the 256-wide configuration (256 x 128 tile by four waves, 64-byte K steps, three LDS slots)
     monkeypatch.setenv('D3R_GEMM_CFG', cfg[0])
     monkeypatch.setenv('D3R_GEMM_F8W4', '1' if cfg.endswith('w4') else '0')
@@ -97,7 +98,7 @@ def test_linear_fp16_fp8(gpu, M, N, K, cfg, monkeypatch):
     w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(gpu)
     b = torch.randn(N, generator=g).to(gpu)
     res = torch.randn((M, N), generator=g).to(gpu)
-    emu = (ops.emulate_f8(a, w) + b.double()).float()
+    emu = (f16f8_matmul(a, w) + b.double()).float()
     exact = (a.double() @ w.double().T + b.double()).float()
     assert relerr(emu, exact) < 4e-5          # the scheme itself: ~15-16 bits per operand
     got = {}
@@ -122,13 +123,14 @@ def test_linear_fp16_fp8_operand_beyond_4_gib(gpu):
     offsets are relative to the tile's first row, so an activation operand larger than 4 GiB (here 280 000 x 4096 x 4 B = 4.6 GB: the
     MLP hidden of ~180 pairs at 512x384 in one engine call) is fine. First and last rows against the fp64 emulation."""
     from dust3r_amd import ops
+    from oracle.f8_ref import f16f8_matmul
     M, N, K = 280000, 128, 4096
     g = torch.Generator(device=gpu).manual_seed(5)
     a = torch.randn((M, K), generator=g, device=gpu)
     w = torch.randn((N, K), generator=g, device=gpu) / math.sqrt(K)
     out = ops.linear_f8(a, w, None, 'f32')
     for sl in (slice(0, 512), slice(M - 777, M)):
-        assert relerr(out[sl], ops.emulate_f8(a[sl], w).float()) < 3e-6
+        assert relerr(out[sl], f16f8_matmul(a[sl], w).float()) < 3e-6
 
 
 @pytest.mark.parametrize('rows,C', [(7, 128), (1000, 768), (513, 1024)])
