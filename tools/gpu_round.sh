@@ -1,6 +1,7 @@
 #!/bin/bash
 # One gpurun visit: parity tests, kernel probes, bench line and a rocprofv3 kernel trace. Everything lands in gpurun_out/.
-# Usage (from the repo root, on the GPU box): bash tools/gpu_round.sh [tests] [probe] [bench] [prof] [pmc]
+# Usage (from the repo root, on the GPU box): bash tools/gpu_round.sh [tests] [probe] [bench] [prof] [pmc] [pmcsq] [f8]
+# (tools/f8_probe.bin: hipcc --offload-arch=gfx950 -O2 tools/f8_probe.hip -o tools/f8_probe.bin, built here, travels with the snapshot)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out
@@ -16,6 +17,11 @@ for w in $WHAT; do
     testsall) timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -15 $OUT/pytest_gpu.log ;;
     probe) timeout 900 python tools/gpu_probe.py gemm conv attn forward aligner > $OUT/probe.log 2>&1; tail -60 $OUT/probe.log ;;
     tune) timeout 600 python tools/gpu_probe.py tune > $OUT/probe_tune.log 2>&1; tail -40 $OUT/probe_tune.log ;;
+    f8) # the fp16 + fp8 mode's side measurements: hardware probe (instruction semantics + MFMA issue rates), error distribution over weight
+        # seeds, per-block phase trace of the block linears
+        [ -x tools/f8_probe.bin ] && timeout 120 ./tools/f8_probe.bin > $OUT/f8_probe.log 2>&1; tail -5 $OUT/f8_probe.log
+        timeout 300 python tools/margin_survey.py 6 4 > $OUT/margin_survey.log 2>&1; tail -3 $OUT/margin_survey.log
+        D3R_PROBE_DT=fp16f8 timeout 300 python tools/gpu_probe.py gemmtrace > $OUT/gemmtrace_f8.log 2>&1; tail -12 $OUT/gemmtrace_f8.log ;;
     benchq) timeout 600 python bench.py --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.log; grep -E "bench\]" $OUT/bench_quick.log | tail -60 ;;
     bench) timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.log; tail -12 $OUT/bench.log; cat $OUT/bench.json ;;
     prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast --single-stream > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.log); find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
