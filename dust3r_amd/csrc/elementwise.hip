@@ -1,6 +1,8 @@
 // dust3r_amd -- bandwidth-bound kernels of the forward path (gfx950): LayerNorm, dtype
 // conversion, patch gather, the standalone 2-D RoPE op, bilinear x2 upsampling and the
 // post-processing epilogues. All of them move 8-16 bytes per lane per access.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace d3r {
@@ -193,7 +195,21 @@ hipError_t launch_rope_table(float* table, int max_pos, float base, float F0, hi
 // One workgroup per output row (b, oy): the row's source lines and vertical weights are wave-uniform, the per-item index
 // math is 32-bit (the first version decomposed a flat 64-bit index with three 64-bit divisions per item and moved 8 B per
 // lane: 2x off the HBM rate at the head's 384x512 maps). NV groups of 4 channels per lane: 16 B accesses for 16-bit types.
-template <int DT, int NV>
+// split-fp16 rows, 8 consecutive elements, with the non-temporal policy: the x2 maps (3.2 GB at the head's last stage) are written once and
+// read by the NEXT launch only after the whole map has been written -- keeping them out of the L2's way of the four input rows being re-read
+D3R_DEV void store8_x3_nt(void* base, size_t elem_off, const float (&v)[8]) {
+    using TX = Traits<D3R_F16X3>;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    uint4 h, l;
+    TX::split2(v[0], v[1], h.x, l.x); TX::split2(v[2], v[3], h.y, l.y);
+    TX::split2(v[4], v[5], h.z, l.z); TX::split2(v[6], v[7], h.w, l.w);
+    char* p = reinterpret_cast<char*>(base) + TX::boff(elem_off);
+    const u32x4_t hv = {h.x, h.y, h.z, h.w}, lv = {l.x, l.y, l.z, l.w};
+    __builtin_nontemporal_store(hv, reinterpret_cast<u32x4_t*>(p));
+    __builtin_nontemporal_store(lv, reinterpret_cast<u32x4_t*>(p + 16));
+}
+
+template <int DT, int NV, bool NT = false>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const void* __restrict__ in, void* __restrict__ out, void* __restrict__ out_relu,
                                                          int Hi, int Wi, int C, int cstride, int Ho, int Wo) {
     const int cn = C / (4 * NV);
@@ -227,8 +243,13 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const void* __restrict_
                 o[k] = hy * (hx * v00[k] + lx * v01[k]) + ly * (hx * v10[k] + lx * v11[k]);
                 orl[k] = fmaxf(o[k], 0.f);
             }
-            store8<DT>(out, oo, o);
-            if (out_relu) store8<DT>(out_relu, oo, orl);
+            if constexpr (NT && DT == D3R_F16X3) {
+                store8_x3_nt(out, oo, o);
+                if (out_relu) store8_x3_nt(out_relu, oo, orl);
+            } else {
+                store8<DT>(out, oo, o);
+                if (out_relu) store8<DT>(out_relu, oo, orl);
+            }
         } else {
             const float4 v00 = load4<DT>(in, a00), v01 = load4<DT>(in, a01), v10 = load4<DT>(in, a10), v11 = load4<DT>(in, a11);
             const float o0 = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
@@ -242,7 +263,12 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const void* __restrict_
 }
 template <int DT> static void launch_upsample_t(const void* in, void* out, void* out_relu, int B, int Hi, int Wi, int C, int cstride, int Ho, int Wo,
                                                 hipStream_t s) {
-    if (C % 8 == 0 && cstride % 8 == 0) hipLaunchKernelGGL((upsample2x_kernel<DT, 2>), dim3(B * Ho), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);
+    // non-temporal stores of the x2 maps: measured 13.41 -> 12.75 ms of "other" kernels per step, forward 218.7 -> 219.6 pairs/s
+    // (profiles/r02_f8/bench_upsample_nt.log); D3R_UPSAMPLE_NT=0: plain stores
+    static const bool nt = [] { const char* e = getenv("D3R_UPSAMPLE_NT"); return e ? e[0] != '0' : true; }();
+    if (DT == D3R_F16X3 && nt && C % 8 == 0 && cstride % 8 == 0)
+        hipLaunchKernelGGL((upsample2x_kernel<DT, 2, true>), dim3(B * Ho), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);
+    else if (C % 8 == 0 && cstride % 8 == 0) hipLaunchKernelGGL((upsample2x_kernel<DT, 2>), dim3(B * Ho), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);
     else hipLaunchKernelGGL((upsample2x_kernel<DT, 1>), dim3(B * Ho), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);
 }
 hipError_t launch_upsample2x(int dt, const void* in, void* out, void* out_relu, int B, int Hi, int Wi, int C, int cstride,
