@@ -13,8 +13,8 @@ pairwise predictions (dust3r_amd/parallel.py), issued asynchronously so that it 
 Usage: python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
 Prints ONE JSON line on rank 0. Extra objects: "roofline" (dominant kernel, live HIP-event timing), "cpu_baseline"
 (the CPU oracle timed on this host's cores on a bounded sample, rank 0 at N=1 only), "aligner", "kernels", "fast_mode"
-(bf16 / fp16 single-pass throughput with their measured error: the headline precision is fp16f8, the engine default and the faster of
-the two modes that meet the 1e-3 bar; the other one, fp16x3, is reported under "parity_mode_fp16x3").
+(the opt-in modes fp16f8 / bf16 / fp16: throughput, their own dominant-kernel roofline block and their measured error against the headline
+engine. The headline precision is fp16x3, the engine default and the mode that meets the 1e-3 per-pixel bar on every weight set tested).
 """
 import argparse
 import ctypes as C
@@ -102,18 +102,84 @@ def read_launch_table(model):
     return sorted(rows, key=lambda r: -r['ms'])
 
 
+def pmc_digest(precision=None):
+    """The committed digest of the rocprofv3 PMC passes for this precision: profiles/pmc_<precision>.json, else profiles/pmc_latest.json
+    when it was taken in that precision (written by tools/summarize_prof.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of
+    this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). Returns (dict, repo-relative path) or (None, None)."""
+    for name in ([f'pmc_{precision}.json'] if precision else []) + ['pmc_latest.json']:
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        if precision is None or d.get('precision', 'bf16') == precision:
+            return d, 'profiles/' + name
+    return None, None
+
+
 def pmc_traffic_gb(cfg, precision=None):
-    """HBM bytes per launch of the dominant kernel from the last committed rocprofv3 PMC passes (profiles/pmc_latest.json,
-    written by tools/summarize_prof.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950). None when no such file travels with the repository."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')) as f:
-            d = json.load(f)
-        if precision is not None and d.get('precision', 'bf16') != precision:
-            return None                       # the committed PMC passes were taken in another precision mode
-        return d.get('gemm_cfg', {}).get(str(cfg), {}).get('hbm_gb_per_launch')
-    except Exception:
+    """(HBM GB per launch of gemm_kernel<precision, cfg> from the committed PMC digest, where it was read from). The counter passes are NOT
+    re-collected by this command (they need rocprofv3 around it): the figure is carried from the profile named in `source`."""
+    d, path = pmc_digest(precision)
+    if d is None:
+        return None, None
+    v = d.get('gemm_cfg', {}).get(str(cfg), {}).get('hbm_gb_per_launch')
+    return v, (f"{path} ({d.get('visit', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --single-stream')})" if v is not None else None)
+
+
+def profile_mode(model, v1, v2, precision, quiet=False):
+    """One extra forward with a HIP event in front of every launch (single-stream schedule) -> the roofline block of the dominant kernel,
+    the per-kernel-class table and the per-shape launch table of the engine's CURRENT precision mode."""
+    from dust3r_amd._lib import lib
+    lib.d3r_model_set_option(model._engine, 1, 1)
+    model(v1, v2)
+    torch.cuda.synchronize()
+    prof = read_profile(model)
+    table = read_launch_table(model)
+    lib.d3r_model_set_option(model._engine, 1, 0)
+    if not prof:
         return None
+    if not quiet:
+        for r in table[:40]:
+            log(f"[bench]   {r['kernel']:12s} M={r['M']:8d} N={r['N']:5d} K={r['K']:5d}  x{r['launches']:3d}  {r['ms']:8.3f} ms  {r['tflops']:7.1f} TF/s")
+    # dominant kernel = the gemm_kernel instantiation with the largest total time (one kernel symbol in rocprofv3)
+    cands = [('fp16x3' if precision == 'fp16f8' else precision, c, v) for c, v in prof['gemm_cfg'].items()]
+    cands += [('fp16f8', c, v) for c, v in prof['gemm_f8_cfg'].items()]
+    dom_dt, dom, d = max(cands, key=lambda t: t[2]['ms'])
+    total_ms = prof['linear']['ms'] + prof['conv']['ms'] + prof['attention']['ms'] + prof['other']['ms']
+    ach = d['gflop'] / d['ms']                              # GFLOP / ms == TFLOP/s (algorithmic: 2 M N K per launch)
+    # MFMA work per logical product in units of one 16-bit MFMA: split-fp16 issues three f16 MFMAs; fp16 + fp8 one f16 MFMA plus
+    # both cross terms on the fp8 pipe at twice the 16-bit rate (2 x 2 M N K flops at 5 PFLOP/s = one more 16-bit unit)
+    mfma_per_product = {'fp16x3': 3, 'fp16f8': 2}.get(dom_dt, 1)
+    cfg_name = GEMM_CFG_NAMES.get(dom, dom)
+    if dom_dt == 'fp16f8' and dom in (1, 2, 3):      # rocprofv3 symbol: gemm_kernel<4, GemmCfg<...,128,2,4>> (DMA pieces interleaved with the MFMA rows)
+        cfg_name = cfg_name.replace(',128,2>', ',128,2,4>')
+    traffic, tsrc = pmc_traffic_gb(dom, dom_dt)
+    out = {'roofline': {
+        'bound': 'mfma', 'kernel': f'd3r::gemm_kernel<{dom_dt}, {cfg_name}>',
+        'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
+        'achieved_executed_mfma': ach * mfma_per_product, 'frac_executed_mfma': ach * mfma_per_product / PEAK_BF16_TFLOPS,
+        'mfma_per_product': mfma_per_product,
+        'traffic': traffic, 'traffic_unit': 'GB per launch (HBM: 2 x FETCH_SIZE + WRITE_SIZE)', 'traffic_source': tsrc,
+        'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
+        'gflop_per_launch': d['gflop'] / d['launches'], 'share_of_step_time': d['ms'] / total_ms,
+        'note': 'achieved / frac = ALGORITHMIC flops (2 M N K per launch, SURVEY 8(d)) over the live HIP-event launch time, against the dense '
+                '16-bit MFMA peak; achieved_executed_mfma counts the MFMA time the mode actually issues in 16-bit-MFMA units per product '
+                '(fp16x3: 3 f16 MFMAs; fp16f8: 1 f16 MFMA + both cross terms on one e4m3 MFMA at twice the rate = 2 units); traffic is NOT '
+                're-measured by this command: it is carried from the committed rocprofv3 PMC digest named in traffic_source',
+        'timing': 'HIP events around every launch on the launch stream, single-stream schedule, one extra forward after the timed region'}}
+    kern = {f'gemm_kernel cfg{c}': dict(v, tflops=v['gflop'] / v['ms']) for c, v in prof['gemm_cfg'].items()}
+    kern.update({f'gemm_kernel<fp16f8> cfg{c}': dict(v, tflops=v['gflop'] / v['ms']) for c, v in prof['gemm_f8_cfg'].items()})
+    for k in ('attention', 'other'):
+        v = prof[k]
+        kern[k] = dict(v, tflops=(v['gflop'] / v['ms'] if v['ms'] > 0 else 0.0))
+    kern['all_gemm_linear'] = dict(prof['linear'], tflops=prof['linear']['gflop'] / max(prof['linear']['ms'], 1e-9))
+    kern['all_gemm_conv'] = dict(prof['conv'], tflops=prof['conv']['gflop'] / max(prof['conv']['ms'], 1e-9))
+    out['kernels'] = kern
+    out['launch_table'] = table[:24]
+    if not quiet:
+        log('[bench] per-kernel: ' + ', '.join(f"{k} {v['ms']:.1f} ms / {v['launches']} launches / {v['tflops']:.0f} TF/s" for k, v in kern.items()))
+    return out
 
 
 def bench_aligner(device, niter=300, n_views=20):
@@ -136,16 +202,16 @@ def bench_aligner(device, niter=300, n_views=20):
     ms = e0.elapsed_time(e1)
     bytes_iter = E * A * 32 + n * A * 4 * 6                    # preds + weights once, depth param/Adam r/w
     gbs = bytes_iter * niter / (ms * 1e-3) / 1e9
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')) as f:
-            traffic = json.load(f).get('aligner_main_kernel', {}).get('hbm_gb_per_launch')
-    except Exception:
-        pass
+    traffic, tsrc = None, None
+    for prec in ('fp16x3', None):
+        d, path = pmc_digest(prec)
+        if d and d.get('aligner_main_kernel', {}).get('hbm_gb_per_launch') is not None:
+            traffic, tsrc = d['aligner_main_kernel']['hbm_gb_per_launch'], path
+            break
     res = dict(metric='global_aligner_iters_per_sec', value=niter / (ms * 1e-3), unit='iters/s', n_views=n, n_edges=E, niter=niter,
                ms_total=ms, final_loss=loss,
                roofline=dict(bound='hbm', kernel='d3r::aligner_main_kernel (+ reduce + small kernels: whole iteration timed)', achieved=gbs,
-                             peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, bytes_per_iter=bytes_iter, traffic=traffic))
+                             peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, bytes_per_iter=bytes_iter, traffic=traffic, traffic_source=tsrc))
     return res, (out, init)
 
 
@@ -226,12 +292,12 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--pairs', type=int, default=32, help='image pairs per GPU per step (configs[1]: 32)')
-    ap.add_argument('--precision', default=os.environ.get('DUST3R_AMD_PRECISION', 'fp16f8'),
-                    help='engine precision of the HEADLINE: fp16f8 (default, the engine default) and fp16x3 meet the 1e-3 pointmap bar; bf16 / fp16 are reported under fast_mode')
+    ap.add_argument('--precision', default=os.environ.get('DUST3R_AMD_PRECISION', 'fp16x3'),
+                    help='engine precision of the HEADLINE: fp16x3 (default, the engine default: meets the 1e-3 per-pixel pointmap bar); fp16f8 / bf16 / fp16 are opt-in modes reported under fast_mode')
     ap.add_argument('--no-aligner', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
-    ap.add_argument('--no-fast', '--no-accurate', dest='no_fast', action='store_true', help='skip the fast_mode block (bf16 / fp16 single-pass throughput + their measured error)')
+    ap.add_argument('--no-fast', '--no-accurate', dest='no_fast', action='store_true', help='skip the fast_mode block (fp16f8 / bf16 / fp16 throughput + their measured error)')
     ap.add_argument('--single-stream', action='store_true', help='keep decoder side 2 / head 2 on the main stream (serialised kernels: use under rocprofv3 so that per-kernel durations are not inflated by overlap)')
     args = ap.parse_args()
 
@@ -242,13 +308,21 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     assert world == args.gpus or world == 1 and args.gpus == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # D3R_BENCH_ONE_DEVICE=1: every rank on cuda:0 (self-test of the N > 1 code path on a one-GPU box; RCCL refuses two ranks on one
+    # device, so pair it with D3R_BENCH_BACKEND=gloo -- the collective then stages through the host: NOT a measurement of anything)
+    one_device = os.environ.get('D3R_BENCH_ONE_DEVICE') == '1'
+    backend = os.environ.get('D3R_BENCH_BACKEND', 'nccl')
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     force_gather = os.environ.get('D3R_BENCH_FORCE_GATHER') == '1'     # exercise the collective path on one GPU (self-test)
     if world > 1 or force_gather:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dust3r_amd import _lib
     from dust3r_amd.parallel import all_gather_packed
@@ -314,7 +388,7 @@ def main():
         result = {
             'metric': 'image_pairs_per_sec_forward_512x384', 'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.precision, 'data': 'synthetic',
+            'dtype': args.precision, 'data': 'synthetic' + (' (SELF-TEST: all ranks on one device, backend ' + backend + ' -- not a scaling measurement)' if one_device and world > 1 else ''),
             'config': {'workload': f'{MODEL} AsymmetricCroCo3DStereo.forward, {B} synthetic 512x384 pairs per GPU per step (BASELINE configs[1]), '
                                    'random-init weights, inputs resident in HBM' + ('; pairs sharded over ranks + one all-gather of the pairwise predictions per step' if world > 1 else ''),
                        'pairs_per_gpu': B, 'global_pairs_per_step': world * B, 'parallelism': f'pair-sharded dp{world}'},
@@ -325,51 +399,11 @@ def main():
 
     # ---- live per-kernel timing (HIP events on the launch stream, outside the timed region) ---------------------
     if rank == 0 and not args.no_profile:
-        from dust3r_amd._lib import lib
-        lib.d3r_model_set_option(model._engine, 1, 1)
-        model(v1, v2)
-        torch.cuda.synchronize()
-        prof = read_profile(model)
-        table = read_launch_table(model)
-        lib.d3r_model_set_option(model._engine, 1, 0)
-        for r in table[:40]:
-            log(f"[bench]   {r['kernel']:12s} M={r['M']:8d} N={r['N']:5d} K={r['K']:5d}  x{r['launches']:3d}  {r['ms']:8.3f} ms  {r['tflops']:7.1f} TF/s")
-        if prof:
-            # dominant kernel = the gemm_kernel instantiation with the largest total time (one kernel symbol in rocprofv3)
-            cands = [('fp16x3' if args.precision == 'fp16f8' else args.precision, c, v) for c, v in prof['gemm_cfg'].items()]
-            cands += [('fp16f8', c, v) for c, v in prof['gemm_f8_cfg'].items()]
-            dom_dt, dom, d = max(cands, key=lambda t: t[2]['ms'])
-            total_ms = prof['linear']['ms'] + prof['conv']['ms'] + prof['attention']['ms'] + prof['other']['ms']
-            ach = d['gflop'] / d['ms']                              # GFLOP / ms == TFLOP/s (algorithmic: 2 M N K per launch)
-            # MFMA work per logical product in units of one 16-bit MFMA: split-fp16 issues three f16 MFMAs; fp16 + fp8 one f16 MFMA plus
-            # both cross terms on the fp8 pipe at twice the 16-bit rate (2 x 2 M N K flops at 5 PFLOP/s = one more 16-bit unit)
-            mfma_per_product = {'fp16x3': 3, 'fp16f8': 2}.get(dom_dt, 1)
-            cfg_name = GEMM_CFG_NAMES.get(dom, dom)
-            if dom_dt == 'fp16f8' and dom in (1, 2, 3):      # rocprofv3 symbol: gemm_kernel<4, GemmCfg<...,128,2,4>> (DMA pieces interleaved with the MFMA rows)
-                cfg_name = cfg_name.replace(',128,2>', ',128,2,4>')
-            result['roofline'] = {
-                'bound': 'mfma', 'kernel': f'd3r::gemm_kernel<{dom_dt}, {cfg_name}>',
-                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                'achieved_executed_mfma': ach * mfma_per_product, 'frac_executed_mfma': ach * mfma_per_product / PEAK_BF16_TFLOPS,
-                'mfma_per_product': mfma_per_product,
-                'traffic': pmc_traffic_gb(dom, dom_dt), 'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
-                'gflop_per_launch': d['gflop'] / d['launches'], 'share_of_step_time': d['ms'] / total_ms,
-                'note': 'achieved / frac = ALGORITHMIC flops (2 M N K per launch, SURVEY 8(d)) over the live HIP-event launch time, against the dense '
-                        '16-bit MFMA peak; achieved_executed_mfma counts the MFMA time the mode actually issues in 16-bit-MFMA units per product '
-                        '(fp16x3: 3 f16 MFMAs; fp16f8: 1 f16 MFMA + both cross terms on one e4m3 MFMA at twice the rate = 2 units)',
-                'timing': 'HIP events around every launch on the launch stream, single-stream schedule, one extra forward after the timed region'}
-            kern = {f'gemm_kernel cfg{c}': dict(v, tflops=v['gflop'] / v['ms']) for c, v in prof['gemm_cfg'].items()}
-            kern.update({f'gemm_kernel<fp16f8> cfg{c}': dict(v, tflops=v['gflop'] / v['ms']) for c, v in prof['gemm_f8_cfg'].items()})
-            for k in ('attention', 'other'):
-                v = prof[k]
-                kern[k] = dict(v, tflops=(v['gflop'] / v['ms'] if v['ms'] > 0 else 0.0))
-            kern['all_gemm_linear'] = dict(prof['linear'], tflops=prof['linear']['gflop'] / max(prof['linear']['ms'], 1e-9))
-            kern['all_gemm_conv'] = dict(prof['conv'], tflops=prof['conv']['gflop'] / max(prof['conv']['ms'], 1e-9))
-            result['kernels'] = kern
-            result['launch_table'] = table[:24]
-            log('[bench] per-kernel: ' + ', '.join(f"{k} {v['ms']:.1f} ms / {v['launches']} launches / {v['tflops']:.0f} TF/s" for k, v in kern.items()))
+        blk = profile_mode(model, v1, v2, args.precision)
+        if blk:
+            result.update(blk)
 
-    # ---- fast modes (single-pass 16-bit operands): NOT parity-grade, reported with their measured error ------------------
+    # ---- opt-in fast modes: NOT parity-grade, reported with their measured error and their own roofline block --------------
     # Error = per-pixel relative pointmap difference against the headline (parity-grade) engine on the same weights and the
     # same first two pairs of the batch; the headline mode itself is held to 1e-3 against the CPU oracle by tests/test_forward_gpu.py.
     if rank == 0 and world == 1 and not args.no_fast:
@@ -379,13 +413,13 @@ def main():
             w1, w2 = sub(v1, 2), sub(v2, 2)
             r1, r2 = model(w1, w2)
             ref = torch.cat((r1['pts3d'], r2['pts3d_in_other_view'])).clone()
-            for prec in [p for p in ('fp16x3', 'bf16', 'fp16') if p != args.precision]:
+            for prec in [p for p in ('fp16f8', 'fp16x3', 'bf16', 'fp16') if p != args.precision]:
                 model.set_precision(prec)
                 if args.single_stream:
                     model.set_two_streams(False)
                 e1, e2 = model(w1, w2)
                 got = torch.cat((e1['pts3d'], e2['pts3d_in_other_view']))
-                rel = ((got - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-12)).flatten()
+                rel = ((got - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-8)).flatten()
                 for _ in range(2):
                     model(v1, v2)
                 torch.cuda.synchronize()
@@ -397,14 +431,20 @@ def main():
                 dtf = (time.perf_counter() - t1) / nrep
                 fast[prec] = {'value': B / dtf, 'unit': 'pairs/s', 'ms_per_step': dtf * 1e3,
                               'frac_of_bf16_mfma_peak': B / dtf * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS,
-                              'rel_pointmap_err_vs_headline': {'max': float(rel.max()), 'p99': float(rel.kthvalue(int(0.99 * rel.numel())).values), 'mean': float(rel.mean())},
-                              'parity': 'parity-grade (22-bit operands everywhere: max 7e-5 vs the CPU oracle on the full-size model)' if prec == 'fp16x3' else 'NOT within the 1e-3 bar'}
-                log(f"[bench] fast mode {prec}: {B / dtf:.1f} pairs/s, rel err max {float(rel.max()):.2e} mean {float(rel.mean()):.2e}")
+                              'rel_pointmap_err_vs_headline': {'max': float(rel.max()), 'p99.99': float(rel.kthvalue(int(0.9999 * rel.numel())).values),
+                                                               'p99': float(rel.kthvalue(int(0.99 * rel.numel())).values), 'mean': float(rel.mean())},
+                              'parity': 'parity-grade (22-bit operands everywhere: max 7e-5 vs the CPU oracle on the full-size model)' if prec == 'fp16x3'
+                              else 'opt-in: NOT claimed to meet the 1e-3 per-pixel bar'}
+                if not args.no_profile and prec in ('fp16f8', 'fp16x3'):
+                    blk = profile_mode(model, v1, v2, prec, quiet=True)
+                    if blk:
+                        fast[prec]['roofline'] = blk['roofline']
+                log(f"[bench] mode {prec}: {B / dtf:.1f} pairs/s, rel err vs headline max {float(rel.max()):.2e} mean {float(rel.mean()):.2e}")
             model.set_precision(args.precision)
+            if args.single_stream:
+                model.set_two_streams(False)
         except Exception as e:
             fast['error'] = repr(e)
-        if 'fp16x3' in fast:      # the other parity-grade mode (22-bit operands everywhere), next to the headline
-            result['parity_mode_fp16x3'] = fast.pop('fp16x3')
         result['fast_mode'] = fast
 
     if world > 1:

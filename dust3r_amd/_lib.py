@@ -61,6 +61,7 @@ def _load():
         'd3r_model_feature_bytes': (C.c_size_t, [vp, i, i]),
         'd3r_model_encode': (i, [vp, fp, i, i, i, vp, vp]),
         'd3r_model_decode': (i, [vp, vp, i, i, i, fp, fp, fp, fp, vp]),
+        'd3r_model_decode_packed': (i, [vp, vp, i, i, i, fp, vp]),
         'd3r_model_debug_read': (i, [vp, i, fp, C.c_size_t, vp]),
         'd3r_model_set_option': (i, [vp, i, i]),
         'd3r_model_profile_read': (i, [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -185,8 +185,8 @@ def align_pose_sets(src, dst):
 
     def centres_and_axes(P):
         c = P[:, :3, 3]
-        d = np.linalg.norm(c[:, None] - c[None], axis=-1)
-        eps = np.median(d) / 100                     # geometry.get_med_dist_between_poses: median over the full distance matrix
+        d = np.linalg.norm(c[:, None] - c[None], axis=-1)[np.triu_indices(len(c), 1)]
+        eps = np.median(d) / 100                     # geometry.py:364-366 get_med_dist_between_poses: median of the CONDENSED pairwise distances (scipy pdist)
         return np.concatenate((c, c + eps * P[:, :3, 2]))
     x, y = centres_and_axes(src), centres_and_axes(dst)
     m = np.zeros(17)

@@ -697,7 +697,16 @@ struct d3r_aligner {
     bool reset_pending = false;   // D3R_ALIGNER_OPT_RESET_ADAM: cleared on the next run's stream
     bool generic_small = false;   // D3R_ALIGNER_OPT_GENERIC_SMALL
     int loss_cap = 0;
+    // create() enqueues its clear + re-layout on the caller's stream and returns without synchronising: a later call on a DIFFERENT
+    // stream first waits for this event (same stream: already ordered, no wait issued)
+    hipStream_t create_stream = nullptr;
+    hipEvent_t ev_ready = nullptr;
 };
+
+// orders `st` behind the work d3r_aligner_create left in flight on its own stream
+static void aligner_wait_ready(d3r_aligner* a, hipStream_t st) {
+    if (a->ev_ready && st != a->create_stream) (void)hipStreamWaitEvent(st, a->ev_ready, 0);
+}
 
 #define HIPCHK(x)                                  \
     do {                                           \
@@ -759,6 +768,10 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     a->state_bytes = fl * sizeof(float) + dbl * sizeof(double) + 64;
     if (hipMalloc((void**)&a->state, a->state_bytes) != hipSuccess) { delete a; return D3R_ERR_ALLOC; }
     hipStream_t st = (hipStream_t)stream;   // the clear and the re-layout below are ordered on the caller's stream, like every later call
+    // D3R_ALIGNER_POISON=1 (stress harness, tools/c4_stress.py): every allocation of the handle is filled with 0xFF bytes (fp32 / fp64 NaN,
+    // int -1) before its real initialisation, so that any read of a byte the create path failed to initialise shows up as NaN / a fault
+    static const bool poison = [] { const char* e = getenv("D3R_ALIGNER_POISON"); return e && e[0] == '1'; }();
+    if (poison && hipMemsetAsync(a->state, 0xFF, a->state_bytes, st) != hipSuccess) { (void)hipFree(a->state); delete a; return D3R_ERR_LAUNCH; }
     if (hipMemsetAsync(a->state, 0, a->state_bytes, st) != hipSuccess) { (void)hipFree(a->state); delete a; return D3R_ERR_LAUNCH; }
     float* b = a->state;
     a->depth_m = b + o_dm; a->depth_v = b + o_dv; a->pw_m = b + o_pwm; a->pw_v = b + o_pwv; a->imp_m = b + o_im;
@@ -770,6 +783,8 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     const size_t ib = (3 * (size_t)n_imgs + (n_imgs + 1) + 2 * (size_t)n_edges) * sizeof(int);
     if (hipMalloc((void**)&a->d_w, ib) != hipSuccess) { (void)hipFree(a->state); delete a; return D3R_ERR_ALLOC; }
     a->d_h = a->d_w + n_imgs; a->d_area = a->d_h + n_imgs; a->d_adj_off = a->d_area + n_imgs; a->d_adj_es = a->d_adj_off + n_imgs + 1;
+    if (poison) { (void)hipMemsetAsync(a->d_w, 0xFF, ib, st); (void)hipStreamSynchronize(st); }
+    // blocking copies (pageable host vectors): complete in device memory when they return, whatever stream the caller works on
     (void)hipMemcpy(a->d_w, a->h_w.data(), n_imgs * sizeof(int), hipMemcpyHostToDevice);
     (void)hipMemcpy(a->d_h, a->h_h.data(), n_imgs * sizeof(int), hipMemcpyHostToDevice);
     (void)hipMemcpy(a->d_area, a->h_area.data(), n_imgs * sizeof(int), hipMemcpyHostToDevice);
@@ -779,17 +794,22 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
         const size_t npix = (size_t)n_edges * max_area;
         if (hipMalloc((void**)&a->planar, 2 * npix * 3 * sizeof(float)) != hipSuccess) { (void)hipFree(a->state); (void)hipFree(a->d_w); delete a; return D3R_ERR_ALLOC; }
         const int grid = (int)((npix + 255) / 256 < 65536 ? (npix + 255) / 256 : 65536);
+        if (poison) (void)hipMemsetAsync(a->planar, 0xFF, 2 * npix * 3 * sizeof(float), st);
         hipLaunchKernelGGL(aligner_planarize_kernel, dim3(grid), dim3(256), 0, st, pred_i, a->planar, npix, max_area);
         hipLaunchKernelGGL(aligner_planarize_kernel, dim3(grid), dim3(256), 0, st, pred_j, a->planar + npix * 3, npix, max_area);
         if (hipGetLastError() != hipSuccess) { (void)hipFree(a->planar); (void)hipFree(a->state); (void)hipFree(a->d_w); delete a; return D3R_ERR_LAUNCH; }
         a->pred[0] = a->planar; a->pred[1] = a->planar + npix * 3;
     }
+    a->create_stream = st;
+    if (hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(a->ev_ready, st);
+    else a->ev_ready = nullptr;
     *out = a;
     return D3R_OK;
 }
 
 extern "C" int d3r_aligner_destroy(d3r_aligner* a) {
     if (!a) return D3R_OK;
+    if (a->ev_ready) (void)hipEventDestroy(a->ev_ready);
     (void)hipFree(a->planar);
     (void)hipFree(a->state);
     (void)hipFree(a->d_w);
@@ -873,6 +893,7 @@ extern "C" int d3r_aligner_run(d3r_aligner* a, int niter, int iter0, int niter_t
                                float* losses_out_device, void* stream) {
     if (!a || niter <= 0 || niter > a->loss_cap || niter_total <= 0) return D3R_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    aligner_wait_ready(a, st);
     if (a->reset_pending) {
         HIPCHK(hipMemsetAsync(a->depth_m, 0, (size_t)((char*)a->d_edge - (char*)a->depth_m), st));
         a->reset_pending = false;
@@ -893,6 +914,7 @@ extern "C" int d3r_aligner_loss_grad(d3r_aligner* a, float* loss_device, float* 
                                      float* g_im_focals, float* g_im_pp, float* g_pw_adaptors, void* stream) {
     if (!a) return D3R_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    aligner_wait_ready(a, st);
     float* gpw = g_pw_poses ? g_pw_poses : a->g_scratch;  // forces the gradient branch of the small kernel
     const int rc = aligner_pass(a, false, 0.0, 0, gpw, g_im_poses, g_im_depth, g_im_focals, true, st, g_im_pp, g_pw_adaptors);
     if (rc != D3R_OK) return rc;

@@ -872,3 +872,11 @@ extern "C" int d3r_model_decode(d3r_model* m, const void* feat, int B, int H, in
     if (!m || !feat || B <= 0 || !pts1 || !conf1 || !pts2 || !conf2) return D3R_ERR_INVALID;
     return run_phases(m, PH_DECODE, nullptr, nullptr, 0, 0, const_cast<void*>(feat), B, H, W, H, W, pts1, conf1, pts2, conf2, (hipStream_t)stream);
 }
+
+extern "C" int d3r_model_decode_packed(d3r_model* m, const void* feat, int B, int H, int W, float* out8, void* stream) {
+    if (!m || !feat || B <= 0 || !out8) return D3R_ERR_INVALID;
+    m->out_pstride = 8; m->out_cstride = 8;
+    const int rc = run_phases(m, PH_DECODE, nullptr, nullptr, 0, 0, const_cast<void*>(feat), B, H, W, H, W, out8, out8 + 3, out8 + 4, out8 + 7, (hipStream_t)stream);
+    m->out_pstride = 3; m->out_cstride = 1;
+    return rc;
+}

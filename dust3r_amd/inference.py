@@ -43,9 +43,13 @@ def loss_of_one_batch(batch, model, criterion, device, symmetrize_batch=False, u
     return result[ret] if ret else result
 
 
-def _engine_step(model, batch_size):
-    """Pairs per model call. The reference runs `batch_size` pairs per call; an engine that declares `engine_batch` gets at least that
-    many (its results do not depend on how the pair list is cut into batches: bit-identical, tests/test_forward_gpu.py)."""
+def _engine_step(model, batch_size, engine_batch=None):
+    """Pairs per model call. The reference runs `batch_size` pairs per call; an engine that declares `engine_batch` (default 32, or
+    DUST3R_AMD_ENGINE_BATCH) gets at least that many -- the demo names 1, which is launch-bound on a GPU -- because its results do not
+    depend on how the pair list is cut into batches (bit-identical, tests/test_forward_gpu.py). A caller who needs SMALLER calls (larger
+    images, less free HBM: the workspace grows with the batch) passes `engine_batch=n` to inference(): exactly n pairs per call."""
+    if engine_batch is not None:
+        return max(int(engine_batch), 1)
     return max(int(batch_size), int(getattr(model, 'engine_batch', 0) or 0), 1)
 
 
@@ -104,6 +108,7 @@ class _PredictionSink:
         self.pred1, self.pred2 = outputs if outputs is not None else _alloc_outputs(n_pairs, H, W, out_device)
         self.out = dict(pred1=self.pred1, pred2=self.pred2)
         self.host = torch.device(out_device).type == 'cpu' and torch.device(compute_device).type == 'cuda'
+        self.compute_device = torch.device(compute_device)
         self.stash = None
         if self.host:
             self.stream = torch.cuda.Stream(device=compute_device)
@@ -127,7 +132,7 @@ class _PredictionSink:
                 self.out[a][b][i:j].copy_(t, non_blocking=True)
             return
         ev = torch.cuda.Event()
-        ev.record()                                     # batch (i, j) is enqueued; now move the PREVIOUS batch while it runs
+        ev.record(torch.cuda.current_stream(self.compute_device))   # on the COMPUTE device's stream (not the process' current device): batch (i, j) is enqueued; now move the PREVIOUS batch while it runs
         prev, self.stash = self.stash, None
         if prev is not None:
             self.stash = prev
@@ -138,8 +143,8 @@ class _PredictionSink:
         if self.host:
             self._flush()
             self.stream.synchronize()
-        elif torch.cuda.is_available():
-            torch.cuda.synchronize()
+        elif self.compute_device.type == 'cuda':
+            torch.cuda.synchronize(self.compute_device)
         return self.pred1, self.pred2
 
 
@@ -166,8 +171,14 @@ def _collate_views(pairs, shared=None, device_stack=None):
     light = [tuple({k: v for k, v in view.items() if k != 'img'} for view in p) for p in pairs]
     view1, view2 = collate_with_cat(light)
     dev = device_stack.device
-    view1['img'] = device_stack.index_select(0, torch.tensor(shared[1], device=dev)).cpu()
-    view2['img'] = device_stack.index_select(0, torch.tensor(shared[2], device=dev)).cpu()
+
+    def gather(index, chunk=128):      # in chunks: 2 x len(pairs) whole images never sit in HBM at once (2.8 GB for 600 pairs at 512x384)
+        out = torch.empty((len(index),) + tuple(device_stack.shape[1:]), dtype=device_stack.dtype)
+        idx = torch.tensor(index, device=dev)
+        for i in range(0, len(index), chunk):
+            out[i:i + chunk].copy_(device_stack.index_select(0, idx[i:i + chunk]))
+        return out
+    view1['img'], view2['img'] = gather(shared[1]), gather(shared[2])
     return view1, view2
 
 
@@ -194,7 +205,7 @@ class _Background:
 
 
 @torch.no_grad()
-def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, output_device='cpu'):
+def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, output_device='cpu', engine_batch=None):
     """Same return value as `inference` (bit-identical: every engine kernel is batch-position independent), but every distinct
     image goes through the ViT-L encoder ONCE: n encoder passes instead of 2 x len(pairs) -- 20 instead of 380 for the demo's
     complete symmetrised graph over 20 views, i.e. ~53 % fewer FLOPs end to end. Predictions stream to the host
@@ -212,7 +223,7 @@ def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, outp
     outputs = _Background(lambda: tuple({k: torch.zeros_like(t) for k, t in d.items()} for d in _alloc_outputs(len(pairs), H, W, output_device))
                           if host_out else _alloc_outputs(len(pairs), H, W, output_device))
     feats, dev_imgs = [], []
-    batch_size = _engine_step(model, batch_size)
+    batch_size = _engine_step(model, batch_size, engine_batch)
     enc_bs = max(2, 2 * batch_size)
     for i in tqdm.trange(0, len(order), enc_bs, disable=not verbose, desc='encode'):
         dev_imgs.append(torch.cat([imgs[k] for k in order[i:i + enc_bs]], dim=0).to(device, non_blocking=True))
@@ -231,22 +242,25 @@ def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, outp
 
 
 @torch.no_grad()
-def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None, output_device='cpu'):
+def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None, output_device='cpu', engine_batch=None):
     """Mirror of dust3r/inference.py:55-72. Extras (defaults keep the reference's behaviour): `encode_once` (None = automatic:
-    encode every distinct image once when the pair list shares images) and `output_device` ('cpu' like the reference's
-    to_cpu; a CUDA device keeps the predictions in HBM for `global_aligner(output, device)`, which would upload them again)."""
+    encode every distinct image once when the pair list shares images), `output_device` ('cpu' like the reference's
+    to_cpu; a CUDA device keeps the predictions in HBM for `global_aligner(output, device)`, which would upload them again) and
+    `engine_batch`. `batch_size` is a LOWER bound on the pairs per engine call: the engine takes `model.engine_batch` pairs (32;
+    DUST3R_AMD_ENGINE_BATCH) whatever smaller value the caller names, with bit-identical results; `engine_batch=n` pins the call size
+    to exactly n pairs (use it to bound the workspace: ~0.8 GB per 512x384 pair in fp16x3)."""
     if verbose:
         print(f'>> Inference with model on {len(pairs)} image pairs')
     multiple_shapes = not check_if_same_size(pairs)
     if encode_once is None:
         encode_once = True
     if encode_once and not multiple_shapes and _encode_once_ok(pairs, model):
-        return inference_encode_once(pairs, model, device, batch_size=batch_size, verbose=verbose, output_device=output_device)
+        return inference_encode_once(pairs, model, device, batch_size=batch_size, verbose=verbose, output_device=output_device, engine_batch=engine_batch)
     if multiple_shapes:
         # dust3r/inference.py:60-68 falls back to one pair per call. Here the pairs are grouped by their (view 1, view 2) image sizes,
         # every group runs `engine_batch` pairs per call, and the per-pair rows go back to their positions in the list: same structure
         # (lists, one entry per pair), bit-identical values.
-        step = int(getattr(model, 'engine_batch', 0) or 0) or 1
+        step = _engine_step(model, 1, engine_batch)
         groups = {}
         for k, (v1, v2) in enumerate(pairs):
             groups.setdefault((tuple(v1['img'].shape[-2:]), tuple(v2['img'].shape[-2:])), []).append(k)
@@ -263,7 +277,7 @@ def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None
         bar.close()
         return collate_with_cat(result, lists=True)
     H, W = pairs[0][0]['img'].shape[-2:]
-    batch_size = _engine_step(model, batch_size)
+    batch_size = _engine_step(model, batch_size, engine_batch)
     on_gpu = torch.device(device).type == 'cuda'
     shared = _shared_images(pairs) if on_gpu else None
     sink = _PredictionSink(len(pairs), H, W, output_device, device)

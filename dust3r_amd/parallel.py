@@ -8,7 +8,9 @@ are collected with a single `all_gather_into_tensor` -- RCCL over xGMI on the GP
 (backend "nccl"), gloo in the CPU tests. Every rank ends up with the dict that single-device
 `inference()` returns, ready for `global_aligner` (which BASELINE.json runs on one GPU).
 
-Nothing here depends on the device type: the gloo tests drive the same code with a stand-in model.
+Every rank encodes only the distinct images its own shard touches (encode-once, like single-device `inference()`), and pair lists of
+several image sizes shard too (flat padded payload). Nothing here depends on the device type: the gloo tests drive the same code with
+a stand-in model.
 """
 import torch
 import torch.distributed as dist
@@ -43,36 +45,124 @@ def all_gather_packed(local, group=None, async_op=False, out=None):
     return (out, work) if async_op else out
 
 
-@torch.no_grad()
-def inference_sharded(pairs, model, device, batch_size=8, verbose=False, group=None, gather_device=None):
-    """Drop-in for `inference(pairs, model, device, batch_size)` when torch.distributed is initialised:
-    identical return value on every rank. Requires all pairs to share one image size (the sharded
-    path is the throughput path; mixed sizes go through `inference`)."""
-    from .inference import _engine_step, check_if_same_size, loss_of_one_batch
-    assert check_if_same_size(pairs), 'inference_sharded needs pairs of one image size'
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    lo, hi, per = shard_bounds(len(pairs), rank, world)
-    batch_size = _engine_step(model, batch_size)     # at least the engine's preferred pairs per call (bit-identical results)
-    gather_device = torch.device(gather_device if gather_device is not None else device)
-    H, W = pairs[0][0]['img'].shape[-2:]
+def _pair_shapes(pairs):
+    return [(tuple(int(x) for x in a['img'].shape[-2:]), tuple(int(x) for x in b['img'].shape[-2:])) for a, b in pairs]
+
+
+def _flat_len(hw1, hw2):
+    """floats of one pair's predictions in the flat payload [pts1 (A1 x 3) | conf1 (A1) | pts2 (A2 x 3) | conf2 (A2)]"""
+    return 4 * (hw1[0] * hw1[1] + hw2[0] * hw2[1])
+
+
+def _flatten_rows(pred1, pred2, n):
+    """(n, H1, W1, 3), (n, H1, W1), (n, H2, W2, 3), (n, H2, W2) -> (n, 4 (A1 + A2)) in the flat payload order."""
+    return torch.cat((pred1['pts3d'].reshape(n, -1), pred1['conf'].reshape(n, -1), pred2['pts3d_in_other_view'].reshape(n, -1),
+                      pred2['conf'].reshape(n, -1)), dim=1)
+
+
+def _unflatten_row(row, hw1, hw2):
+    a1, a2 = hw1[0] * hw1[1], hw2[0] * hw2[1]
+    o = [0, 3 * a1, 4 * a1, 4 * a1 + 3 * a2, 4 * (a1 + a2)]
+    return (dict(pts3d=row[o[0]:o[1]].reshape(1, *hw1, 3).clone(), conf=row[o[1]:o[2]].reshape(1, *hw1).clone()),
+            dict(pts3d_in_other_view=row[o[2]:o[3]].reshape(1, *hw2, 3).clone(), conf=row[o[3]:o[4]].reshape(1, *hw2).clone()))
+
+
+def _local_same_size(pairs, lo, hi, per, model, device, batch_size, gather_device, encode_once, H, W):
+    """This rank's shard of a one-size pair list -> (per, H, W, 8) packed payload (zero in the padding slots)."""
+    from .inference import _encode_once_ok, loss_of_one_batch
     local = torch.zeros((per, H, W, 8), dtype=torch.float32, device=gather_device)
-    for i in range(lo, hi, batch_size):
-        batch = collate_with_cat(pairs[i:min(i + batch_size, hi)])
+    shard = pairs[lo:hi]
+    if not shard:
+        return local
+    if encode_once and _encode_once_ok(shard, model):
+        # every DISTINCT image of the shard goes through the encoder once (contiguous slices of make_pairs' list share images: the
+        # complete graph over 20 views cut in 8 touches 4-9 images per rank instead of 2 x 24 pair slots), then the shard's pairs are decoded
+        imgs, order = {}, []
+        for v1, v2 in shard:
+            for v in (v1, v2):
+                k = int(v['idx'])
+                if k not in imgs:
+                    imgs[k] = v['img']
+                    order.append(k)
+        pos = {k: i for i, k in enumerate(order)}
+        enc_bs = max(2, 2 * batch_size)
+        feats = torch.cat([model.encode_images(torch.cat([imgs[k] for k in order[i:i + enc_bs]], dim=0).to(device)) for i in range(0, len(order), enc_bs)], dim=0)
+        i1 = torch.tensor([pos[int(a['idx'])] for a, _ in shard], device=feats.device)
+        i2 = torch.tensor([pos[int(b['idx'])] for _, b in shard], device=feats.device)
+        for i in range(0, len(shard), batch_size):
+            j = min(i + batch_size, len(shard))
+            f = feats.index_select(0, torch.cat((i1[i:j], i2[i:j])))
+            if local.is_cuda and local.device == feats.device:
+                model.decode_pairs(f, H, W, packed_out=local[i:j])           # the heads write the payload in place
+            else:
+                p1, p2 = model.decode_pairs(f, H, W)
+                local[i:j] = pack_predictions(p1, p2).to(gather_device)
+        return local
+    for i in range(0, len(shard), batch_size):
+        batch = collate_with_cat(shard[i:i + batch_size])
         n = batch[0]['img'].shape[0]
         if hasattr(model, 'forward_packed') and local.is_cuda:
             # the engine's heads write the interleaved payload in place: no pack pass
-            model.forward_packed(dict(img=batch[0]['img'].to(device)), dict(img=batch[1]['img'].to(device)), out=local[i - lo:i - lo + n])
+            model.forward_packed(dict(img=batch[0]['img'].to(device)), dict(img=batch[1]['img'].to(device)), out=local[i:i + n])
         else:
             res = loss_of_one_batch(batch, model, None, device)
-            local[i - lo:i - lo + n] = pack_predictions(res['pred1'], res['pred2']).to(gather_device)
-    gathered = all_gather_packed(local, group)
-    # drop the padding slots of the short last shards
-    keep = torch.cat([torch.arange(r * per, r * per + (shard_bounds(len(pairs), r, world)[1] - shard_bounds(len(pairs), r, world)[0]))
-                      for r in range(world)]).to(gathered.device)
-    pred1, pred2 = unpack_predictions(gathered.index_select(0, keep).cpu())
-    # view metadata is rebuilt deterministically on every rank (host side), as SURVEY.md 8(e) prescribes
-    view1 = collate_with_cat([(p[0], p[1]) for p in pairs])[0]
-    view2 = collate_with_cat([(p[0], p[1]) for p in pairs])[1]
-    view1 = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in view1.items()}
-    view2 = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in view2.items()}
-    return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)
+            local[i:i + n] = pack_predictions(res['pred1'], res['pred2']).to(gather_device)
+    return local
+
+
+def _local_mixed(pairs, shapes, lo, hi, per, slot, model, device, batch_size, gather_device):
+    """This rank's shard of a pair list with SEVERAL image sizes -> (per, slot) flat payload: the shard's pairs are grouped by their two
+    image sizes and every group is batched (dust3r_amd.inference does the same on one device); slot = the longest pair of the WHOLE list."""
+    from .inference import loss_of_one_batch
+    local = torch.zeros((per, slot), dtype=torch.float32, device=gather_device)
+    groups = {}
+    for k in range(lo, hi):
+        groups.setdefault(shapes[k], []).append(k)
+    for (hw1, hw2), members in groups.items():
+        L = _flat_len(hw1, hw2)
+        for i in range(0, len(members), batch_size):
+            chunk = members[i:i + batch_size]
+            res = loss_of_one_batch(collate_with_cat([pairs[k] for k in chunk]), model, None, device)
+            rows = _flatten_rows(res['pred1'], res['pred2'], len(chunk)).to(gather_device)
+            local[torch.tensor([k - lo for k in chunk], device=gather_device), :L] = rows
+    return local
+
+
+@torch.no_grad()
+def inference_sharded(pairs, model, device, batch_size=8, verbose=False, group=None, gather_device=None, encode_once=None, engine_batch=None):
+    """Drop-in for `inference(pairs, model, device, batch_size)` when torch.distributed is initialised: identical return value on
+    every rank (bit-identical to the single-process call: every engine kernel is batch-position independent). Rank r runs a contiguous
+    slice of the pair list; the predictions travel in ONE all_gather_into_tensor.
+      * one image size: the payload is the engine's packed (pairs, H, W, 8) tensor, written in place by the head epilogues; with
+        `encode_once` (None = automatic, like inference()) a rank encodes every distinct image of ITS shard once and decodes its pairs;
+      * several image sizes (a portrait picture among landscape ones, dust3r/inference.py:60-68): pairs are grouped by shape inside
+        the shard and the payload is one flat fp32 row per pair, padded to the longest pair of the list -- still one collective; the
+        result has the reference's list-per-pair structure, exactly as `inference()` returns it for such a list."""
+    from .inference import _engine_step, check_if_same_size
+    from .utils.device import to_cpu
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi, per = shard_bounds(len(pairs), rank, world)
+    batch_size = _engine_step(model, batch_size, engine_batch)     # at least the engine's preferred pairs per call (bit-identical results)
+    gather_device = torch.device(gather_device if gather_device is not None else device)
+    counts = [shard_bounds(len(pairs), r, world)[1] - shard_bounds(len(pairs), r, world)[0] for r in range(world)]
+    keep = torch.cat([torch.arange(r * per, r * per + counts[r]) for r in range(world)])      # drops the padding slots of the short last shards
+    if check_if_same_size(pairs):
+        H, W = pairs[0][0]['img'].shape[-2:]
+        local = _local_same_size(pairs, lo, hi, per, model, device, batch_size, gather_device, encode_once is None or bool(encode_once), H, W)
+        gathered = all_gather_packed(local, group)
+        pred1, pred2 = unpack_predictions(gathered.index_select(0, keep.to(gathered.device)).cpu())
+        # view metadata is rebuilt deterministically on every rank (host side), as SURVEY.md 8(e) prescribes
+        view1, view2 = collate_with_cat([(p[0], p[1]) for p in pairs])
+        view1 = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in view1.items()}
+        view2 = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in view2.items()}
+        return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)
+    shapes = _pair_shapes(pairs)
+    slot = max(_flat_len(*s) for s in shapes)
+    local = _local_mixed(pairs, shapes, lo, hi, per, slot, model, device, batch_size, gather_device)
+    gathered = all_gather_packed(local, group).index_select(0, keep.to(gather_device)).cpu()
+    result = []
+    for k, (a, b) in enumerate(pairs):
+        v1, v2 = to_cpu(collate_with_cat([(a, b)]))
+        p1, p2 = _unflatten_row(gathered[k], *shapes[k])
+        result.append(dict(view1=v1, view2=v2, pred1=p1, pred2=p2, loss=None))
+    return collate_with_cat(result, lists=True)

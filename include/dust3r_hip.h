@@ -150,6 +150,9 @@ size_t d3r_model_feature_bytes(const d3r_model* m, int H, int W);
 int d3r_model_encode(d3r_model* m, const float* img, int n, int H, int W, void* feat_out, void* stream);
 int d3r_model_decode(d3r_model* m, const void* feat, int B, int H, int W, float* pts1, float* conf1, float* pts2, float* conf2,
                      void* stream);
+/* d3r_model_decode with the outputs interleaved per pixel like d3r_model_forward_packed: out8 fp32 [B][H][W][8]. This is what a rank of
+ * the pair-sharded path runs on its shard after encoding the distinct images of that shard once (dust3r_amd/parallel.py). */
+int d3r_model_decode_packed(d3r_model* m, const void* feat, int B, int H, int W, float* out8, void* stream);
 /* bytes of device memory currently held (weights + workspace) */
 size_t d3r_model_device_bytes(const d3r_model* m);
 /* Measurement hook (bench.py): with D3R_MODEL_OPT_PROFILE = 1 the next forwards record one HIP event before every
@@ -186,7 +189,8 @@ int d3r_model_debug_read(d3r_model* m, int what, float* out_f32, size_t max_elem
  * (zero in padding), fp32. ei/ej/img_h/img_w are HOST arrays. Alignment: pw_poses, im_depthmaps, pred_*, w_* 16 bytes, pw_adaptors 8
  * (D3R_ERR_INVALID otherwise; any torch allocation satisfies it). create enqueues its one-off work (clearing the Adam state, the planar
  * copy of pred_*) on `stream` and does not synchronise the device: pred_* must be complete on that stream, and may be freed once it has
- * drained; run / loss_grad on the same stream need no further ordering.
+ * drained; run / loss_grad on the same stream need no further ordering, and on ANOTHER stream they first wait for an event the create
+ * call recorded behind its work (no caller-side synchronisation either way).
  */
 typedef struct d3r_aligner d3r_aligner;
 #define D3R_SCHEDULE_COSINE 0

@@ -1,0 +1,49 @@
+"""Worker of the two-ranks-on-one-GPU test (tests/test_forward_gpu.py): one process per rank, BOTH on cuda:0, the real engine, gloo with CUDA
+tensors as the transport (RCCL refuses two ranks on one device; its code path is covered at world size 1 on the same engine)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def scene_pairs(kind):
+    import torch
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.synthetic import synthetic_image_list
+    if kind == 'same':       # 5 views, complete symmetrised graph: 20 pairs sharing 5 images (the encode-once route)
+        return make_pairs(synthetic_image_list(5, 32, 48, seed=8), 'complete', None, symmetrize=True)
+    g = torch.Generator().manual_seed(4)
+    shapes = [(32, 48), (48, 32), (32, 48), (32, 32), (48, 32)]
+    imgs = [dict(img=torch.rand((1, 3, h, w), generator=g) * 2 - 1, true_shape=torch.tensor([[h, w]], dtype=torch.int32), idx=k, instance=str(k))
+            for k, (h, w) in enumerate(shapes)]
+    return [(imgs[i], imgs[j]) for i in range(len(imgs)) for j in range(len(imgs)) if i != j]
+
+
+def build_engine(gpu):
+    from dust3r_amd.model import AsymmetricCroCo3DStereo
+    from dust3r_amd.synthetic import MODEL_CONFIGS
+    from oracle.dust3r_ref import build_ref_model
+    m = AsymmetricCroCo3DStereo(precision='fp16x3', landscape_only=False, **MODEL_CONFIGS['tiny_dpt'])
+    m.load_state_dict(build_ref_model('tiny_dpt').state_dict(), strict=True)
+    return m.to(gpu)
+
+
+def worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    gpu = torch.device('cuda', 0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from dust3r_amd.parallel import inference_sharded
+        eng = build_engine(gpu)
+        out = {}
+        for kind in ('same', 'mixed'):
+            out[kind] = inference_sharded(scene_pairs(kind), eng, gpu, batch_size=4)
+        torch.save(out, os.path.join(outdir, f'rank{rank}.pt'))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()

@@ -31,7 +31,7 @@ def _engine(gpu):
     from dust3r_amd.synthetic import MODEL_CONFIGS
     from oracle.dust3r_ref import build_ref_model
     m = AsymmetricCroCo3DStereo(landscape_only=False, **MODEL_CONFIGS['tiny_dpt'])        # default precision = the parity-grade mode
-    assert m.precision == 'fp16f8'
+    assert m.precision == 'fp16x3'
     m.load_state_dict(build_ref_model('tiny_dpt').state_dict())
     return m.to(gpu)
 

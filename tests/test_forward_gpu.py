@@ -1,12 +1,12 @@
 """GPU parity of the model engine (C ABI d3r_model_forward through dust3r_amd.model) against the CPU
 fp32 oracle and the golden vectors generated from the reference.
 
-Tolerances (per-pixel relative pointmap error |d| / |ref|):
+Tolerances. The error measure is SURVEY.md 8(d)'s: per pixel, ||pts_hip - pts_ref||_2 / max(||pts_ref||_2, eps) with ONE eps for
+every mode and test: eps = 1e-8, i.e. no floor -- the strict per-pixel ratio.
   fp32 mode : max  <= 1e-3  -- the north-star bar; the engine's fp32-MFMA path is held to it strictly
-  fp16x3    : max  <= 1e-3  -- split-fp16 MFMA mode (3 f16 MFMAs per product, 22-bit operands): held to the same bar
-  fp16/bf16 : mean <= 8e-3 / 5e-2 on the tiny configs -- 16-bit operand rounding through the depth,
-              measured and reported (DESIGN.md "precision modes"); the bar there is the rounding floor of the
-              same network evaluated by PyTorch with operands rounded to the same type (tools/precision_probe.py)
+  fp16x3    : max  <= 1e-3  -- THE DEFAULT ENGINE (3 f16 MFMAs per product, 22-bit operands): held to the same bar, same assertions
+  fp16f8 / fp16 / bf16 : opt-in fast modes, NOT claimed to meet the bar: bounded at their measured rounding floor (99th percentile
+              and mean; the per-pixel max is heavy-tailed at pixels whose pointmap norm is near zero) and reported in DESIGN.md
 """
 import os
 
@@ -39,17 +39,13 @@ def engine_from_oracle(oracle, config, precision, gpu):
     return m.to(gpu)
 
 
-# precision -> (bound on the max, bound on the mean, which statistic "max" is taken over)
-#   fp32 / fp16x3: the north-star bar, max over ALL pixels <= 1e-3
-#   fp16f8       : (the default engine: the transformer blocks' linears on fp16 + fp8 operand rows -- hi.hi on the f16 MFMA, both cross
-#                  terms on one e4m3 MFMA --, everything else fp16x3) held to max <= 1e-3 on the BASELINE model
-#                  (test_full_size_fp32_pair_matches_oracle: measured 3.3e-4). On these tiny random networks, whose pointmaps pass
-#                  close to the origin, the same per-operand error (~2^-16) shows a heavier tail: mean 3-4e-5, 99th percentile 1-2e-4,
-#                  max up to 1.8e-3 at a handful of pixels (fp16x3: 8e-5 at the same pixels) -- bounded here at max 3e-3, mean 2e-4
+# precision -> (bound on the statistic, bound on the mean, which statistic: 'max' over ALL pixels or the 99th percentile)
+#   fp32 / fp16x3: the north-star bar, max over ALL pixels <= 1e-3 (fp16x3 is the default engine)
+#   fp16f8       : opt-in (the transformer blocks' cross terms on the e4m3 MFMA, ~2^-16 per operand): 99th percentile <= 1e-3, mean <= 2e-4
+#                  (measured p99 1-2e-4, mean 3-4e-5, per-pixel max up to 1.8e-3 on these tiny networks -- which is why it is NOT the default)
 #   fp16 / bf16  : single-pass 16-bit operands cannot meet 1e-3 (unit roundoff 4.9e-4 / 3.9e-3 per operand, 36 blocks deep,
 #                  expm1 at the end); they are bounded at the rounding floor of the network instead: mean and 99th percentile
-#                  (the per-pixel max is heavy-tailed at pixels whose pointmap norm is near zero) and reported in DESIGN.md
-TOLS = {'fp32': (1e-3, 2e-4, 'max'), 'fp16x3': (1e-3, 2e-4, 'max'), 'fp16f8': (3e-3, 2e-4, 'max'), 'fp16': (5e-2, 8e-3, 'p99'), 'bf16': (3e-1, 5e-2, 'p99')}
+TOLS = {'fp32': (1e-3, 2e-4, 'max'), 'fp16x3': (1e-3, 2e-4, 'max'), 'fp16f8': (1e-3, 2e-4, 'p99'), 'fp16': (5e-2, 8e-3, 'p99'), 'bf16': (3e-1, 5e-2, 'p99')}
 
 
 def compare(engine, oracle, v1, v2, max_tol, mean_tol, stat='max', tag=''):
@@ -238,15 +234,18 @@ def test_inference_batching_is_output_identical(gpu):
         for eb in (1, 5):
             eng.engine_batch = eb
             outs.append(inference(pairs, eng, gpu, batch_size=1, verbose=False, encode_once=False))
-        a, b = outs
-        for view, keys in (('pred1', ('pts3d', 'conf')), ('pred2', ('pts3d_in_other_view', 'conf'))):
-            for k in keys:
-                xa, xb = a[view][k], b[view][k]
-                if isinstance(xa, list):
-                    assert len(xa) == len(xb) == len(pairs) and all(torch.equal(p, q) for p, q in zip(xa, xb)), (view, k)
-                else:
-                    assert torch.equal(xa, xb), (view, k)
-        assert a['view1']['idx'] == b['view1']['idx'] and a['view2']['instance'] == b['view2']['instance']
+        eng.engine_batch = 32
+        outs.append(inference(pairs, eng, gpu, batch_size=8, verbose=False, encode_once=False, engine_batch=2))   # the caller pins a SMALLER call size
+        a = outs[0]
+        for b in outs[1:]:
+            for view, keys in (('pred1', ('pts3d', 'conf')), ('pred2', ('pts3d_in_other_view', 'conf'))):
+                for k in keys:
+                    xa, xb = a[view][k], b[view][k]
+                    if isinstance(xa, list):
+                        assert len(xa) == len(xb) == len(pairs) and all(torch.equal(p, q) for p, q in zip(xa, xb)), (view, k)
+                    else:
+                        assert torch.equal(xa, xb), (view, k)
+            assert a['view1']['idx'] == b['view1']['idx'] and a['view2']['instance'] == b['view2']['instance']
 
 
 def test_full_size_fp32_pair_matches_oracle(gpu):
@@ -259,13 +258,17 @@ def test_full_size_fp32_pair_matches_oracle(gpu):
     v1, v2 = synthetic_views(1, 384, 512, seed=0)
     with torch.no_grad():
         r1, r2 = oracle(v1, v2)
-    for prec in ('fp32', 'fp16x3', 'fp16f8'):   # the modes held to the north-star bar (1e-3 relative on pointmaps)
+    for prec in ('fp32', 'fp16x3', 'fp16f8'):   # fp32 and fp16x3 (the default) are held to the north-star bar: per-pixel max <= 1e-3
         eng.set_precision(prec)
         e1, e2 = eng(v1, v2)
         for name, a, b in (('pts1', e1['pts3d'], r1['pts3d']), ('pts2', e2['pts3d_in_other_view'], r2['pts3d_in_other_view'])):
             mx, mean = pix_rel(a, b)
-            print(f'[512_dpt {prec}] {name} rel err max {mx:.3e} mean {mean:.3e}')
-            assert mx < 1e-3 and mean < 2e-4, (prec, name, mx, mean)
+            p99 = pix_rel_p99(a, b)
+            print(f'[512_dpt {prec}] {name} rel err max {mx:.3e} p99 {p99:.3e} mean {mean:.3e}')
+            if prec == 'fp16f8':                # opt-in fast mode: characterised, not claimed (measured max 3.3e-4 on this seed)
+                assert p99 < 1e-3 and mean < 2e-4, (prec, name, mx, p99, mean)
+            else:
+                assert mx < 1e-3 and mean < 2e-4, (prec, name, mx, mean)
         cerr = float(((e1['conf'].cpu() - r1['conf']).abs() / r1['conf']).max())
         print(f'[512_dpt {prec}] conf1 rel err max {cerr:.3e}')
         assert cerr < 3e-3
@@ -280,15 +283,17 @@ def test_full_size_fp32_pair_matches_oracle(gpu):
 
 @pytest.mark.parametrize('big', [40.0, 150.0])
 def test_full_size_default_mode_under_sharp_attention_and_outlier_channels(gpu, big):
-    """Robustness of the default engine (fp16f8: e4m3 copies of the operands carry the cross terms of the blocks' linears) on weights
-    with two traits of TRAINED ViTs that a seeded random network lacks: sharp attention (q / k projections x2: logit std ~2 instead of
-    ~0.5) and outlier channels in the MLP inputs (LayerNorm gains of norm2 / norm3: every 97th channel x8, one channel x40 or x150 --
-    activations in the hundreds; at x150 the e4m3 copies saturate at 448). (Outliers in the ATTENTION inputs turn the softmax into an
-    argmax and the network into a discontinuous function that no arithmetic reproduces, fp32 engine vs fp32 oracle included.)
-    These weights also push pointmaps through the origin (min |pts| 0.02), so the per-pixel RELATIVE error is ill-conditioned in every
-    mode: measured max 6e-4 / 2.6e-3 for the exact-fp32 engine against the fp32 oracle. What is pinned here is that outliers and
-    saturation do not change the character of the mode: its error stays a fixed multiple (measured 15-27x, as on the plain weights) of
-    the fp32 engine's own accumulation-order noise, with a mean below 1e-3."""
+    """Robustness of the default engine (fp16x3) on weights with two traits of TRAINED ViTs that a seeded random network lacks: sharp
+    attention (q / k projections x2: logit std ~2 instead of ~0.5) and outlier channels in the MLP inputs (LayerNorm gains of norm2 /
+    norm3: every 97th channel x8, one channel x40 or x150 -- activations in the hundreds). (Outliers in the ATTENTION inputs turn the
+    softmax into an argmax and the network into a discontinuous function that no arithmetic reproduces, fp32 engine vs fp32 oracle
+    included.) These weights also push pointmaps through the origin (min |pts| 0.02), so the per-pixel RELATIVE error is
+    ill-conditioned in every mode: measured max 6e-4 / 2.6e-3 for the exact-fp32 ENGINE against the fp32 oracle (accumulation order).
+    Held against the CPU oracle, per view:
+      fp16x3 (default): 99th percentile <= 1e-3, mean <= 3e-4, and a per-pixel max that is either inside the bar or within 2x of what
+                        the exact-fp32 engine itself shows on the same weights (i.e. the conditioning of the test, not the arithmetic);
+      fp16f8 (opt-in) : printed. Its un-scaled e4m3 copies saturate at 448: p99 1.3e-3 (x40) / 2.2-4.0e-3 (x150) in round 2 --
+                        the reason the mode is not the default. Only its mean is bounded (a broken kernel, not a rounding floor)."""
     from oracle.dust3r_ref import build_ref_model_fast
     cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
     oracle = build_ref_model_fast(cfg)
@@ -302,33 +307,36 @@ def test_full_size_default_mode_under_sharp_attention_and_outlier_channels(gpu, 
                 p[5::97] *= 8.0
                 p[3] *= big
     eng = engine_from_oracle(oracle, cfg, None, gpu)
-    assert eng.precision == 'fp16f8'
+    assert eng.precision == 'fp16x3'
     v1, v2 = synthetic_views(1, 384, 512, seed=3)
     with torch.no_grad():
         r1, r2 = oracle(v1, v2)
-    worst = {}
-    for prec in ('fp16f8', 'fp16x3', 'fp32'):
+    worst, stats = {}, {}
+    for prec in ('fp32', 'fp16x3', 'fp16f8'):
         eng.set_precision(prec)
         e1, e2 = eng(v1, v2)
         for name, a, b in (('pts1', e1['pts3d'], r1['pts3d']), ('pts2', e2['pts3d_in_other_view'], r2['pts3d_in_other_view'])):
             mx, mean = pix_rel(a, b)
-            print(f'[512_dpt {prec}, sharp attention + outlier channels x{big:g}] {name} rel err max {mx:.3e} p99 {pix_rel_p99(a, b):.3e} mean {mean:.3e}   |pts| min {float(b.norm(dim=-1).min()):.3e}')
+            p99 = pix_rel_p99(a, b)
+            print(f'[512_dpt {prec}, sharp attention + outlier channels x{big:g}] {name} rel err max {mx:.3e} p99 {p99:.3e} mean {mean:.3e}   |pts| min {float(b.norm(dim=-1).min()):.3e}')
             worst[prec] = max(worst.get(prec, 0.0), mx)
-        if prec == 'fp16f8':
-            assert mean < 1.5e-3
-    assert worst['fp16f8'] < 50 * worst['fp32'], worst
-    assert worst['fp16x3'] < 5 * worst['fp32'], worst
+            stats[(prec, name)] = (mx, p99, mean)
+    for name in ('pts1', 'pts2'):
+        mx, p99, mean = stats[('fp16x3', name)]
+        assert p99 < 1e-3 and mean < 3e-4, ('fp16x3', name, mx, p99, mean)
+        assert stats[('fp16f8', name)][2] < 1.5e-3
+    assert worst['fp16x3'] < max(1e-3, 2 * worst['fp32']), worst
 
 
 @pytest.mark.parametrize('seed', [1, 3])
 def test_default_mode_error_distribution_over_seeds(gpu, seed):
-    """How the error of the parity-grade modes is distributed, on the two weight seeds of tools/margin_survey.py (6 seeds x 4 pairs,
-    profiles/r02_f8/margin_survey.log) whose per-pixel maximum is largest. Comparator: the exact-fp32 ENGINE (within 5e-5 of the CPU
+    """How the error of the default mode (fp16x3) is distributed, on the two weight seeds of tools/margin_survey.py (6 seeds x 4 pairs,
+    profiles/r02_f8/margin_survey.log) with the largest per-pixel maxima. Comparator: the exact-fp32 ENGINE (within 5e-5 of the CPU
     oracle in test_full_size_fp32_pair_matches_oracle; a CPU oracle run per seed would take minutes), BASELINE model, 2 pairs 512x384.
     A seeded random network sends some pointmaps through the origin (|pts| down to 0.03 % of the mean norm), where |delta| / |pts| is
-    ill-conditioned for ANY arithmetic: fp16x3 itself reaches 8e-4 there. Held to 1e-3 for the default mode (fp16f8): the 99.99th
-    percentile of the per-pixel relative error and the maximum error relative to the pointmap's scale (max |delta| / mean |pts|);
-    the per-pixel maximum is printed, and wherever it exceeds the bar the pixel must lie within 2 % of the pointmap's scale of the origin."""
+    ill-conditioned for ANY arithmetic. Held for the default: per-pixel max <= 1e-3 (the bar, strict ratio), 99.99th percentile <= 3e-4,
+    max |delta| / mean |pts| <= 3e-4. The opt-in fp16f8 mode is characterised next to it (p99.99 and scale-relative max <= 1e-3; its
+    per-pixel max passes the bar on these seeds: 1.9e-3 / 2.7e-3 in round 2 -- printed, not asserted)."""
     from dust3r_amd.model import AsymmetricCroCo3DStereo
     from dust3r_amd.synthetic import OUT_GAIN, synthetic_state_dict
     cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
@@ -338,8 +346,8 @@ def test_default_mode_error_distribution_over_seeds(gpu, seed):
     v1, v2 = synthetic_views(2, 384, 512, seed=100 + seed, device=gpu)
     r1, r2 = m(v1, v2)
     ref = torch.cat((r1['pts3d'], r2['pts3d_in_other_view'])).clone()
-    nrm = ref.norm(dim=-1).clamp_min(1e-12)
-    for prec, bar in (('fp16f8', 1e-3), ('fp16x3', 3e-4)):
+    nrm = ref.norm(dim=-1).clamp_min(1e-8)
+    for prec, bar in (('fp16x3', 3e-4), ('fp16f8', 1e-3)):
         m.set_precision(prec)
         e1, e2 = m(v1, v2)
         dn = (torch.cat((e1['pts3d'], e2['pts3d_in_other_view'])) - ref).norm(dim=-1)
@@ -350,8 +358,8 @@ def test_default_mode_error_distribution_over_seeds(gpu, seed):
         print(f'[512_dpt seed {seed} {prec} vs fp32 engine] per-pixel max {float(rel[-1]):.3e} (at a pixel with |pts| = {worst_norm:.2e} of the mean norm) '
               f'p99.99 {p9999:.3e} mean {float(rel.mean()):.3e}; max |delta| / mean |pts| {scaled:.3e}')
         assert p9999 < bar and scaled < bar and float(rel.mean()) < bar / 5, (prec, p9999, scaled)
-        # wherever the per-pixel ratio exceeds the bar, it is the denominator: a point within 2 % of the scene scale of the origin
-        assert float(rel[-1]) < bar or worst_norm < 0.02, (prec, float(rel[-1]), worst_norm)
+        if prec == 'fp16x3':
+            assert float(rel[-1]) < 1e-3, (prec, float(rel[-1]), worst_norm)
 
 
 def test_config1_pairviewer_pipeline(gpu):
@@ -440,6 +448,45 @@ def test_sharded_inference_on_the_engine_with_rccl(gpu):
     assert out['view1']['idx'] == ref['view1']['idx'] and out['view2']['idx'] == ref['view2']['idx']
     assert torch.equal(out['pred1']['pts3d'], ref['pred1']['pts3d']) and torch.equal(out['pred1']['conf'], ref['pred1']['conf'])
     assert torch.equal(out['pred2']['pts3d_in_other_view'], ref['pred2']['pts3d_in_other_view']) and torch.equal(out['pred2']['conf'], ref['pred2']['conf'])
+
+
+def test_two_ranks_on_one_gpu_sharded_inference(gpu, tmp_path):
+    """dust3r_amd.parallel.inference_sharded with TWO ranks, both on this box's one GPU, each with its own engine (gloo moves the CUDA
+    payload; RCCL refuses two ranks on one device and is exercised at world size 1 above): the one-size list takes the encode-once route
+    (each rank encodes the images of its shard once, the heads write the packed payload in place), the mixed-size list the flat padded
+    payload. Every rank's result must be bit-identical to single-process inference() on the same engine."""
+    import socket
+    import torch.multiprocessing as mp
+    sys_path_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    if sys_path_root not in sys.path:
+        sys.path.insert(0, sys_path_root)
+    from tests._dist_worker import build_engine, scene_pairs, worker
+    from dust3r_amd.inference import inference
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    eng = build_engine(gpu)                                  # meanwhile: the single-process reference on a third engine
+    ref = {kind: inference(scene_pairs(kind), eng, gpu, batch_size=4, verbose=False) for kind in ('same', 'mixed')}
+    for p in procs:
+        p.join(timeout=500)
+        assert p.exitcode == 0
+    for r in range(2):
+        got = torch.load(os.path.join(str(tmp_path), f'rank{r}.pt'), weights_only=False)
+        for kind in ('same', 'mixed'):
+            a, b = ref[kind], got[kind]
+            assert a['view1']['idx'] == b['view1']['idx'] and a['view2']['idx'] == b['view2']['idx']
+            for view, keys in (('pred1', ('pts3d', 'conf')), ('pred2', ('pts3d_in_other_view', 'conf'))):
+                for k in keys:
+                    xa, xb = a[view][k], b[view][k]
+                    if isinstance(xa, list):
+                        assert len(xa) == len(xb) and all(torch.equal(p, q) for p, q in zip(xa, xb)), (kind, view, k)
+                    else:
+                        assert torch.equal(xa, xb), (kind, view, k)
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'fp16x3', 'fp16f8'])

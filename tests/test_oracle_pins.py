@@ -147,6 +147,38 @@ def test_cloud_restatements_equal_live_reference():
 
 
 @pytest.mark.skipif(not reference_available(), reason='/root/reference only exists in the build container')
+@pytest.mark.parametrize('n', [2, 3, 7])
+def test_align_pose_sets_equals_live_reference(n):
+    """dust3r_amd.cloud_opt.bootstrap.align_pose_sets (init='known_poses', PairViewer) against the unmodified
+    init_im_poses.align_multiple_poses: the epsilon of the "point down the optical axis" is the median of the CONDENSED pairwise
+    centre distances (geometry.py:364-366, scipy pdist) -- with 2 poses that is d / 100, not d / 200."""
+    from oracle.ref_import import import_reference
+    import_reference()
+    import numpy as np
+    from dust3r.cloud_opt.init_im_poses import align_multiple_poses
+    from dust3r_amd.cloud_opt.bootstrap import align_pose_sets
+    from oracle.roma_ref import unitquat_to_rotmat
+    g = torch.Generator().manual_seed(n)
+
+    def poses(k):
+        q = torch.randn((k, 4), generator=g, dtype=torch.float64)
+        P = torch.eye(4, dtype=torch.float64).repeat(k, 1, 1)
+        P[:, :3, :3] = unitquat_to_rotmat(q / q.norm(dim=-1, keepdim=True))
+        P[:, :3, 3] = torch.randn((k, 3), generator=g, dtype=torch.float64) * 2
+        return P
+    src = poses(n)
+    # dst = a similarity of src plus a little noise, so that the registration is well conditioned
+    S = poses(1)[0]
+    dst = S @ src
+    dst[:, :3, 3] = 1.7 * dst[:, :3, 3] + 0.01 * torch.randn((n, 3), generator=g, dtype=torch.float64)
+    s_ref, R_ref, T_ref = align_multiple_poses(src, dst)
+    from dust3r_amd.cloud_opt.bootstrap import split_similarity
+    s, R, t = split_similarity(align_pose_sets(src.numpy(), dst.numpy()))
+    assert abs(float(s) / float(s_ref) - 1) < 1e-9
+    assert np.abs(np.asarray(R) - R_ref.numpy()).max() < 1e-9 and np.abs(np.asarray(t).ravel() - T_ref.numpy().ravel()).max() < 1e-8
+
+
+@pytest.mark.skipif(not reference_available(), reason='/root/reference only exists in the build container')
 def test_reference_demo_binds_to_the_engine_through_the_integration_aliases():
     """with `dust3r.<hot-path module>` aliased to `dust3r_amd.<module>`, the reference's OWN dust3r/demo.py
     (imported unmodified; gradio / matplotlib / trimesh stubbed) resolves every function of its reconstruction body to the engine's."""

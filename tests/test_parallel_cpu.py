@@ -26,6 +26,43 @@ class StandInModel:
         return dict(pts3d=pts1, conf=conf1), dict(pts3d_in_other_view=pts2, conf=conf2)
 
 
+class StandInEncodeOnce(StandInModel):
+    """The same function split the way the engine's encode-once API splits it (encode_images / decode_pairs), counting encoder calls."""
+    _engine = object()
+
+    def __init__(self):
+        self.encoded = 0
+
+    def encode_images(self, img):
+        self.encoded += img.shape[0]
+        return img.reshape(img.shape[0], -1).clone()
+
+    def decode_pairs(self, feat, H, W, packed_out=None):
+        B = feat.shape[0] // 2
+        a, b = feat[:B].reshape(B, 3, H, W), feat[B:].reshape(B, 3, H, W)
+        return StandInModel.__call__(self, dict(img=a), dict(img=b))
+
+
+class StandInMixed:
+    """Stand-in for pairs whose two views differ in size: view 1's outputs at view 1's size, view 2's at view 2's, each depending on both images."""
+
+    def __call__(self, view1, view2):
+        a, b = view1['img'], view2['img']
+        ma, mb = a.mean(dim=(2, 3), keepdim=True), b.mean(dim=(2, 3), keepdim=True)
+        pts1 = (a * 2 + mb).permute(0, 2, 3, 1).contiguous()
+        pts2 = (b * 3 - ma).permute(0, 2, 3, 1).contiguous()
+        return dict(pts3d=pts1, conf=1 + (a * mb).sum(1).abs()), dict(pts3d_in_other_view=pts2, conf=1 + (b + ma).sum(1).abs())
+
+
+def _mixed_pairs():
+    """7 images of three sizes -> 42 ordered pairs of mixed (view 1, view 2) sizes, the list dust3r/inference.py:60-68 runs one by one"""
+    g = torch.Generator().manual_seed(4)
+    shapes = [(16, 32), (32, 16), (16, 32), (16, 16), (32, 16), (16, 32), (16, 32)]
+    imgs = [dict(img=torch.rand((1, 3, h, w), generator=g) * 2 - 1, true_shape=torch.tensor([[h, w]], dtype=torch.int32), idx=k, instance=str(k))
+            for k, (h, w) in enumerate(shapes)]
+    return [(imgs[i], imgs[j]) for i in range(len(imgs)) for j in range(len(imgs)) if i != j]
+
+
 def _pairs(n_views, H, W):
     sys.path.insert(0, ROOT)
     from dust3r_amd.image_pairs import make_pairs
@@ -33,12 +70,27 @@ def _pairs(n_views, H, W):
     return make_pairs(synthetic_image_list(n_views, H, W, seed=3), 'complete', None, symmetrize=False)
 
 
-def _worker(rank, world, port, n_views, outdir, H=16, W=32):
+def _worker(rank, world, port, n_views, outdir, H=16, W=32, mode='plain'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from dust3r_amd.parallel import inference_sharded
-        out = inference_sharded(_pairs(n_views, H, W), StandInModel(), 'cpu', batch_size=2)
+        if mode == 'mixed':
+            out = inference_sharded(_mixed_pairs(), StandInMixed(), 'cpu', batch_size=3)
+            torch.save((rank, out), os.path.join(outdir, f'rank{rank}.pt'))
+            dist.barrier()
+            return
+        model = StandInEncodeOnce() if mode == 'encode_once' else StandInModel()
+        from dust3r_amd.image_pairs import make_pairs
+        from dust3r_amd.synthetic import synthetic_image_list
+        pairs = make_pairs(synthetic_image_list(n_views, H, W, seed=3), 'complete', None, symmetrize=True) if mode == 'encode_once' else _pairs(n_views, H, W)
+        out = inference_sharded(pairs, model, 'cpu', batch_size=2)
+        if mode == 'encode_once':
+            # a rank encodes the distinct images of ITS shard once: fewer encoder passes than its 2 x (pairs in the shard) view slots
+            from dust3r_amd.parallel import shard_bounds
+            lo, hi, _ = shard_bounds(len(pairs), rank, world)
+            touched = {int(v['idx']) for p in pairs[lo:hi] for v in p}
+            assert model.encoded == len(touched) < 2 * (hi - lo), (model.encoded, len(touched), hi - lo)
         torch.save((rank, out['pred1']['pts3d'], out['pred1']['conf'], out['pred2']['pts3d_in_other_view'], out['pred2']['conf'],
                     out['view1']['idx'], out['view2']['idx']), os.path.join(outdir, f'rank{rank}.pt'))
         dist.barrier()
@@ -72,6 +124,50 @@ def test_sharded_inference_equals_single_process(n_views, world, H, W, tmp_path)
         assert torch.equal(pts1, ref['pred1']['pts3d']) and torch.equal(conf1, ref['pred1']['conf'])
         assert torch.equal(pts2, ref['pred2']['pts3d_in_other_view']) and torch.equal(conf2, ref['pred2']['conf'])
         assert idx1 == ref['view1']['idx'] and idx2 == ref['view2']['idx']
+
+
+def _spawn(world, tmp_path, *args):
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    return [torch.load(os.path.join(str(tmp_path), f'rank{r}.pt'), weights_only=False) for r in range(world)]
+
+
+def test_sharded_inference_encodes_each_image_of_a_shard_once(tmp_path):
+    """The encode-once route of inference_sharded (what the engine takes on the GPU): 5 views, complete symmetrised graph = 20 pairs on
+    2 ranks; every rank encodes only the images its shard touches, once; result bit-identical to the single-process pair-by-pair call."""
+    sys.path.insert(0, ROOT)
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.inference import inference
+    from dust3r_amd.synthetic import synthetic_image_list
+    pairs = make_pairs(synthetic_image_list(5, 16, 32, seed=3), 'complete', None, symmetrize=True)
+    ref = inference(pairs, StandInModel(), 'cpu', batch_size=2, verbose=False)
+    for rank, pts1, conf1, pts2, conf2, idx1, idx2 in _spawn(2, tmp_path, 5, str(tmp_path), 16, 32, 'encode_once'):
+        assert torch.equal(pts1, ref['pred1']['pts3d']) and torch.equal(conf1, ref['pred1']['conf'])
+        assert torch.equal(pts2, ref['pred2']['pts3d_in_other_view']) and torch.equal(conf2, ref['pred2']['conf'])
+        assert idx1 == ref['view1']['idx'] and idx2 == ref['view2']['idx']
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_inference_with_mixed_image_sizes(world, tmp_path):
+    """Pairs of several image sizes shard too: grouped by shape inside each shard, one flat padded payload, ONE all-gather; the result
+    has the list-per-pair structure `inference()` returns for such a list (dust3r/inference.py:60-72), bit-identical."""
+    from dust3r_amd.inference import inference
+    pairs = _mixed_pairs()
+    ref = inference(pairs, StandInMixed(), 'cpu', batch_size=1, verbose=False)
+    assert isinstance(ref['pred1']['pts3d'], list) and len(ref['pred1']['pts3d']) == len(pairs) == 42
+    for rank, out in _spawn(world, tmp_path, 0, str(tmp_path), 0, 0, 'mixed'):
+        assert out['loss'] is None or out['loss'] == [None] * len(pairs) or out['loss'] == ref['loss']
+        for view, keys in (('pred1', ('pts3d', 'conf')), ('pred2', ('pts3d_in_other_view', 'conf')), ('view1', ('img', 'true_shape')), ('view2', ('img', 'true_shape'))):
+            for k in keys:
+                a, b = ref[view][k], out[view][k]
+                assert isinstance(b, list) and len(a) == len(b) and all(x.shape == y.shape and torch.equal(x, y) for x, y in zip(a, b)), (view, k)
+        assert out['view1']['idx'] == ref['view1']['idx'] and out['view2']['instance'] == ref['view2']['instance']
 
 
 def test_shard_bounds_cover_everything_once():

@@ -32,7 +32,7 @@ def main():
     cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
     if '--align-only' in sys.argv:
         return align_stage(n, graph, H, W, dev)
-    prec = next((a.split('=')[1] for a in sys.argv if a.startswith('--precision=')), None)      # default: the engine default (fp16f8, parity-grade)
+    prec = next((a.split('=')[1] for a in sys.argv if a.startswith('--precision=')), None)      # default: the engine default (fp16x3, parity-grade)
     m = AsymmetricCroCo3DStereo(precision=prec, landscape_only=False, **MODEL_CONFIGS[cfg])
     m.load_state_dict(synthetic_state_dict({k: torch.empty(v, device='meta') for k, v in m._spec.items()}, 0, OUT_GAIN[cfg], device=dev))
     m.to(dev)
