@@ -195,6 +195,22 @@ def attention(q, k, vt, Nk=None, scale=0.125):
     return out
 
 
+def attention_x3(q, k, v, scale=0.125):
+    """`attention` in the split-fp16 precision mode: q (B,H,Nq,64), k, v (B,H,Nk,64) fp32 are packed to the x3 row layout (q, k per
+    token; v transposed to (B,H,64,ldv) with the keys zero padded to a multiple of 64), the (B,Nq,H*64) result comes back as fp32."""
+    _lib.require_device()
+    B, H, Nq, D = q.shape
+    Nk = k.shape[2]
+    assert D == 64
+    ldv = (Nk + 63) // 64 * 64
+    vt = torch.zeros((B, H, 64, ldv), dtype=torch.float32, device=q.device)
+    vt[..., :Nk] = v.float().transpose(-1, -2)
+    qp, kp, vp = pack_x3(q), pack_x3(k), pack_x3(vt)
+    out = torch.empty((B, Nq, H * 64 * 2), dtype=torch.float16, device=q.device)
+    check(lib.d3r_attention(ptr(qp), ptr(kp), ptr(vp), ptr(out), B, H, Nq, Nk, ldv, scale, _lib.DTYPE_F16X3, current_stream()), 'attention(x3)')
+    return unpack_x3(out)
+
+
 def upsample2x_nhwc(x, out_hw=None):
     _lib.require_device()
     B, H, W, Cc = x.shape

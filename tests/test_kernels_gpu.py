@@ -237,6 +237,44 @@ def test_attention(gpu, dtype, B, H, Nq, Nk):
     assert relerr(out, ref) < tol
 
 
+@pytest.mark.parametrize('v1', ['0', '1'])
+@pytest.mark.parametrize('B,H,Nq,Nk', [(2, 3, 196, 196), (1, 2, 768, 768), (2, 1, 6, 6), (1, 4, 130, 70), (1, 1, 768, 196), (1, 2, 40, 129), (1, 1, 300, 64), (1, 1, 64, 128)])
+def test_attention_split_fp16(gpu, v1, B, H, Nq, Nk, monkeypatch):
+    """The split-fp16 attention of the default engine at kernel level, both kernels (D3R_ATTN_V1=1: the round-2 kernel; default: the
+    software-pipelined one): against the fp64 softmax(Q K^T / 8) V of the SAME fp32 operands. Operands keep 22 significand bits and the
+    probabilities are split too, so the result is fp32-class (3e-5 like the exact-fp32 kernel); 1 to 12 key tiles, ragged last tiles,
+    query blocks with idle lanes. A subprocess-free switch: the choice is read on every launch."""
+    from dust3r_amd import ops
+    monkeypatch.setenv('D3R_ATTN_V1', v1)
+    g = torch.Generator(device='cpu').manual_seed(Nq * 5 + Nk)
+    q = (torch.randn((B, H, Nq, 64), generator=g) * 1.5).to(gpu)
+    k = (torch.randn((B, H, Nk, 64), generator=g) * 1.5).to(gpu)
+    v = torch.randn((B, H, Nk, 64), generator=g).to(gpu)
+    out = ops.attention_x3(q, k, v, scale=0.125)
+    a = (q.double() @ k.double().transpose(-1, -2)) * 0.125
+    ref = (a.softmax(-1) @ v.double()).transpose(1, 2).flatten(2)
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    print(f'attention x3 v1={v1} B{B} H{H} Nq{Nq} Nk{Nk}: rel err {err:.2e}')
+    assert err < 3e-5
+
+
+def test_attention_split_fp16_sharp_rows_and_late_maximum(gpu):
+    """Running-maximum rescale of the pipelined kernel: one key dominating by a huge margin in a LATE tile (alpha = 0 there), and rows
+    whose maximum moves in every tile."""
+    from dust3r_amd import ops
+    B, H, N = 1, 2, 320
+    q = torch.zeros((B, H, N, 64), device=gpu)
+    k = torch.zeros((B, H, N, 64), device=gpu)
+    q[..., 0] = 30.0
+    k[0, 0, 200, 0] = 30.0                                   # head 0: score 112.5 for key 200, 0 elsewhere
+    k[0, 1, :, 0] = torch.linspace(0, 20, N, device=gpu)     # head 1: the maximum grows with the key index
+    v = torch.randn((B, H, N, 64), device=gpu)
+    out = ops.attention_x3(q, k, v, scale=0.125)
+    a = (q.double() @ k.double().transpose(-1, -2)) * 0.125
+    ref = (a.softmax(-1) @ v.double()).transpose(1, 2).flatten(2)
+    assert float((out.double() - ref).abs().max()) < 1e-5
+
+
 def test_attention_softmax_is_stable(gpu):
     """one key dominating by a huge margin at a late tile: the running-max rescale branch must be exact."""
     from dust3r_amd import ops
