@@ -58,6 +58,7 @@ def _load():
         'd3r_model_forward_mixed': (i, [vp, fp, i, i, fp, i, i, i, fp, fp, fp, fp, vp]),
         'd3r_model_forward_packed': (i, [vp, fp, fp, i, i, i, fp, vp]),
         'd3r_model_device_bytes': (C.c_size_t, [vp]),
+        'd3r_model_graph_replays': (C.c_long, [vp]),
         'd3r_model_feature_bytes': (C.c_size_t, [vp, i, i]),
         'd3r_model_encode': (i, [vp, fp, i, i, i, vp, vp]),
         'd3r_model_decode': (i, [vp, vp, i, i, i, fp, fp, fp, fp, vp]),

@@ -85,6 +85,29 @@ struct d3r_model {
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     bool two_streams = true;
     int out_pstride = 3, out_cstride = 1;   // output element strides between pixels (8, 8 while d3r_model_forward_packed runs)
+    // ---- hipGraph replay of small-batch forwards (d3r_model_forward* with B <= graph_max_pairs) ------------------------------------
+    // One pair per call (dust3r/demo.py:156 batch_size=1, visloc.py:88) is ~700 launches of kernels that each fill a fraction of the
+    // chip: the host-side enqueue and the two-stream event traffic, not the GPU, set the pace. The second call with the same
+    // (entry point, B, image sizes, output layout, stream plan) is stream-captured on an engine-owned stream into a graph that works on
+    // engine-owned input / output staging buffers; every later call is [copy inputs -> staging] + hipGraphLaunch + [copy staging ->
+    // outputs] on the caller's stream. Same kernels, same order: bit-identical to the eager call.
+    struct GraphKey {
+        int B, H1, W1, H2, W2, pstride, two;
+        bool operator==(const GraphKey& o) const { return B == o.B && H1 == o.H1 && W1 == o.W1 && H2 == o.H2 && W2 == o.W2 && pstride == o.pstride && two == o.two; }
+    };
+    struct GraphEntry { GraphKey key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int seen = 0; float* io = nullptr; size_t io_bytes = 0; };
+    std::vector<GraphEntry> graphs;
+    hipStream_t cap = nullptr;              // capture origin (the legacy default stream cannot be captured)
+    int graph_max_pairs = 4;                // D3R_MODEL_OPT_GRAPH_MAX_PAIRS; 0 = off
+    long graph_replays = 0;                 // statistics (tests)
+    void drop_graphs() {
+        for (auto& g : graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+            if (g.io) (void)hipFree(g.io);
+        }
+        graphs.clear();
+    }
     // last forward (debug hook)
     const void* last_encn = nullptr; size_t last_encn_elems = 0;
     // optional per-launch HIP-event timing (d3r_model_set_option(D3R_MODEL_OPT_PROFILE)); off in timed runs
@@ -383,6 +406,7 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     if (launch_rope_table(m->rope_table, 512, cfg->rope_freq, 1.0f, nullptr) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_LAUNCH; }
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
+    if (const char* e = getenv("D3R_GRAPH_MAX_PAIRS")) m->graph_max_pairs = atoi(e) > 0 ? atoi(e) : 0;
     (void)hipDeviceSynchronize();
     *out = m;
     return D3R_OK;
@@ -395,6 +419,8 @@ extern "C" int d3r_model_destroy(d3r_model* m) {
     if (m->ev_main) (void)hipEventDestroy(m->ev_main);
     if (m->ev_side) (void)hipEventDestroy(m->ev_side);
     if (m->side) (void)hipStreamDestroy(m->side);
+    m->drop_graphs();
+    if (m->cap) (void)hipStreamDestroy(m->cap);
     if (m->ws) (void)hipFree(m->ws);
     if (m->stage) (void)hipFree(m->stage);
     delete m;
@@ -469,6 +495,7 @@ extern "C" int d3r_model_set_option(d3r_model* m, int option, int value) {
     if (!m) return D3R_ERR_INVALID;
     if (option == D3R_MODEL_OPT_PROFILE) { m->prof_on = value != 0; m->prof_rec.clear(); return D3R_OK; }
     if (option == D3R_MODEL_OPT_TWO_STREAMS) { m->two_streams = value != 0; return D3R_OK; }
+    if (option == D3R_MODEL_OPT_GRAPH_MAX_PAIRS) { m->graph_max_pairs = value > 0 ? value : 0; if (!value) m->drop_graphs(); return D3R_OK; }
     return D3R_ERR_INVALID;
 }
 
@@ -825,6 +852,7 @@ static int run_phases(d3r_model* m, int phases, const float* img1, const float* 
     if (need > m->ws_bytes) {
         (void)hipStreamSynchronize(st);
         if (m->side) (void)hipStreamSynchronize(m->side);
+        m->drop_graphs();                         // captured launches point into the old workspace
         if (m->ws) (void)hipFree(m->ws);
         m->ws = nullptr; m->ws_bytes = 0;
         if (hipMalloc(&m->ws, need) != hipSuccess) return D3R_ERR_ALLOC;
@@ -832,9 +860,76 @@ static int run_phases(d3r_model* m, int phases, const float* img1, const float* 
     }
     int rc = D3R_OK;
     m->prof_rec.clear();
+    // ---- small whole forwards: replay a captured graph (see d3r_model::GraphEntry) ---------------------------------------------------
+    const bool graphable = phases == (PH_ENCODE | PH_DECODE) && m->graph_max_pairs > 0 && B <= m->graph_max_pairs && !m->prof_on && nimg1 == B && nimg == 2 * B;
+    if (graphable) {
+        const d3r_model::GraphKey key{B, H1, W1, H2, W2, m->out_pstride, (m->two_streams && m->side) ? 1 : 0};
+        d3r_model::GraphEntry* ge = nullptr;
+        for (auto& g : m->graphs)
+            if (g.key == key) { ge = &g; break; }
+        if (!ge) {
+            if (m->graphs.size() >= 16) m->drop_graphs();      // a handful of (batch, size) combinations is the expected use
+            m->graphs.push_back(d3r_model::GraphEntry());
+            ge = &m->graphs.back();
+            ge->key = key;
+        }
+        const size_t n_in1 = (size_t)B * 3 * H1 * W1, n_in2 = (size_t)B * 3 * H2 * W2;
+        const size_t a1 = (size_t)B * H1 * W1, a2 = (size_t)B * H2 * W2;
+        const bool packed = m->out_pstride == 8;                 // one [B][H][W][8] payload (H1 == H2, W1 == W2)
+        const size_t n_out = packed ? a1 * 8 : 4 * (a1 + a2);
+        // staging layout (floats): img1 | img2 | pts1 conf1 pts2 conf2 (or the packed payload)
+        float* io = ge->io;
+        auto s_img1 = [&]() { return io; };
+        auto s_img2 = [&]() { return io + n_in1; };
+        auto s_out = [&]() { return io + n_in1 + n_in2; };
+        if (ge->seen >= 1 && !ge->exec && ge->seen < 1000) {     // second call: capture
+            bool ok = true;
+            if (!m->cap) ok = hipStreamCreateWithFlags(&m->cap, hipStreamNonBlocking) == hipSuccess;
+            const size_t bytes = (n_in1 + n_in2 + n_out) * sizeof(float);
+            if (ok && !ge->io) { ok = hipMalloc((void**)&ge->io, bytes) == hipSuccess; ge->io_bytes = bytes; io = ge->io; }
+            if (ok) {
+                float *o1 = s_out(), *c1, *o2, *c2;
+                if (packed) { c1 = o1 + 3; o2 = o1 + 4; c2 = o1 + 7; }
+                else { c1 = o1 + 3 * a1; o2 = c1 + a1; c2 = o2 + 3 * a2; }
+                ok = hipStreamBeginCapture(m->cap, hipStreamCaptureModeRelaxed) == hipSuccess;
+                if (ok) {
+                    int crc = D3R_OK;
+                    forward_impl(m, m->ws, m->ws_bytes, phases, s_img1(), s_img2(), nimg1, nimg, feat, B, d0, d1, o1, c1, o2, c2, m->cap, &crc);
+                    hipGraph_t g = nullptr;
+                    const bool ended = hipStreamEndCapture(m->cap, &g) == hipSuccess && g != nullptr;
+                    ok = ended && crc == D3R_OK && hipGraphInstantiate(&ge->exec, g, nullptr, nullptr, 0) == hipSuccess;
+                    if (ok) ge->graph = g;
+                    else if (g) (void)hipGraphDestroy(g);
+                }
+            }
+            if (!ok) {                        // this shape stays eager
+                (void)hipGetLastError();
+                ge->exec = nullptr;
+                ge->seen = 1000;
+            }
+        }
+        if (ge->exec) {
+            io = ge->io;
+            bool ok = hipMemcpyAsync(s_img1(), img1, n_in1 * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                      hipMemcpyAsync(s_img2(), img2, n_in2 * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                      hipGraphLaunch(ge->exec, st) == hipSuccess;
+            const float* o1 = s_out();
+            if (ok && packed) ok = hipMemcpyAsync(pts1, o1, n_out * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess;
+            else if (ok)
+                ok = hipMemcpyAsync(pts1, o1, 3 * a1 * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                     hipMemcpyAsync(conf1, o1 + 3 * a1, a1 * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                     hipMemcpyAsync(pts2, o1 + 4 * a1, 3 * a2 * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                     hipMemcpyAsync(conf2, o1 + 4 * a1 + 3 * a2, a2 * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess;
+            if (ok) { ++m->graph_replays; return D3R_OK; }
+            return D3R_ERR_LAUNCH;
+        }
+        if (ge->seen < 1000) ++ge->seen;
+    }
     forward_impl(m, m->ws, m->ws_bytes, phases, img1, img2, nimg1, nimg, feat, B, d0, d1, pts1, conf1, pts2, conf2, st, &rc);
     return rc;
 }
+
+extern "C" long d3r_model_graph_replays(const d3r_model* m) { return m ? m->graph_replays : -1; }
 
 extern "C" int d3r_model_forward(d3r_model* m, const float* img1, const float* img2, int B, int H, int W, float* pts1, float* conf1,
                                  float* pts2, float* conf2, void* stream) {

@@ -261,6 +261,15 @@ class AsymmetricCroCo3DStereo(nn.Module):
         check(lib.d3r_model_set_option(self._engine, 2, int(bool(flag))), 'set_option(two_streams)')
         return self
 
+    def set_graph_max_pairs(self, n=4):
+        """Whole forwards of at most `n` pairs are replayed as a hipGraph from the third call with the same shapes on (the launch-bound
+        one-pair-per-call use of dust3r/demo.py:156 and visloc.py:88); 0 = always eager. Bit-identical either way."""
+        check(lib.d3r_model_set_option(self._engine, 3, int(n)), 'set_option(graph_max_pairs)')
+        return self
+
+    def graph_replays(self):
+        return int(lib.d3r_model_graph_replays(self._engine)) if self._engine is not None else 0
+
     @property
     def device(self):
         return self._device

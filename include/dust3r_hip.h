@@ -153,6 +153,8 @@ int d3r_model_decode(d3r_model* m, const void* feat, int B, int H, int W, float*
 /* d3r_model_decode with the outputs interleaved per pixel like d3r_model_forward_packed: out8 fp32 [B][H][W][8]. This is what a rank of
  * the pair-sharded path runs on its shard after encoding the distinct images of that shard once (dust3r_amd/parallel.py). */
 int d3r_model_decode_packed(d3r_model* m, const void* feat, int B, int H, int W, float* out8, void* stream);
+/* number of forwards served by a graph replay so far (tests, probes) */
+long d3r_model_graph_replays(const d3r_model* m);
 /* bytes of device memory currently held (weights + workspace) */
 size_t d3r_model_device_bytes(const d3r_model* m);
 /* Measurement hook (bench.py): with D3R_MODEL_OPT_PROFILE = 1 the next forwards record one HIP event before every
@@ -166,6 +168,11 @@ size_t d3r_model_device_bytes(const d3r_model* m);
 #define D3R_MODEL_OPT_PROFILE 1
 #define D3R_MODEL_OPT_TWO_STREAMS 2 /* 1 (default): decoder side 2 and head 2 run on an engine-owned second HIP stream, joined back
                                      * into the caller's stream before d3r_model_forward's work completes; 0: everything on the caller's stream */
+#define D3R_MODEL_OPT_GRAPH_MAX_PAIRS 3 /* whole forwards (d3r_model_forward / _mixed / _packed) of at most this many pairs are replayed as a hipGraph
+                                         * from the third call with the same (B, image sizes, output layout) on: ~700 launches become one
+                                         * graph launch + input / output copies through engine-owned staging buffers (bit-identical results;
+                                         * one pair per call is what dust3r/demo.py:156 and visloc.py:88 ask for). Default 4
+                                         * (D3R_GRAPH_MAX_PAIRS at create); 0 switches the replay off and drops the captured graphs */
 int d3r_model_set_option(d3r_model* m, int option, int value);
 int d3r_model_profile_read(d3r_model* m, int kind, int* launches, double* ms, double* work);
 /* launch `index` of the last profiled forward: class, GEMM shape (attention: batch*heads, queries, keys), ms, flops;

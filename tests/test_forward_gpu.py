@@ -450,6 +450,46 @@ def test_sharded_inference_on_the_engine_with_rccl(gpu):
     assert torch.equal(out['pred2']['pts3d_in_other_view'], ref['pred2']['pts3d_in_other_view']) and torch.equal(out['pred2']['conf'], ref['pred2']['conf'])
 
 
+@pytest.mark.parametrize('precision', ['fp16x3', 'bf16'])
+def test_small_batch_graph_replay_is_bit_identical(gpu, precision):
+    """One or two pairs per call (dust3r/demo.py:156 passes batch_size=1, visloc.py:88 one pair per query): from the third call with the
+    same shapes on, the engine replays a captured hipGraph through its own staging buffers. Results must be bit-identical to the eager
+    schedule, for the plain, the mixed-size and the packed entry points, with fresh input / output tensors on every call, and a call with
+    other shapes in between must not disturb a captured graph."""
+    from oracle.dust3r_ref import build_ref_model
+    eng = engine_from_oracle(build_ref_model('tiny_dpt'), 'tiny_dpt', precision, gpu)
+    g = torch.Generator().manual_seed(12)
+
+    def views(B, hw1, hw2):
+        return (dict(img=torch.rand((B, 3) + hw1, generator=g) * 2 - 1, true_shape=torch.tensor([hw1] * B, dtype=torch.int32), idx=list(range(B)), instance=['a'] * B),
+                dict(img=torch.rand((B, 3) + hw2, generator=g) * 2 - 1, true_shape=torch.tensor([hw2] * B, dtype=torch.int32), idx=list(range(B)), instance=['b'] * B))
+    cases = [views(1, (64, 96), (64, 96)), views(2, (32, 48), (32, 48)), views(1, (32, 48), (48, 32))]
+    eng.set_graph_max_pairs(0)
+    want = []
+    for v1, v2 in cases:
+        r1, r2 = eng(v1, v2)
+        want.append([t.clone() for t in (r1['pts3d'], r1['conf'], r2['pts3d_in_other_view'], r2['conf'])])
+    want_packed = eng.forward_packed(*cases[0]).clone()
+    eng.set_graph_max_pairs(4)
+    before = eng.graph_replays()
+    keep = []
+    for rep in range(4):                      # eager, capture + replay, replay, replay -- interleaved over the three shapes
+        for (v1, v2), w in zip(cases, want):
+            r1, r2 = eng(v1, v2)
+            keep.append((r1, r2))             # outputs stay alive: every call sees new output addresses
+            got = (r1['pts3d'], r1['conf'], r2['pts3d_in_other_view'], r2['conf'])
+            assert all(torch.equal(a, b) for a, b in zip(got, w)), rep
+        assert torch.equal(eng.forward_packed(*cases[0]), want_packed), rep
+    torch.cuda.synchronize()
+    assert eng.graph_replays() - before >= 8, eng.graph_replays() - before
+    # a bigger batch than the limit stays eager and still agrees row by row
+    v1, v2 = views(5, (32, 48), (32, 48))
+    full1, _ = eng(v1, v2)
+    one1, _ = eng(dict(img=v1['img'][3:4], true_shape=v1['true_shape'][3:4], idx=[0], instance=['a']),
+                  dict(img=v2['img'][3:4], true_shape=v2['true_shape'][3:4], idx=[0], instance=['b']))
+    assert torch.equal(full1['pts3d'][3], one1['pts3d'][0])
+
+
 def test_two_ranks_on_one_gpu_sharded_inference(gpu, tmp_path):
     """dust3r_amd.parallel.inference_sharded with TWO ranks, both on this box's one GPU, each with its own engine (gloo moves the CUDA
     payload; RCCL refuses two ranks on one device and is exercised at world size 1 above): the one-size list takes the encode-once route

@@ -15,18 +15,22 @@ from dust3r_amd.synthetic import synthetic_scene, synthetic_views  # noqa: E402
 def main():
     dev = torch.device('cuda', 0)
     model = build_model('fp16x3', dev)
-    for B in (1, 2, 4, 8, 32):
-        v1, v2 = synthetic_views(B, H, W, seed=0, device=dev)
-        for _ in range(3):
-            model(v1, v2)
-        torch.cuda.synchronize()
-        n = 20 if B <= 8 else 5
-        t = time.perf_counter()
-        for _ in range(n):
-            model(v1, v2)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t) / n
-        print(f'forward B={B:2d}: {dt * 1e3:8.2f} ms/call  {B / dt:7.1f} pairs/s', flush=True)
+    for graphs in (0, 4):              # eager launches vs the hipGraph replay of small forwards (D3R_MODEL_OPT_GRAPH_MAX_PAIRS)
+        model.set_graph_max_pairs(graphs)
+        for B in ((1, 2, 4, 8, 32) if graphs == 0 else (1, 2, 4)):
+            v1, v2 = synthetic_views(B, H, W, seed=0, device=dev)
+            for _ in range(4):
+                model(v1, v2)
+            torch.cuda.synchronize()
+            n = 20 if B <= 8 else 5
+            t = time.perf_counter()
+            for _ in range(n):
+                model(v1, v2)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / n
+            print(f"forward B={B:2d} {'graph replay' if graphs else 'eager       '}: {dt * 1e3:8.2f} ms/call  {B / dt:7.1f} pairs/s", flush=True)
+    if 'forward-only' in sys.argv:
+        return
     del model
     from dust3r_amd.cloud_opt import global_aligner
     from dust3r_amd.cloud_opt.base_opt import global_alignment_loop
