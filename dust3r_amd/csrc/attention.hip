@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
 //   * PV of tile t (24 MFMAs) carries the fp16 hi / lo split of P: group g + 1 is split under the MFMAs of group g.
 //   * program order alternates one MFMA with a handful of VALU instructions (sched_group_barrier): an in-order wave cannot
 //     issue past an MFMA that waits for the matrix pipe, so a burst of MFMAs followed by a burst of VALU serialises the two.
-//   * the lane <-> lane + 32 exchange of the row maximum is v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip
+//   * the lane <-> lane + 32 exchange of the row maximum is v_permlane32_swap (VALU, inline asm) instead of ds_bpermute (an LDS round trip
 //     in the middle of the softmax); V^T tiles sit in LDS as a hi plane and a lo plane per row, so that one ds_read2_b64 returns a
 //     whole MFMA operand (the interleaved [hi x8][lo x8] image cost 52 v_mov per tile to regroup); packed fp32 math for the
 //     exponent argument, the row sum and the rescale.
@@ -273,13 +273,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4b_t __attribute__((ext_vector_type(4)));
 
+// v_permlane32_swap_b32 a, b exchanges lanes 32-63 of a with lanes 0-31 of b: with a = b = v on entry, a holds v[lane & 31] and b holds
+// v[32 + (lane & 31)] in every lane afterwards, i.e. {a, b} = {v[l], v[l ^ 32]} in some order. Issued from inline asm: hipcc 7.2's
+// __builtin_amdgcn_permlane32_swap returns its FIRST result in both elements (measured: fmaxf(r[0], r[1]) compiles to a move of r[0]),
+// which made the two lane halves of a query disagree on the running maximum. s_nop 1: a VALU-written VGPR needs wait states before a
+// permlane reads it, and the assembler does not see inside the asm.
+D3R_DEV void xor32_pair(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
 D3R_DEV float xor32_max(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));   // {v[l], v[l ^ 32]} in every lane
+    float a, b;
+    xor32_pair(v, a, b);
+    return fmaxf(a, b);
 }
 D3R_DEV float xor32_sum(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    float a, b;
+    xor32_pair(v, a, b);
+    return a + b;
 }
 
 template <int ODT>

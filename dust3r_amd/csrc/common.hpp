@@ -112,25 +112,22 @@ template <> struct Traits<D3R_F16X3> {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a), h8(bl), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a), h8(b), acc, 0, 0, 0);
     }
-    // split two floats into packed (hi, hi) and (lo, lo) fp16 pairs; inputs saturate at the fp16 range
-    D3R_DEV static void split2(float x, float y, uint32_t& hi, uint32_t& lo) {
-        typedef __attribute__((ext_vector_type(2))) _Float16 v2;
-        x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);   // one v_med3_f32 (fminf(fmaxf()) costs two canonicalising v_max on top)
-        y = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
-        const _Float16 hx = (_Float16)x, hy = (_Float16)y;
-        v2 h = {hx, hy};
-        v2 l = {(_Float16)(x - (float)hx), (_Float16)(y - (float)hy)};
+    // split two floats into packed (hi, hi) and (lo, lo) fp16 pairs; inputs saturate at the fp16 range. Written on 2-vectors so that hipcc
+    // emits the packed forms (v_cvt_pk_f16_f32, v_pk_add_f32 with a negated operand: 5 VALU per pair instead of 8); same roundings.
+    typedef float v2f_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 v2h_t __attribute__((ext_vector_type(2)));
+    D3R_DEV static void split2_inrange(float x, float y, uint32_t& hi, uint32_t& lo) {
+        const v2f_t xv = {x, y};
+        const v2h_t h = __builtin_convertvector(xv, v2h_t);
+        const v2f_t d = xv - __builtin_convertvector(h, v2f_t);
+        const v2h_t l = __builtin_convertvector(d, v2h_t);
         hi = __builtin_bit_cast(uint32_t, h);
         lo = __builtin_bit_cast(uint32_t, l);
     }
-    // the same without the range clamps, for values known to lie inside the fp16 range (softmax probabilities)
-    D3R_DEV static void split2_inrange(float x, float y, uint32_t& hi, uint32_t& lo) {
-        typedef __attribute__((ext_vector_type(2))) _Float16 v2;
-        const _Float16 hx = (_Float16)x, hy = (_Float16)y;
-        v2 h = {hx, hy};
-        v2 l = {(_Float16)(x - (float)hx), (_Float16)(y - (float)hy)};
-        hi = __builtin_bit_cast(uint32_t, h);
-        lo = __builtin_bit_cast(uint32_t, l);
+    D3R_DEV static void split2(float x, float y, uint32_t& hi, uint32_t& lo) {
+        x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);   // one v_med3_f32 (fminf(fmaxf()) costs two canonicalising v_max on top)
+        y = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
+        split2_inrange(x, y, hi, lo);
     }
     D3R_DEV static float join_lo(uint32_t hi, uint32_t lo) {
         return (float)__builtin_bit_cast(_Float16, (uint16_t)(hi & 0xFFFFu)) + (float)__builtin_bit_cast(_Float16, (uint16_t)(lo & 0xFFFFu));
@@ -365,6 +362,39 @@ D3R_DEV float erf_as(float x) {
 template <int DT> D3R_DEV float gelu(float x) {
     if constexpr (DT == D3R_F32) return gelu_erf(x);
     else return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+}
+// Two GELUs on packed fp32 (v_pk_mul / v_pk_fma: two lanes' worth per issue slot): the epilogue of fc1 runs 128 times per lane per 256 x 256
+// tile and is VALU-bound (15 us of an 85 us tile in round 2). Same erf approximation as erf_as (Abramowitz-Stegun 7.1.26), rearranged so that
+// no sign has to be copied: gelu(x) = x/2 + |x|/2 erf(|x| / sqrt 2), erf(|z|) = 1 - poly(t) exp(-z^2), t = 1 / (1 + p |z|).
+typedef float d3r_v2f_t __attribute__((ext_vector_type(2)));
+D3R_DEV d3r_v2f_t gelu_pk(d3r_v2f_t x) {
+    typedef d3r_v2f_t v2;
+    const v2 z = x * (v2){0.70710678118654752440f, 0.70710678118654752440f};
+    v2 az;
+    az[0] = fabsf(z[0]); az[1] = fabsf(z[1]);
+    const v2 d = __builtin_elementwise_fma(az, (v2){0.3275911f, 0.3275911f}, (v2){1.0f, 1.0f});
+    v2 t;
+    t[0] = __builtin_amdgcn_rcpf(d[0]); t[1] = __builtin_amdgcn_rcpf(d[1]);
+    v2 poly = __builtin_elementwise_fma(t, (v2){1.061405429f, 1.061405429f}, (v2){-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(poly, t, (v2){1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(poly, t, (v2){-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(poly, t, (v2){0.254829592f, 0.254829592f});
+    poly = poly * t;
+    const v2 e2 = (az * (v2){-1.44269504088896340736f, -1.44269504088896340736f}) * az;
+    v2 ex;
+    ex[0] = __builtin_amdgcn_exp2f(e2[0]); ex[1] = __builtin_amdgcn_exp2f(e2[1]);
+    const v2 r = __builtin_elementwise_fma(-poly, ex, (v2){1.0f, 1.0f});          // erf(|z|) >= 0
+    const v2 h = x * (v2){0.5f, 0.5f};
+    return __builtin_elementwise_fma(az * (v2){0.70710678118654752440f, 0.70710678118654752440f}, r, h);   // |x| / 2 = |z| / sqrt 2
+}
+// four accumulator values at once (what every epilogue holds per fragment): exact erf for the fp32 mode, the packed form otherwise
+template <int DT> D3R_DEV void gelu4(float& v0, float& v1, float& v2, float& v3) {
+    if constexpr (DT == D3R_F32) {
+        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+    } else {
+        const d3r_v2f_t a = gelu_pk((d3r_v2f_t){v0, v1}), b = gelu_pk((d3r_v2f_t){v2, v3});
+        v0 = a[0]; v1 = a[1]; v2 = b[0]; v3 = b[1];
+    }
 }
 
 // XCD-aware bijective block remap (8 XCDs, block b runs on XCD b % 8): gives each XCD a

@@ -98,7 +98,7 @@ struct d3r_model {
     struct GraphEntry { GraphKey key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int seen = 0; float* io = nullptr; size_t io_bytes = 0; };
     std::vector<GraphEntry> graphs;
     hipStream_t cap = nullptr;              // capture origin (the legacy default stream cannot be captured)
-    int graph_max_pairs = 4;                // D3R_MODEL_OPT_GRAPH_MAX_PAIRS; 0 = off
+    int graph_max_pairs = 0;                // D3R_MODEL_OPT_GRAPH_MAX_PAIRS; 0 = off (default: measured no latency gain on MI355X, see the header)
     long graph_replays = 0;                 // statistics (tests)
     void drop_graphs() {
         for (auto& g : graphs) {

@@ -897,7 +897,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
 #pragma unroll
                         for (int fl = 0; fl < 4; ++fl) {
                             float v0 = vals[fl][0], v1 = vals[fl][1], v2 = vals[fl][2], v3 = vals[fl][3];
-                            if (p.epi == EPI_GELU) { v0 = gelu<DT>(v0); v1 = gelu<DT>(v1); v2 = gelu<DT>(v2); v3 = gelu<DT>(v3); }
+                            if (p.epi == EPI_GELU) gelu4<DT>(v0, v1, v2, v3);
                             if (p.flags & GF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                             uint2 pk;
                             pk.x = TR::pack2(v0, v1);
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                             for (int fl = 0; fl < 4; ++fl) {
                                 const f32x4_t a = acc[g * 4 + fl][fj];
                                 float v0 = a[0] + bq[fl].x, v1 = a[1] + bq[fl].y, v2 = a[2] + bq[fl].z, v3 = a[3] + bq[fl].w;
-                                if (p.epi == EPI_GELU) { v0 = gelu<DT>(v0); v1 = gelu<DT>(v1); v2 = gelu<DT>(v2); v3 = gelu<DT>(v3); }
+                                if (p.epi == EPI_GELU) gelu4<DT>(v0, v1, v2, v3);
                                 if (p.flags & GF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                                 uint2 hh; uint32_t a8, b8;
                                 TF::enc4<false>(v0, v1, v2, v3, hh, a8, b8);
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
 #pragma unroll
                         for (int fl = 0; fl < 2; ++fl) {
                             float v0 = vals[fl][0], v1 = vals[fl][1], v2 = vals[fl][2], v3 = vals[fl][3];
-                            if (p.epi == EPI_GELU) { v0 = gelu<DT>(v0); v1 = gelu<DT>(v1); v2 = gelu<DT>(v2); v3 = gelu<DT>(v3); }
+                            if (p.epi == EPI_GELU) gelu4<DT>(v0, v1, v2, v3);
                             if (p.flags & GF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                             uint2 hh, ll;
                             TX::split2(v0, v1, hh.x, ll.x);
@@ -1232,7 +1232,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                         *reinterpret_cast<float4*>(o) = make_float4(v0, v1, v2, v3);
                         if (p.out2) store4<O2DT>(p.out2, (size_t)m * p.ldo2 + n, v0, v1, v2, v3);
                     } else {
-                        if (p.epi == EPI_GELU) { v0 = gelu<DT>(v0); v1 = gelu<DT>(v1); v2 = gelu<DT>(v2); v3 = gelu<DT>(v3); }
+                        if (p.epi == EPI_GELU) gelu4<DT>(v0, v1, v2, v3);
                         if (p.flags & GF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                         store4<DT>(p.out, (size_t)m * p.ldo + n, v0, v1, v2, v3);
                     }
@@ -1249,7 +1249,8 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                         if (p.out2) store4<O2DT>(p.out2, (size_t)m * p.ldo2 + n, v0, v1, v2, v3);
                     } break;
                     case EPI_GELU:
-                        store4<DT>(p.out, (size_t)m * p.ldo + n, gelu<DT>(v0), gelu<DT>(v1), gelu<DT>(v2), gelu<DT>(v3));
+                        gelu4<DT>(v0, v1, v2, v3);
+                        store4<DT>(p.out, (size_t)m * p.ldo + n, v0, v1, v2, v3);
                         break;
                     case EPI_CONVT: {
                         // ConvTranspose2d(k == stride): column n = (tap, co); row m = input pixel
@@ -1336,8 +1337,10 @@ template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hi
     const int grid = cdiv(p.M, CF::BM) * cdiv(p.n_store, CF::BN);
     GemmParams q = p;
     {   // first-round stagger (see the kernel): spread = factor x (epilogue bytes of the resident tiles / ~4.5 TB/s)
-        static const float factor = [] { const char* e = getenv("D3R_GEMM_STAGGER"); return e ? (float)atof(e) : 0.0f; }();   // default off: measured no gain (profiles/README.md), costs half a burst per launch
-        static const int mode = [] { const char* e = getenv("D3R_GEMM_STAGGER_MODE"); return e ? atoi(e) : 0; }();
+        const char* e_st = getenv("D3R_GEMM_STAGGER");       // default off: measured no gain (profiles/README.md), costs half a burst per launch; read per launch (probes toggle it)
+        const float factor = e_st ? (float)atof(e_st) : 0.0f;
+        const char* e_sm = getenv("D3R_GEMM_STAGGER_MODE");
+        const int mode = e_sm ? atoi(e_sm) : 0;
         static const DevInfo dev = dev_info();
         const int resident = dev.cus * (CF::LDS * 2 <= 160 * 1024 ? 2 : 1);
         if (factor > 0.f && grid > resident && !(p.flags & GF_NOSTORE)) {

@@ -168,11 +168,13 @@ size_t d3r_model_device_bytes(const d3r_model* m);
 #define D3R_MODEL_OPT_PROFILE 1
 #define D3R_MODEL_OPT_TWO_STREAMS 2 /* 1 (default): decoder side 2 and head 2 run on an engine-owned second HIP stream, joined back
                                      * into the caller's stream before d3r_model_forward's work completes; 0: everything on the caller's stream */
-#define D3R_MODEL_OPT_GRAPH_MAX_PAIRS 3 /* whole forwards (d3r_model_forward / _mixed / _packed) of at most this many pairs are replayed as a hipGraph
+#define D3R_MODEL_OPT_GRAPH_MAX_PAIRS 3 /* n > 0: whole forwards (d3r_model_forward / _mixed / _packed) of at most n pairs are replayed as a hipGraph
                                          * from the third call with the same (B, image sizes, output layout) on: ~700 launches become one
-                                         * graph launch + input / output copies through engine-owned staging buffers (bit-identical results;
-                                         * one pair per call is what dust3r/demo.py:156 and visloc.py:88 ask for). Default 4
-                                         * (D3R_GRAPH_MAX_PAIRS at create); 0 switches the replay off and drops the captured graphs */
+                                         * graph launch + input / output copies through engine-owned staging buffers (bit-identical results).
+                                         * DEFAULT 0 = off (or D3R_GRAPH_MAX_PAIRS at create): measured on MI355X, one 512x384 pair per call
+                                         * takes 14.83 ms replayed vs 14.86 ms eager -- the one-pair forward is bound by the dependent chain of
+                                         * ~700 partially filled kernels on the GPU, not by the host's launch rate (profiles/r03_a/latency.log);
+                                         * the replay only frees the host thread. 0 also drops the captured graphs */
 int d3r_model_set_option(d3r_model* m, int option, int value);
 int d3r_model_profile_read(d3r_model* m, int kind, int* launches, double* ms, double* work);
 /* launch `index` of the last profiled forward: class, GEMM shape (attention: batch*heads, queries, keys), ms, flops;

@@ -94,31 +94,55 @@ def gemmtrace_probe():
 
         def run():
             check(lib.d3r_linear(ptr(a), ptr(w), ptr(b), ptr(out), ptr(res), M, N, K, epi, dtc, current_stream()))
-        for _ in range(2):
+
+        def traced(tag):
+            for _ in range(2):
+                run()
+            ms = timeit(run, warm=1, reps=5)
+            buf.zero_()
+            check(lib.d3r_gemm_set_trace(ptr(buf), nblk))
             run()
-        ms = timeit(run, warm=1, reps=5)
-        check(lib.d3r_gemm_set_trace(ptr(buf), nblk))
-        run()
-        torch.cuda.synchronize()
-        check(lib.d3r_gemm_set_trace(None, 0))
-        t = buf.cpu().numpy()
-        t = t[t[:, 0] > 0]
-        us = lambda x: x / rate * 1e6  # noqa: E731
-        pro, kl, ep, dr = us(t[:, 1] - t[:, 0]), us(t[:, 2] - t[:, 1]), us(t[:, 3] - t[:, 2]), us(t[:, 4] - t[:, 3])
-        span = us(t[:, 4].max() - t[:, 0].min())
-        # per CU: (xcc, se, cu) from XCC_ID / HW_ID; gap between consecutive blocks on the same CU
-        hw, xcc = t[:, 5], t[:, 6] & 0xF
-        cu_key = (xcc << 16) | (hw & 0xFF00)            # se_id[15:13] sh_id[12] cu_id[11:8]
-        gaps = []
-        for key in np.unique(cu_key):
-            sel = t[cu_key == key]
-            sel = sel[np.argsort(sel[:, 0])]
-            if len(sel) > 1:
-                gaps.extend(us(sel[1:, 0] - sel[:-1, 4]))
-        gaps = np.array(gaps) if gaps else np.zeros(1)
-        print(f'  {name:28s} M={M} N={N} K={K}: {ms:.3f} ms = {2 * M * N * K / ms / 1e9:6.1f} TF/s; {len(t)} blocks on {len(np.unique(cu_key))} CUs, traced span {span:.0f} us')
-        print(f'      per block (mean / p90 us): prologue {pro.mean():5.1f} / {np.percentile(pro, 90):5.1f}   K loop {kl.mean():6.1f} / {np.percentile(kl, 90):6.1f}   '
-              f'epilogue {ep.mean():5.1f} / {np.percentile(ep, 90):5.1f}   drain {dr.mean():5.1f} / {np.percentile(dr, 90):5.1f}   gap to next block on the CU {gaps.mean():5.1f} / {np.percentile(gaps, 90):5.1f}')
+            torch.cuda.synchronize()
+            check(lib.d3r_gemm_set_trace(None, 0))
+            t = buf.cpu().numpy()
+            t = t[t[:, 0] > 0]
+            us = lambda x: x / rate * 1e6  # noqa: E731
+            pro, kl, ep, dr = us(t[:, 1] - t[:, 0]), us(t[:, 2] - t[:, 1]), us(t[:, 3] - t[:, 2]), us(t[:, 4] - t[:, 3])
+            span = us(t[:, 4].max() - t[:, 0].min())
+            # per CU: (xcc, se, cu) from XCC_ID / HW_ID; gap between consecutive blocks on the same CU; "round" = position in the CU's sequence
+            hw, xcc = t[:, 5], t[:, 6] & 0xF
+            cu_key = (xcc << 16) | (hw & 0xFF00)            # se_id[15:13] sh_id[12] cu_id[11:8]
+            gaps, rnd = [], np.zeros(len(t), dtype=np.int64)
+            for key in np.unique(cu_key):
+                idx = np.where(cu_key == key)[0]
+                idx = idx[np.argsort(t[idx, 0])]
+                rnd[idx] = np.arange(len(idx))
+                if len(idx) > 1:
+                    gaps.extend(us(t[idx[1:], 0] - t[idx[:-1], 4]))
+            gaps = np.array(gaps) if gaps else np.zeros(1)
+            print(f'  {name:28s} [{tag}] M={M} N={N} K={K}: {ms:.3f} ms = {2 * M * N * K / ms / 1e9:6.1f} TF/s; {len(t)} blocks on {len(np.unique(cu_key))} CUs, traced span {span:.0f} us')
+            print(f'      per block (mean / p90 us): prologue {pro.mean():5.1f} / {np.percentile(pro, 90):5.1f}   K loop {kl.mean():6.1f} / {np.percentile(kl, 90):6.1f}   '
+                  f'epilogue {ep.mean():5.1f} / {np.percentile(ep, 90):5.1f}   drain {dr.mean():5.1f} / {np.percentile(dr, 90):5.1f}   gap to next block on the CU {gaps.mean():5.1f} / {np.percentile(gaps, 90):5.1f}')
+            # does a tile's K loop run slower when it starts behind other tiles' epilogue traffic? K loop / epilogue by position on the CU,
+            # and the spread of epilogue start times inside a round (lockstep = all CUs store at once)
+            nr = int(rnd.max()) + 1
+            rows = []
+            for r in range(min(nr, 6)):
+                sel = rnd == r
+                rows.append(f'r{r}: K {kl[sel].mean():6.1f} epi {ep[sel].mean():5.1f} epi-start spread {us(np.percentile(t[sel, 2], 90) - np.percentile(t[sel, 2], 10)):6.1f}')
+            print('      by position on the CU (us): ' + ' | '.join(rows))
+        traced('random operands')
+        if os.environ.get('D3R_PROBE_EXTRA', '1') == '1':
+            os.environ['D3R_GEMM_NOSTORE'] = '1'
+            traced('same, epilogue skipped (D3R_GEMM_NOSTORE)')
+            os.environ.pop('D3R_GEMM_NOSTORE')
+            a.zero_()
+            traced('activation operand all zero (data-dependent MFMA power)')
+            if not f8:
+                a.copy_(ops.pack_x3(torch.randn((M, K), device=dev)))
+            os.environ['D3R_GEMM_STAGGER'] = '1.0'
+            traced('first-round stagger 1.0')
+            os.environ.pop('D3R_GEMM_STAGGER')
         del a, w, out, buf
 
 
