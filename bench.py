@@ -55,7 +55,8 @@ def build_model(precision, device):
 
 
 GEMM_CFG_NAMES = {0: 'GemmCfg<2,2,4,4,2,128,2> (128x128 tile)', 1: 'GemmCfg<2,4,8,4,2,128,2> (256x256 tile)', 2: 'GemmCfg<2,4,4,4,2,128,2> (256x128 tile)',
-                  3: 'GemmCfg<1,8,8,4,2,128,2> (512x128 tile)', 4: 'GemmCfg<1,4,8,4,2,64,3> (256x128, 4 waves)', 5: 'GemmCfg<2,4,8,4,2,64,4> (256x256, 4 stages)', 6: 'GemmCfg<2,4,8,4,2,64,4,1> (256x256, ping-pong)'}
+                  3: 'GemmCfg<1,8,8,4,2,128,2> (512x128 tile)', 4: 'GemmCfg<1,4,8,4,2,64,3> (256x128, 4 waves)', 5: 'GemmCfg<2,4,8,4,2,64,4> (256x256, 4 stages)', 6: 'GemmCfg<2,4,8,4,2,64,4,1> (256x256, ping-pong)',
+                  7: 'GemmCfg<1,4,8,4,2,128,2,6> (256x128 tile, 4 waves, weights of a K step in registers, 2 blocks / CU)'}
 
 
 def read_profile(model):

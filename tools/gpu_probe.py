@@ -132,6 +132,10 @@ def gemmtrace_probe():
                 rows.append(f'r{r}: K {kl[sel].mean():6.1f} epi {ep[sel].mean():5.1f} epi-start spread {us(np.percentile(t[sel, 2], 90) - np.percentile(t[sel, 2], 10)):6.1f}')
             print('      by position on the CU (us): ' + ' | '.join(rows))
         traced('random operands')
+        if not f8:
+            os.environ['D3R_GEMM_CFG'] = '7'
+            traced('cfg 7: 256x128, weights in registers, 2 blocks / CU')
+            os.environ.pop('D3R_GEMM_CFG')
         if os.environ.get('D3R_PROBE_EXTRA', '1') == '1':
             os.environ['D3R_GEMM_NOSTORE'] = '1'
             traced('same, epilogue skipped (D3R_GEMM_NOSTORE)')

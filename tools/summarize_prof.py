@@ -81,7 +81,8 @@ CFG_OF = {(2, 2, 4, 4, 2, 128, 2, 0): 0, (2, 4, 8, 4, 2, 128, 2, 0): 1, (2, 4, 4
           (2, 2, 4, 4, 2, 128, 2): 0, (2, 4, 8, 4, 2, 128, 2): 1, (2, 4, 4, 4, 2, 128, 2): 2, (1, 8, 8, 4, 2, 128, 2): 3,
           (1, 4, 8, 4, 2, 64, 3): 4, (2, 4, 8, 4, 2, 64, 4): 5, (2, 4, 8, 4, 2, 64, 4, 1): 6,
           # fp16 + fp8 rows, DMA pieces interleaved with the MFMA rows (PP = 4)
-          (2, 2, 4, 4, 2, 128, 2, 4): 0, (2, 4, 8, 4, 2, 128, 2, 4): 1, (2, 4, 4, 4, 2, 128, 2, 4): 2, (1, 8, 8, 4, 2, 128, 2, 4): 3}
+          (2, 2, 4, 4, 2, 128, 2, 4): 0, (2, 4, 8, 4, 2, 128, 2, 4): 1, (2, 4, 4, 4, 2, 128, 2, 4): 2, (1, 8, 8, 4, 2, 128, 2, 4): 3,
+          (1, 4, 8, 4, 2, 128, 2, 6): 7}
 
 
 def pmc_means(tag, counter):
