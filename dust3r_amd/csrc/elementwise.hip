@@ -261,11 +261,99 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const void* __restrict_
         }
     }
 }
+// x2 bilinear upsampling, a 2 x 2 block of output pixels x 8 channels per thread (round 3). The one-pixel kernel above issues 8 sixteen-byte
+// loads per 2-4 stores and is bound by the CU's vector-memory issue path, not by HBM (2.7 TB/s on the 4 GB the head's last stage moves;
+// waves waiting to issue 77 % of their cycles, profiles/r03_b/prof_summary.txt). With align_corners = True the source coordinate of output
+// index o is o (n - 1) / (2 n - 1): outputs 2 c and 2 c + 1 need input columns {x0, x0 + 1} and {x0', x0' + 1} with x0' = x0 or x0 + 1, so a
+// 2 x 2 output block reads a 3 x 3 input neighbourhood: 18 loads per 8 stores instead of 32 per 8. Every output pixel is evaluated with the
+// expression of the one-pixel kernel (rows interpolated along x, then along y).
+template <int DT, bool NT>
+__global__ __launch_bounds__(256) void upsample2x_quad_kernel(const void* __restrict__ in, void* __restrict__ out, void* __restrict__ out_relu,
+                                                              int Hi, int Wi, int C, int cstride, int Ho, int Wo) {
+    const int cn = C / 8;
+    const int hp = (Ho + 1) / 2, wp = (Wo + 1) / 2;
+    const int b = blockIdx.x / hp, r = blockIdx.x - b * hp;
+    const float sh = Hi > 1 ? (float)(Hi - 1) / (float)(2 * Hi - 1) : 0.f;
+    const float sw = Wi > 1 ? (float)(Wi - 1) / (float)(2 * Wi - 1) : 0.f;
+    // the two output rows of this block
+    const int oyA = 2 * r, oyB = min(2 * r + 1, Ho - 1);
+    const float fyA = sh * (float)oyA, fyB = sh * (float)oyB;
+    const int yb = (int)fyA, y0B = (int)fyB;
+    const float lyA = fyA - (float)yb, hyA = 1.f - lyA, lyB = fyB - (float)y0B, hyB = 1.f - lyB;
+    const bool offY = y0B > yb;                                   // row B starts one input row further down
+    const int ry0 = yb, ry1 = min(yb + 1, Hi - 1), ry2 = min(yb + 2, Hi - 1);
+    const size_t row[3] = {((size_t)b * Hi + ry0) * Wi, ((size_t)b * Hi + ry1) * Wi, ((size_t)b * Hi + ry2) * Wi};
+    const size_t orowA = ((size_t)b * Ho + oyA) * Wo, orowB = ((size_t)b * Ho + oyB) * Wo;
+    const bool haveB = 2 * r + 1 < Ho;
+    const int items = wp * cn;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int cpair = i / cn, c = (i - cpair * cn) * 8;
+        const int oxA = 2 * cpair, oxB = min(2 * cpair + 1, Wo - 1);
+        const float fxA = sw * (float)oxA, fxB = sw * (float)oxB;
+        const int xb = (int)fxA, x0B = (int)fxB;
+        const float lxA = fxA - (float)xb, hxA = 1.f - lxA, lxB = fxB - (float)x0B, hxB = 1.f - lxB;
+        const bool offX = x0B > xb;
+        const int cx0 = xb, cx1 = min(xb + 1, Wi - 1), cx2 = min(xb + 2, Wi - 1);
+        // rows interpolated along x at the two output columns: hA[r][k], hB[r][k]
+        float hA[3][8], hB[3][8];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            float v0[8], v1[8], v2[8];
+            load8<DT>(in, (row[rr] + cx0) * (size_t)cstride + c, v0);
+            load8<DT>(in, (row[rr] + cx1) * (size_t)cstride + c, v1);
+            load8<DT>(in, (row[rr] + cx2) * (size_t)cstride + c, v2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                hA[rr][k] = hxA * v0[k] + lxA * v1[k];
+                const float b0 = offX ? v1[k] : v0[k], b1 = offX ? v2[k] : v1[k];
+                hB[rr][k] = hxB * b0 + lxB * b1;
+            }
+        }
+        float oAA[8], oAB[8], oBA[8], oBB[8];      // (row, column)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            oAA[k] = hyA * hA[0][k] + lyA * hA[1][k];
+            oAB[k] = hyA * hB[0][k] + lyA * hB[1][k];
+            const float a0 = offY ? hA[1][k] : hA[0][k], a1 = offY ? hA[2][k] : hA[1][k];
+            const float b0 = offY ? hB[1][k] : hB[0][k], b1 = offY ? hB[2][k] : hB[1][k];
+            oBA[k] = hyB * a0 + lyB * a1;
+            oBB[k] = hyB * b0 + lyB * b1;
+        }
+        const bool haveXB = 2 * cpair + 1 < Wo;
+        auto put = [&](size_t orow, int ox, const float (&o)[8]) __attribute__((always_inline)) {
+            const size_t oo = (orow + ox) * (size_t)cstride + c;
+            float orl[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) orl[k] = fmaxf(o[k], 0.f);
+            if constexpr (NT && DT == D3R_F16X3) {
+                store8_x3_nt(out, oo, o);
+                if (out_relu) store8_x3_nt(out_relu, oo, orl);
+            } else {
+                store8<DT>(out, oo, o);
+                if (out_relu) store8<DT>(out_relu, oo, orl);
+            }
+        };
+        put(orowA, oxA, oAA);
+        if (haveXB) put(orowA, oxB, oAB);
+        if (haveB) {
+            put(orowB, oxA, oBA);
+            if (haveXB) put(orowB, oxB, oBB);
+        }
+    }
+}
+
 template <int DT> static void launch_upsample_t(const void* in, void* out, void* out_relu, int B, int Hi, int Wi, int C, int cstride, int Ho, int Wo,
                                                 hipStream_t s) {
     // non-temporal stores of the x2 maps: measured 13.41 -> 12.75 ms of "other" kernels per step, forward 218.7 -> 219.6 pairs/s
     // (profiles/r02_f8/bench_upsample_nt.log); D3R_UPSAMPLE_NT=0: plain stores
     static const bool nt = [] { const char* e = getenv("D3R_UPSAMPLE_NT"); return e ? e[0] != '0' : true; }();
+    const char* e_v1 = getenv("D3R_UPSAMPLE_V1");            // 1: the one-output-pixel-per-thread kernel (A/B, parity tests); read per launch
+    if (!(e_v1 && e_v1[0] == '1') && C % 8 == 0 && cstride % 8 == 0) {
+        const int blocks = B * ((Ho + 1) / 2);
+        if (DT == D3R_F16X3 && nt) hipLaunchKernelGGL((upsample2x_quad_kernel<DT, true>), dim3(blocks), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);
+        else hipLaunchKernelGGL((upsample2x_quad_kernel<DT, false>), dim3(blocks), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);
+        return;
+    }
     if (DT == D3R_F16X3 && nt && C % 8 == 0 && cstride % 8 == 0)
         hipLaunchKernelGGL((upsample2x_kernel<DT, 2, true>), dim3(B * Ho), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);
     else if (C % 8 == 0 && cstride % 8 == 0) hipLaunchKernelGGL((upsample2x_kernel<DT, 2>), dim3(B * Ho), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);

@@ -1473,10 +1473,16 @@ int gemm_pick_config(const GemmParams& p, int dt) {
         return GEMM_CFG_128;
     }
     // split-fp16, launches without attention heads (their V^T regions need a square tile): the two-blocks-per-CU 256 x 128 shape with the
-    // weights of a K step in registers, from a round of resident blocks on. D3R_GEMM_R=0 / 1 (default: see launch_t / profiles/README.md)
+    // weights of a K step in registers. Measured on MI355X (profiles/r03_c/gemmtrace_cfg7.log, bench_r*.log): it wins where the epilogue
+    // is an HBM burst that the other block's MFMAs can run under -- the fp32-residual projections at K <= 1024 (proj 49152 x 1024 x
+    // 1024: 337 vs 296 TFLOP/s) -- and loses 1-6 % where the epilogue is VALU work (GELU, typed stores: on gfx950 VALU and MFMA of a
+    // SIMD overlap only by half, tools/issue_probe.hip) or the K loop dominates (fc2): default = those projections only.
+    // D3R_GEMM_R=0: never; =1: every eligible launch (the A/B of the round).
     if (dt == D3R_F16X3 && !heads && p.epi != EPI_HEADS && p.n_store > 128) {
-        static const int r_on = [] { const char* e = getenv("D3R_GEMM_R"); return e ? atoi(e) : 0; }();
-        if (r_on && (long)cdiv(p.M, 256) * cdiv(p.n_store, 128) >= 512) return GEMM_CFG_256x128R;
+        static const int r_on = [] { const char* e = getenv("D3R_GEMM_R"); return e ? atoi(e) : -1; }();
+        const long tiles = (long)cdiv(p.M, 256) * cdiv(p.n_store, 128);
+        if (r_on == 1 && tiles >= 512) return GEMM_CFG_256x128R;
+        if (r_on < 0 && p.epi == EPI_F32 && p.res1 != nullptr && p.K <= 1024 && p.amode == AMODE_LINEAR && tiles >= 1024) return GEMM_CFG_256x128R;
     }
     const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.n_store, 256);
     // fp16 + fp8 rows: the 256-wide tile is 1.3-1.6x ahead of the 128 x 128 one per tile (its K loop lost a third of its MFMA work, the small

@@ -87,6 +87,17 @@ def linear_x3(act, weight, bias=None, epilogue='store', residual=None):
     return out if epi == 1 else unpack_x3(out)
 
 
+def upsample2x_x3(x, out_hw=None):
+    """`upsample2x_nhwc` on split-fp16 maps: x (B,H,W,C) fp32, C % 8 == 0, packed along the channel axis; fp32 result."""
+    _lib.require_device()
+    B, H, W, Cc = x.shape
+    Ho, Wo = out_hw if out_hw is not None else (2 * H, 2 * W)
+    xp = pack_x3(x)
+    out = torch.empty((B, Ho, Wo, 2 * Cc), dtype=torch.float16, device=x.device)
+    check(lib.d3r_upsample2x_nhwc(ptr(xp), ptr(out), B, H, W, Cc, Ho, Wo, _lib.DTYPE_F16X3, current_stream()), 'upsample2x(x3)')
+    return unpack_x3(out)
+
+
 def _e4m3(x):
     """Round to OCP e4m3 (the encoding v_cvt_pk_fp8_f32 produces on gfx950: nearest even, subnormals kept), saturating at +-448
     as the kernels clamp before converting. Returns the bytes (uint8)."""

@@ -321,6 +321,24 @@ def test_upsample2x(gpu, dtype, B, H, W, C, crop):
     assert out.shape == ref.shape and relerr(out, ref) < OUT_TOL[dtype]
 
 
+@pytest.mark.parametrize('v1', ['0', '1'])
+@pytest.mark.parametrize('B,H,W,C,crop', [(2, 12, 16, 256, None), (1, 24, 32, 128, None), (2, 7, 5, 64, None), (1, 12, 16, 256, (24, 31)), (1, 9, 11, 8, (17, 22)),
+                                          (1, 1, 6, 16, None), (3, 6, 1, 16, None)])
+def test_upsample2x_split_fp16(gpu, v1, B, H, W, C, crop, monkeypatch):
+    """x2 bilinear (align_corners=True, crop like dpt_head.py:57) on split-fp16 maps, both kernels (D3R_UPSAMPLE_V1=1: one output pixel per
+    thread; default: a 2 x 2 output block per thread from its 3 x 3 input neighbourhood): fp32-class against torch, odd / cropped output
+    sizes (blocks with a missing second row or column), single-row and single-column inputs."""
+    from dust3r_amd import ops
+    monkeypatch.setenv('D3R_UPSAMPLE_V1', v1)
+    g = torch.Generator(device='cpu').manual_seed(H * W + C)
+    x = torch.randn((B, H, W, C), generator=g).to(gpu)
+    ref = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode='bilinear', align_corners=True).permute(0, 2, 3, 1)
+    if crop:
+        ref = ref[:, :crop[0], :crop[1]]
+    out = ops.upsample2x_x3(x, crop)
+    assert out.shape == ref.shape and relerr(out, ref) < 2e-6
+
+
 def test_find_reciprocal_matches_matches_kdtree(gpu):
     """dust3r_amd.utils.geometry.find_reciprocal_matches (exhaustive GPU scan) vs the reference's SciPy KD-tree formulation."""
     import numpy as np
