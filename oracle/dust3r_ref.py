@@ -205,7 +205,7 @@ def build_ref_model(config='DUSt3R_ViTLarge_BaseDecoder_512_dpt', seed=0, out_ga
     return model
 
 
-def build_ref_model_fast(config='DUSt3R_ViTLarge_BaseDecoder_512_dpt', out_gain=None):
+def build_ref_model_fast(config='DUSt3R_ViTLarge_BaseDecoder_512_dpt', out_gain=None, seed=0):
     """Timing-only construction of the full-size oracle (bench.py's cpu_baseline leg): the modules are created on the
     meta device and materialised once, then filled in place (N(0, 1/fan_in) matrices, unit LayerNorm weights, small
     biases) -- first-touch page faults of the 2.6 GB of parameters dominate the normal construction path in the
@@ -216,7 +216,7 @@ def build_ref_model_fast(config='DUSt3R_ViTLarge_BaseDecoder_512_dpt', out_gain=
     with torch.device('meta'):
         model = DUSt3RRef(**cfg)
     model = model.to_empty(device='cpu').eval()
-    g = torch.Generator().manual_seed(0)
+    g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in model.named_parameters():
             if p.ndim >= 2:
