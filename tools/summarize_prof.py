@@ -126,7 +126,7 @@ for name in names:
             digest['gemm_cfg'][str(cfg)] = entry
     elif 'aligner_main_kernel' in name:
         digest['aligner_main_kernel'] = entry
-    elif 'attention_kernel<' in name:
+    elif 'attention_kernel<' in name or 'attention_x3_kernel<' in name:
         digest['attention_kernel'] = entry
 if fetch or write:
     with open(os.path.join(out, 'pmc_latest.json'), 'w') as f:
