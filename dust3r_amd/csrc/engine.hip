@@ -324,7 +324,9 @@ struct Ctx {
     }
 };
 // profile record kinds: GEMM-kernel launches carry their tile configuration: kind = cfg (0..7) + 8 for implicit-GEMM convolution
-enum { PRF_GEMM = 0, PRF_CONV = 8, PRF_ATTN = 16, PRF_OTHER = 17, PRF_END = 18, PRF_GEMM_F8 = 24 };   // 24..31: fp16 + fp8 linear launches by tile configuration
+enum { PRF_GEMM = 0, PRF_CONV = 8, PRF_ATTN = 16, PRF_OTHER = 17, PRF_GEMM_64 = 18, PRF_CONV_64 = 19, PRF_END = 20, PRF_GEMM_F8 = 24 };   // 24..31: fp16 + fp8 linear launches by tile configuration
+// tile configuration 8 (the 64 x 64 tile of the small-batch forwards, split-fp16 only) has its own two kinds behind the 0..7 ranges
+static inline int prf_kind(int base, int cfg) { return cfg == GEMM_CFG_64 ? (base == PRF_CONV ? PRF_CONV_64 : PRF_GEMM_64) : base + cfg; }
 #define D3R_OTHER(call) do { c.mark(PRF_OTHER, 0.0); c.chk(call); } while (0)
 
 void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi, void* out, int ldo, const void* res1 = nullptr,
@@ -333,7 +335,7 @@ void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi,
     p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_rows = L.n_rows;
     p.n_store = n_store >= 0 ? n_store : L.N;
     p.epi = epi; p.out = out; p.ldo = ldo; p.res1 = res1; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo2; p.flags = flags;
-    c.mark((L.dt == D3R_F16F8 ? PRF_GEMM_F8 : PRF_GEMM) + gemm_pick_config(p, L.dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
+    c.mark(prf_kind(L.dt == D3R_F16F8 ? PRF_GEMM_F8 : PRF_GEMM, gemm_pick_config(p, L.dt)), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(L.dt, p, c.st));
 }
 
@@ -344,7 +346,7 @@ void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_
     p.epi = EPI_HEADS; p.head_c = head_c;
     for (int i = 0; i < nreg; ++i) { p.head_kind[i] = kinds[i]; p.head_dst[i] = dsts[i]; }
     p.heads = heads; p.ntok = ntok; p.tok_w = tok_w; p.ldv = ldv; p.rope_table = c.m->rope_table;
-    c.mark((L.dt == D3R_F16F8 ? PRF_GEMM_F8 : PRF_GEMM) + gemm_pick_config(p, L.dt), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
+    c.mark(prf_kind(L.dt == D3R_F16F8 ? PRF_GEMM_F8 : PRF_GEMM, gemm_pick_config(p, L.dt)), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(L.dt, p, c.st));
 }
 
@@ -357,7 +359,7 @@ void conv(Ctx& c, const void* in, int B, int Hin, int Win, int cstride, const Co
     p.M = B * p.Hout * p.Wout; p.K = w.K; p.n_pad = w.n_pad; p.n_rows = w.n_rows; p.n_store = n_store >= 0 ? n_store : w.Cout;
     p.zero_page = c.m->zero_page;
     p.epi = EPI_T; p.flags = flags; p.out = out; p.ldo = ldo; p.res1 = res1; p.res2 = res2; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo;
-    c.mark(PRF_CONV + gemm_pick_config(p, c.m->dt), 2.0 * p.M * (double)w.Cout * w.k * w.k * w.Cin, p.M, w.Cout, w.k * w.k * w.Cin);
+    c.mark(prf_kind(PRF_CONV, gemm_pick_config(p, c.m->dt)), 2.0 * p.M * (double)w.Cout * w.k * w.k * w.Cin, p.M, w.Cout, w.k * w.k * w.Cin);
     c.chk(launch_gemm(c.m->dt, p, c.st));
 }
 
@@ -568,7 +570,7 @@ void run_dpt(Ctx& c, const DptHead& D, Arena ar, const void* const hooks[4], con
             p.n_pad = D.convt[i].n_pad; p.n_rows = D.convt[i].n_rows; p.n_store = D.convt[i].N; p.epi = EPI_CONVT; p.ksize = D.convt_k[i]; p.ct_cout = D.convt_coutp[i];
             p.Hin = th; p.Win = tw; p.out = cmap[i]; p.ldo = D.cstride[i];
             const int ldi[2] = {96, 192};
-            c.mark(PRF_CONV + gemm_pick_config(p, m->dt), 2.0 * p.M * (double)(D.convt_k[i] * D.convt_k[i] * ldi[i]) * ldi[i], p.M, D.convt_k[i] * D.convt_k[i] * ldi[i], ldi[i]);
+            c.mark(prf_kind(PRF_CONV, gemm_pick_config(p, m->dt)), 2.0 * p.M * (double)(D.convt_k[i] * D.convt_k[i] * ldi[i]) * ldi[i], p.M, D.convt_k[i] * D.convt_k[i] * ldi[i], ldi[i]);
             c.chk(launch_gemm(m->dt, p, c.st));
         } else if (i == 3) {
             conv(c, t1, B, th, tw, D.cstride[3], D.act3conv, 2, 1, cmap[3], D.cstride[3], 0);

@@ -86,6 +86,15 @@ typedef GemmCfg<1, 4, 8, 4, 2, 128, 2, 6> Cfg256x128r;
 // (256 x 256 by FOUR waves of 128 x 128 -- 256 accumulator registers per lane, one wave per SIMD, a third less LDS read traffic per
 // MFMA -- compiles to 256 VGPR + 256 AGPR with the accumulator array in scratch: 90-105 TF/s algorithmic against 390-480, round 2.
 // With hipcc as the register allocator the 128 x 64 wave tile at two waves per SIMD is the largest that stays in registers.)
+// split-fp16, SMALL problems (round 3): 64 x 64 by four waves of 32 x 32 -- four times the waves of the 128 x 128 tile for the same
+// problem, so that the one-pair forward (M = 1536 token rows: 96 tiles of 128 x 128 on 256 CUs) fills the chip. Twice the LDS read
+// traffic per MFMA (8 ds_read_b128 per 12 MFMAs); 32 KiB of LDS, up to four blocks per CU. Same K order per output element as every
+// other shape: bit-identical results.
+typedef GemmCfg<2, 2, 2, 2, 4> Cfg64;
+// the same tile on a three- / four-slot ring (48 / 64 KiB): two / three K steps of DMA in flight -- a small problem has too few waves per CU
+// to hide the load latency of a one-step lookahead (measured: 1 us per K step of 0.1 us of MFMA work, profiles/r03_f). Default: three slots.
+typedef GemmCfg<2, 2, 2, 2, 4, 128, 3> Cfg64s3;
+typedef GemmCfg<2, 2, 2, 2, 2, 128, 4> Cfg64s4;
 typedef GemmCfg<1, 4, 8, 4, 2, 64, 3> Cfg256x128w4;  // M 256 x N 128, 4 waves of 128 (n) x 64 (m), 64-byte K rows: 48 KiB LDS, TWO
                                                   // blocks per CU, three stages (72 KiB)
 
@@ -121,6 +130,15 @@ D3R_DEV void conv_k_step(const GemmParams& p, int kel, int S, int& tap, int& c0)
         tap = kel / p.Cin;
         c0 = kel - tap * p.Cin;
     }
+}
+
+// the same for ONE 32-column half of a head (xhalf 0: the y position's rows, 1: x): what a 32-wide epilogue group needs
+D3R_DEV void load_rope_half(const float* table, int ntok, int tok_w, int M, int jj, int i4, int xhalf, float4 (&d)[2]) {
+    const int mm = jj < M ? jj : M - 1;
+    const int b = mm / ntok, t = mm - b * ntok;
+    const int ty = t / tok_w, tx = t - ty * tok_w;
+    const float4* c = reinterpret_cast<const float4*>(table + ((size_t)(xhalf ? tx : ty) * 16 + i4) * 2);
+    d[0] = c[0]; d[1] = c[1];
 }
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -905,7 +923,8 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                         (p.ldo & 63) == 0 && (p.n_store & 63) == 0;
     if (wide16 || wide32 || widex3 || widef8) {
         __syncthreads();   // every wave is done with the K loop's LDS stages
-        char* wreg = smem + wave * (64 * WROW);
+        constexpr int WR = FJ * 16, RP = FJ * 2;   // staging rows per wave (its j range) / read-phase passes of 8 rows
+        char* wreg = smem + wave * (WR * WROW);
         // P side (i, 4 consecutive per lane) base / Q side (j) base in global coordinates
         const int ib = (swap ? m0 : n0) + wi * (FI * 16), jb = (swap ? n0 : m0) + wj * (FJ * 16);
         const int rrow = lane >> 3, rch = lane & 7;   // read phase: 8 lanes cover one 128-byte row
@@ -1118,13 +1137,13 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                         const float4 t = *reinterpret_cast<const float4*>(bsrc + max(min(ig + fl * 16 + i4, p.n_store - 4), 0));
                         bq[fl] = make_float4(bias_i ? t.x : 0.f, bias_i ? t.y : 0.f, bias_i ? t.z : 0.f, bias_i ? t.w : 0.f);
                     }
-                    float4 rt[2][4];   // RoPE table rows, double buffered across fragments
-                    load_rope_rows(rtab, r_ntok, r_tokw, r_M, jb + jl, i4, rt[0]);
+                    float4 rt[2][2];   // RoPE table rows of this half of the head, double buffered across fragments
+                    load_rope_half(rtab, r_ntok, r_tokw, r_M, jb + jl, i4, xhalf, rt[0]);
 #pragma unroll
                     for (int fj = 0; fj < FJ; ++fj) {
                         const float bj = bias_j ? bjv[fj] : 0.f;
-                        if (fj + 1 < FJ) load_rope_rows(rtab, r_ntok, r_tokw, r_M, jb + (fj + 1) * 16 + jl, i4, rt[(fj + 1) & 1]);
-                        const float4 a0 = xhalf ? rt[fj & 1][2] : rt[fj & 1][0], a1 = xhalf ? rt[fj & 1][3] : rt[fj & 1][1];
+                        if (fj + 1 < FJ) load_rope_half(rtab, r_ntok, r_tokw, r_M, jb + (fj + 1) * 16 + jl, i4, xhalf, rt[(fj + 1) & 1]);
+                        const float4 a0 = rt[fj & 1][0], a1 = rt[fj & 1][1];
                         const float cc[4] = {a0.x, a0.z, a1.x, a1.z}, ss[4] = {a0.y, a0.w, a1.y, a1.w};
                         float vals[2][4];
 #pragma unroll
@@ -1158,7 +1177,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     // ---- LDS -> global: 8 lanes x 16 B = the 128 bytes of 32 consecutive logical i of row j
 #pragma unroll
-                    for (int pass = 0; pass < 8; ++pass) {
+                    for (int pass = 0; pass < RP; ++pass) {
                         const int row = pass * 8 + rrow;
                         const uint4 v = *reinterpret_cast<const uint4*>(wreg + row * WROW + rch * 16);
                         const int j = jb + row;
@@ -1195,11 +1214,11 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             // trace (tools/gpu_probe.py gemmtrace) showed this epilogue as four serial HBM round trips, ~19 us per 256 x 256 tile.
             // In place (res1 == out) is fine: a lane reads exactly the elements it stores later, and group g + 1's columns are
             // disjoint from the columns group g is storing.
-            float4 rr[2][8];
-            auto request_rows = [&](int g, float4 (&dst)[8]) __attribute__((always_inline)) {
+            float4 rr[2][RP];
+            auto request_rows = [&](int g, float4 (&dst)[RP]) __attribute__((always_inline)) {
                 const int ig = ib + g * 32;
 #pragma unroll
-                for (int pass = 0; pass < 8; ++pass) {
+                for (int pass = 0; pass < RP; ++pass) {
                     const int m = min(jb + pass * 8 + rrow, p.M - 1), n = max(min(ig + rch * 4, p.n_store - 4), 0);
                     dst[pass] = *reinterpret_cast<const float4*>(rsrc + (size_t)m * rld + n);
                 }
@@ -1226,7 +1245,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int pass = 0; pass < 8; ++pass) {
+                for (int pass = 0; pass < RP; ++pass) {
                     const int row = pass * 8 + rrow;
                     float4 v = *reinterpret_cast<const float4*>(wreg + row * WROW + rch * 16);
                     const int m = jb + row, n = ig + rch * 4;
@@ -1247,19 +1266,18 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     if (!swap) {
         const int nb = n0 + wi * (FI * 16), mb = m0 + wj * (FJ * 16);
         if (p.epi == EPI_HEADS) {
-            // q / k projections: bias, 2-D RoPE on the fp32 accumulator, head-major store. A wave's n range holds FI/4 heads.
+            // q / k projections: bias, 2-D RoPE on the fp32 accumulator, head-major store. A wave's n range is walked in 32-column halves
+            // of a head (columns 0-31 rotate with the token's y position, 32-63 with x; pairs are (c, c + 16) inside a half).
 #pragma unroll
-            for (int hb = 0; hb < FI / 4; ++hb) {
-                const int nh = nb + hb * 64;
+            for (int hb = 0; hb < FI / 2; ++hb) {
+                const int nh = nb + hb * 32;
                 if (nh >= p.n_store) continue;
                 const int region = nh / p.head_c;
-                const int h = (nh - region * p.head_c) >> 6;
+                const int h = (nh - region * p.head_c) >> 6, half = (nh >> 5) & 1;
                 void* dst = p.head_dst[region];
                 const bool rope = p.head_kind[region] == HEAD_ROPE;
-                float4 bias[4];
-#pragma unroll
-                for (int fi = 0; fi < 4; ++fi)
-                    bias[fi] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nh + fi * 16 + i4) : make_float4(0, 0, 0, 0);
+                const float4 bu = p.bias ? *reinterpret_cast<const float4*>(p.bias + nh + i4) : make_float4(0, 0, 0, 0);
+                const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + nh + 16 + i4) : make_float4(0, 0, 0, 0);
 #pragma unroll
                 for (int fj = 0; fj < FJ; ++fj) {
                     const int m = mb + fj * 16 + jl;
@@ -1267,27 +1285,23 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                     const int b = m / p.ntok, t = m - b * p.ntok;
                     const int ty = t / p.tok_w, tx = t - ty * p.tok_w;
                     const size_t obase = ((size_t)(b * p.heads + h) * p.ntok + t) * 64;
+                    const f32x4_t u = acc[hb * 2][fj], v = acc[hb * 2 + 1][fj];
+                    float uu[4] = {u[0] + bu.x, u[1] + bu.y, u[2] + bu.z, u[3] + bu.w};
+                    float vv[4] = {v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w};
+                    if (rope) {
+                        const int pos = half ? tx : ty;
+                        const float4* cs = reinterpret_cast<const float4*>(p.rope_table + ((size_t)pos * 16 + i4) * 2);
+                        const float4 c01 = cs[0], c23 = cs[1];  // (cos0,sin0,cos1,sin1), (cos2,sin2,cos3,sin3)
+                        const float cc[4] = {c01.x, c01.z, c23.x, c23.z}, ss[4] = {c01.y, c01.w, c23.y, c23.w};
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        f32x4_t u = acc[hb * 4 + half * 2][fj], v = acc[hb * 4 + half * 2 + 1][fj];
-                        const float4 bu = bias[half * 2], bv = bias[half * 2 + 1];
-                        float uu[4] = {u[0] + bu.x, u[1] + bu.y, u[2] + bu.z, u[3] + bu.w};
-                        float vv[4] = {v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w};
-                        if (rope) {
-                            const int pos = half ? tx : ty;
-                            const float4* cs = reinterpret_cast<const float4*>(p.rope_table + ((size_t)pos * 16 + i4) * 2);
-                            const float4 c01 = cs[0], c23 = cs[1];  // (cos0,sin0,cos1,sin1), (cos2,sin2,cos3,sin3)
-                            const float cc[4] = {c01.x, c01.z, c23.x, c23.z}, ss[4] = {c01.y, c01.w, c23.y, c23.w};
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float a = uu[r], bq = vv[r];
-                                uu[r] = a * cc[r] - bq * ss[r];
-                                vv[r] = bq * cc[r] + a * ss[r];
-                            }
+                        for (int r = 0; r < 4; ++r) {
+                            const float a = uu[r], bq = vv[r];
+                            uu[r] = a * cc[r] - bq * ss[r];
+                            vv[r] = bq * cc[r] + a * ss[r];
                         }
-                        store4<HDT>(dst, obase + half * 32 + i4, uu[0], uu[1], uu[2], uu[3]);
-                        store4<HDT>(dst, obase + half * 32 + 16 + i4, vv[0], vv[1], vv[2], vv[3]);
                     }
+                    store4<HDT>(dst, obase + half * 32 + i4, uu[0], uu[1], uu[2], uu[3]);
+                    store4<HDT>(dst, obase + half * 32 + 16 + i4, vv[0], vv[1], vv[2], vv[3]);
                 }
             }
             return;
@@ -1363,7 +1377,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             }
         }
     } else {
-        // V^T tiles: lane owns 4 consecutive tokens (i = m) of one feature (j = n); a wave's n range (FJ*16 = 64) is one head
+        // V^T tiles: lane owns 4 consecutive tokens (i = m) of one feature (j = n); a wave's n range (FJ*16 = 64 or 32) lies inside one head
         const int mb = m0 + wi * (FI * 16), nb = n0 + wj * (FJ * 16);
         if (nb >= p.n_store) return;
         const int region = nb / p.head_c;
@@ -1371,8 +1385,8 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         void* dst = p.head_dst[region];
 #pragma unroll
         for (int fj = 0; fj < FJ; ++fj) {
-            const int dd = fj * 16 + jl;
-            const float bias = p.bias ? p.bias[nb + dd] : 0.f;
+            const int dd = (nb & 63) + fj * 16 + jl;
+            const float bias = p.bias ? p.bias[nb + fj * 16 + jl] : 0.f;
 #pragma unroll
             for (int fi = 0; fi < FI; ++fi) {
                 const int m = mb + fi * 16 + i4;
@@ -1458,9 +1472,9 @@ int gemm_pick_config(const GemmParams& p, int dt) {
     int forced = p.force_cfg;
     if (forced < 0) {   // D3R_GEMM_CFG=0|1|2|3 pins the tile configuration (parity tests, probes); infeasible choices are ignored
         const char* e = getenv("D3R_GEMM_CFG");
-        if (e && e[0] >= '0' && e[0] <= '7' && e[1] == 0) forced = e[0] - '0';
+        if (e && e[0] >= '0' && e[0] <= '8' && e[1] == 0) forced = e[0] - '0';
     }
-    if (forced == GEMM_CFG_128 || (forced == GEMM_CFG_256 && ok256) ||
+    if (forced == GEMM_CFG_128 || forced == GEMM_CFG_64 || (forced == GEMM_CFG_256 && ok256) ||
         ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128 || forced == GEMM_CFG_256x128W4 || forced == GEMM_CFG_256x128R) && !heads) || ((forced == GEMM_CFG_256S4 || forced == GEMM_CFG_256PP) && ok256))
         return forced;
     if (p.epi == EPI_F32 && p.K <= 1024) {   // probe: tile of the HBM-heavy residual-stream epilogues at short K (D3R_GEMM_F32CFG=0|2|4)
@@ -1484,6 +1498,15 @@ int gemm_pick_config(const GemmParams& p, int dt) {
         if (r_on == 1 && tiles >= 512) return GEMM_CFG_256x128R;
         if (r_on < 0 && p.epi == EPI_F32 && p.res1 != nullptr && p.K <= 1024 && p.amode == AMODE_LINEAR && tiles >= 1024) return GEMM_CFG_256x128R;
     }
+    // split-fp16, small problems (the one- and two-pair forwards of dust3r/demo.py:156 / visloc.py:88, batch_size = 1): below ~1.5
+    // 128 x 128 tiles per CU the chip is not full -- the 64 x 64 tile by four waves of 32 x 32 runs the same problem on four times the
+    // waves. D3R_GEMM_T64 moves the crossover (0 = never); measured at 200 / 400 / 600 / 1000 / 2000 for 1-8 pairs per call: 200 is the
+    // best or within noise of it everywhere (profiles/r03_f/latency_small_tiles.log).
+    if (dt == D3R_F16X3 && p.n_store > 128) {
+        long t64 = 200;
+        if (const char* e = getenv("D3R_GEMM_T64")) t64 = atol(e);
+        if ((long)cdiv(p.M, 128) * cdiv(p.n_store, 128) < t64) return GEMM_CFG_64;
+    }
     const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.n_store, 256);
     // fp16 + fp8 rows: the 256-wide tile is 1.3-1.6x ahead of the 128 x 128 one per tile (its K loop lost a third of its MFMA work, the small
     // tile's LDS read traffic per MFMA is twice as high), so it pays from a single round of resident blocks on: measured +1.5 % on the
@@ -1505,6 +1528,7 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
     constexpr bool SPLIT = (DT == D3R_F16X3 || DT == D3R_F16F8);   // split-fp16 and fp16 + fp8 rows need 128-byte K rows, two stages
     if (cfg == GEMM_CFG_256x128W4 && SPLIT) cfg = GEMM_CFG_256x128;
     if (cfg == GEMM_CFG_256x128R && DT != D3R_F16X3) cfg = GEMM_CFG_256x128;      // the weights-in-registers shape exists for split-fp16 only
+    if (cfg == GEMM_CFG_64 && DT != D3R_F16X3) cfg = GEMM_CFG_128;                // the 64 x 64 shape too
     if ((cfg == GEMM_CFG_256S4 || cfg == GEMM_CFG_256PP) && SPLIT) cfg = GEMM_CFG_256;
     // the ping-pong schedule has no operand-role swap: attention projections only through the wide V^T route
     if (cfg == GEMM_CFG_256PP && p.epi == EPI_HEADS && !((DT == D3R_BF16 || DT == D3R_F16) && (p.ntok & 63) == 0 && !(p.flags & GF_NOWIDE))) cfg = GEMM_CFG_256;
@@ -1520,6 +1544,11 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
     }
     if constexpr (DT == D3R_F16X3) {
         if (cfg == GEMM_CFG_256x128R) return launch_cfg<DT, Cfg256x128r>(p, s);
+        if (cfg == GEMM_CFG_64) {
+            const char* e_ns = getenv("D3R_GEMM_64NS");     // probe: LDS ring depth of the 64 x 64 tile (2 | 3 | 4)
+            const int ns = e_ns ? atoi(e_ns) : 3;             // measured (profiles/r03_f): one pair 14.56 ms on the 128 x 128 tile, 12.36 / 10.38 / 10.48 ms with 2 / 3 / 4 slots
+            return ns == 2 ? launch_cfg<DT, Cfg64>(p, s) : ns == 3 ? launch_cfg<DT, Cfg64s3>(p, s) : launch_cfg<DT, Cfg64s4>(p, s);
+        }
         // split-fp16: D3R_GEMM_X3SW=1 selects the software-pipelined K loop. Measured on MI355X (profiles/r02_*): equal to the plain
         // two-stage loop on the 256-wide tiles, 10-15 % behind on the 128 x 128 tile -- the K loop is not where the time goes (the
         // same launches without their epilogue run 30 % faster in either form), so the plain loop stays the default.

@@ -162,7 +162,8 @@ size_t d3r_model_device_bytes(const d3r_model* m);
  * launches, their summed duration in ms and their summed algorithmic work (flops) for one kernel class:
  * kind 0..7 = gemm_kernel launches of tile configuration `kind` on nn.Linear operands (0 = 128x128, 1 = 256x256,
  * 2 = 256x128, 3 = 512x128, 4 = 256x128 4-wave, 5 = 256x256 4-stage), 8..15 = the same configurations on implicit-GEMM
- * convolution operands, 16 = attention_kernel, 17 = all other kernels, 24..31 = gemm_kernel launches on fp16 + fp8 operand rows
+ * convolution operands, 16 = attention_kernel, 17 = all other kernels, 18 / 19 = tile configuration 8 (64x64, the small-batch
+ * forwards of a split-fp16 engine) on nn.Linear / convolution operands, 24..31 = gemm_kernel launches on fp16 + fp8 operand rows
  * (D3R_DTYPE_F16F8 engines: the transformer blocks' linears) by tile configuration.
  * Profiling adds event overhead: never enable it inside a timed region. */
 #define D3R_MODEL_OPT_PROFILE 1
