@@ -173,7 +173,7 @@ size_t d3r_model_device_bytes(const d3r_model* m);
                                          * from the third call with the same (B, image sizes, output layout) on: ~700 launches become one
                                          * graph launch + input / output copies through engine-owned staging buffers (bit-identical results).
                                          * DEFAULT 0 = off (or D3R_GRAPH_MAX_PAIRS at create): measured on MI355X, one 512x384 pair per call
-                                         * takes 14.83 ms replayed vs 14.86 ms eager -- the one-pair forward is bound by the dependent chain of
+                                         * took 14.83 ms replayed vs 14.86 ms eager (before the small-problem GEMM tile: 10.4 ms now) -- the one-pair forward is bound by the dependent chain of
                                          * ~700 partially filled kernels on the GPU, not by the host's launch rate (profiles/r03_a/latency.log);
                                          * the replay only frees the host thread. 0 also drops the captured graphs */
 int d3r_model_set_option(d3r_model* m, int option, int value);
