@@ -33,9 +33,7 @@ def main():
         # the 64 x 64 GEMM tile of the small-batch forwards: crossover sweep (D3R_GEMM_T64 = 128x128-tile count below which it is taken; 0 = never)
         for ns in ('2', '3', '4'):
             os.environ['D3R_GEMM_64NS'] = ns
-            for t64 in ('0', '200', '400', '600', '1000', '2000'):
-                if t64 == '0' and ns != '2':
-                    continue
+            for t64 in ('0', '200', '400', '1000'):
                 os.environ['D3R_GEMM_T64'] = t64
                 print(f'D3R_GEMM_64NS={ns} D3R_GEMM_T64={t64:5s}: ' + '  '.join(f'B={B}: {timed_forward(model, B, dev) * 1e3:7.2f} ms' for B in (1, 2, 3, 4, 6, 8)), flush=True)
         os.environ.pop('D3R_GEMM_T64')
