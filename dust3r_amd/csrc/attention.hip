@@ -293,7 +293,9 @@ D3R_DEV float xor32_sum(float v) {
     return a + b;
 }
 
-template <int ODT>
+// PROBE (measurement aid, results invalid when != 0; tools/gpu_probe.py attnparts): bit 0 drops the VALU slices (softmax, P split), bit 1 the
+// MFMAs, bit 2 the per-tile barrier, bit 3 the staging of the next tiles (global loads + LDS writes) -- what each part costs next to the others
+template <int ODT, int PROBE = 0>
 __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TR = Traits<D3R_F16X3>;
@@ -408,19 +410,25 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     // What depends on t + 1 < ntiles is a template parameter (the last tile is a peeled instance without QK^T); tail loads are clamped.
     auto tile_step = [&](auto has_next_c, int t, f32x16_t (&s_cur)[2], f32x16_t (&s_nxt)[2]) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(has_next_c)::value;
-        __syncthreads();   // K_{t+1}, V_t are visible; every wave is done with K_t (ring slot t & 1) and V_{t-1} (slot (t + 1) & 1)
+        if constexpr (!(PROBE & 4)) __syncthreads();   // K_{t+1}, V_t are visible; every wave is done with K_t (ring slot t & 1) and V_{t-1} (slot (t + 1) & 1)
         const char* kb = smem + ((t + 1) & 1) * KT + koff;
         uint4 kh = make_uint4(0, 0, 0, 0), kl = kh;
         if constexpr (HAS_NEXT) {       // the first K fragment of S_{t+1}: requested right behind the barrier, used ~60 instructions later
             kh = *reinterpret_cast<const uint4*>(kb);
             kl = *reinterpret_cast<const uint4*>(kb + 16);
         }
-        if constexpr (HAS_NEXT) {
-            lds_put_k(t & 1);            // K_{t+2} (at t = ntiles - 2 a second copy of the last tile: that slot is not read again)
-            lds_put_v((t + 1) & 1);      // V_{t+1}
-            gload_k(min(t + 3, last) * 64);
-            gload_v(min(t + 2, last) * 64);
-        } else {
+        if constexpr (HAS_NEXT && !(PROBE & 8)) {
+            if constexpr (!(PROBE & 16)) {
+                lds_put_k(t & 1);            // K_{t+2} (at t = ntiles - 2 a second copy of the last tile: that slot is not read again)
+                lds_put_v((t + 1) & 1);      // V_{t+1}
+            } else {                         // probe: loads without the LDS writes (kept alive)
+                asm volatile("" :: "v"(kst0), "v"(kst1), "v"(kst2), "v"(kst3), "v"(vst0), "v"(vst1), "v"(vst2), "v"(vst3));
+            }
+            if constexpr (!(PROBE & 32)) {
+                gload_k(min(t + 3, last) * 64);
+                gload_v(min(t + 2, last) * 64);
+            }
+        } else if constexpr (!HAS_NEXT) {
             // keys beyond Nk: only the last tile of a ragged sequence has them (selects, no branch)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
@@ -526,21 +534,22 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
                     nh = *reinterpret_cast<const uint4*>(kr);
                     nl = *reinterpret_cast<const uint4*>(kr + 16);
                 }
-                s_nxt[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q8(kl), q8(qf[2 * ks]), st < 2 ? zero16 : s_nxt[rb], 0, 0, 0);
+                if constexpr (!(PROBE & 2)) s_nxt[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q8(kl), q8(qf[2 * ks]), st < 2 ? zero16 : s_nxt[rb], 0, 0, 0);
+                else if (st < 2) s_nxt[rb] = zero16;
                 if (st == 0) { PIN_A1(); } else { PIN_A(); }
-                valu_slice(3 * st);
-                s_nxt[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q8(kh), q8(qf[2 * ks + 1]), s_nxt[rb], 0, 0, 0);
+                if constexpr (!(PROBE & 1)) valu_slice(3 * st);
+                if constexpr (!(PROBE & 2)) s_nxt[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q8(kh), q8(qf[2 * ks + 1]), s_nxt[rb], 0, 0, 0);
                 if (st == 0) { PIN_A1(); } else { PIN_A(); }
-                valu_slice(3 * st + 1);
-                s_nxt[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q8(kh), q8(qf[2 * ks]), s_nxt[rb], 0, 0, 0);
+                if constexpr (!(PROBE & 1)) valu_slice(3 * st + 1);
+                if constexpr (!(PROBE & 2)) s_nxt[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q8(kh), q8(qf[2 * ks]), s_nxt[rb], 0, 0, 0);
                 if (st == 0) { PIN_A1(); } else { PIN_A(); }
-                valu_slice(3 * st + 2);
+                if constexpr (!(PROBE & 1)) valu_slice(3 * st + 2);
                 kh = nh; kl = nl;
             }
             PIN_A();
         } else {
 #pragma unroll
-            for (int v = 0; v < 24; ++v) valu_slice(v);
+            for (int v = 0; v < 24; ++v) if constexpr (!(PROBE & 1)) valu_slice(v);
         }
         // ---- phase B: O^T += V_t^T P_t^T, contraction over keys permuted identically on both operands ---------------------------
         // unit u = (group g = (rb, sh): 16 keys, d-block db): 3 MFMAs; the next unit's V^T fragments are read, and (over a group's two
@@ -564,13 +573,13 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
             const int nrb = (g + 1) >> 1, nsh = (g + 1) & 1;
             u32x4_t nvh = vh, nvl = vl;
             if (u + 1 < 8) vfrag(u + 1, nvh, nvl);
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(vl), h8(pH[cs]), o[db], 0, 0, 0);
+            if constexpr (!(PROBE & 2)) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(vl), h8(pH[cs]), o[db], 0, 0, 0);
             PIN_B();
-            if (g + 1 < 4) SPLIT2(s_cur[nrb][8 * nsh + 4 * db], s_cur[nrb][8 * nsh + 4 * db + 1], pH[ns], pL[ns], 2 * db)
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(vh), h8(pL[cs]), o[db], 0, 0, 0);
+            if constexpr (!(PROBE & 1)) if (g + 1 < 4) SPLIT2(s_cur[nrb][8 * nsh + 4 * db], s_cur[nrb][8 * nsh + 4 * db + 1], pH[ns], pL[ns], 2 * db)
+            if constexpr (!(PROBE & 2)) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(vh), h8(pL[cs]), o[db], 0, 0, 0);
             PIN_B();
-            if (g + 1 < 4) SPLIT2(s_cur[nrb][8 * nsh + 4 * db + 2], s_cur[nrb][8 * nsh + 4 * db + 3], pH[ns], pL[ns], 2 * db + 1)
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(vh), h8(pH[cs]), o[db], 0, 0, 0);
+            if constexpr (!(PROBE & 1)) if (g + 1 < 4) SPLIT2(s_cur[nrb][8 * nsh + 4 * db + 2], s_cur[nrb][8 * nsh + 4 * db + 3], pH[ns], pL[ns], 2 * db + 1)
+            if constexpr (!(PROBE & 2)) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(vh), h8(pH[cs]), o[db], 0, 0, 0);
             PIN_B();
             vh = nvh; vl = nvl;
         }
@@ -622,19 +631,38 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     }
 }
 
-template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream_t s) {
+template <int ODT, int PROBE> static hipError_t launch_x3_v2p(const AttnParams& p, hipStream_t s) {
     constexpr int LDS = 2 * 64 * (256 + 16) + 2 * 64 * (256 + 8);
     static std::atomic<unsigned long long> attr_done{0};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     const unsigned long long dev_bit = 1ull << (dev_id & 63);
     if (!(attr_done.load(std::memory_order_relaxed) & dev_bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_x3_kernel<ODT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_x3_kernel<ODT, PROBE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done.fetch_or(dev_bit, std::memory_order_relaxed);
     }
     const int grid = p.B * p.H * ((p.Nq + 127) / 128);
-    hipLaunchKernelGGL((attention_x3_kernel<ODT>), dim3(grid), dim3(256), LDS, s, p);
+    hipLaunchKernelGGL((attention_x3_kernel<ODT, PROBE>), dim3(grid), dim3(256), LDS, s, p);
     return hipGetLastError();
+}
+template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream_t s) {
+    if constexpr (ODT == D3R_F16X3) {
+        if (const char* e = getenv("D3R_ATTN_PROBE")) {      // ablation instances (results invalid), see the kernel
+            switch (atoi(e)) {
+                case 1: return launch_x3_v2p<ODT, 1>(p, s);
+                case 2: return launch_x3_v2p<ODT, 2>(p, s);
+                case 4: return launch_x3_v2p<ODT, 4>(p, s);
+                case 8: return launch_x3_v2p<ODT, 8>(p, s);
+                case 12: return launch_x3_v2p<ODT, 12>(p, s);
+                case 13: return launch_x3_v2p<ODT, 13>(p, s);
+                case 14: return launch_x3_v2p<ODT, 14>(p, s);
+                case 16: return launch_x3_v2p<ODT, 16>(p, s);
+                case 32: return launch_x3_v2p<ODT, 32>(p, s);
+                default: break;
+            }
+        }
+    }
+    return launch_x3_v2p<ODT, 0>(p, s);
 }
 
 template <int DT, int ODT = DT> static hipError_t launch_t(const AttnParams& p, hipStream_t s) {

@@ -184,6 +184,29 @@ def attn_probe():
         print(f'  B={B} H={H} {str(dt)[6:]:9s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s')
 
 
+def attnparts_probe():
+    """The split-fp16 attention kernel with parts of its instruction stream removed (D3R_ATTN_PROBE bit mask: 1 no softmax / split VALU,
+    2 no MFMAs, 4 no per-tile barrier, 8 no staging of the next tiles; results invalid): what each part costs next to the others."""
+    import os
+    from dust3r_amd import _lib
+    from dust3r_amd._lib import lib
+    from dust3r_amd.ops import check, current_stream, pack_x3, ptr
+    B, H, N = 64, 16, 768
+    q, k = torch.randn((B, H, N, 64), device=dev), torch.randn((B, H, N, 64), device=dev)
+    vt = torch.randn((B, H, 64, N), device=dev)
+    qp, kp, vp = pack_x3(q), pack_x3(k), pack_x3(vt)
+    out = torch.empty((B, N, H * 64 * 2), dtype=torch.float16, device=dev)
+    fl = 4 * B * H * N * N * 64
+    print(f'== split-fp16 attention, B={B} H={H} N={N}: ablation (D3R_ATTN_PROBE)')
+    names = {0: 'full kernel', 1: 'no VALU', 2: 'no MFMA', 4: 'no barrier', 8: 'no staging', 12: 'no barrier, no staging', 13: 'MFMA + fragment reads only',
+             14: 'VALU only', 16: 'no LDS writes of the staging', 32: 'no global loads of the staging'}
+    for probe, name in names.items():
+        os.environ['D3R_ATTN_PROBE'] = str(probe)
+        ms = timeit(lambda: check(lib.d3r_attention(ptr(qp), ptr(kp), ptr(vp), ptr(out), B, H, N, N, N, 0.125, _lib.DTYPE_F16X3, current_stream()), 'attention'), warm=3, reps=20)
+        print(f'  probe {probe:2d} {name:28s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s-equivalent', flush=True)
+    os.environ.pop('D3R_ATTN_PROBE')
+
+
 def forward_probe():
     from dust3r_amd.model import AsymmetricCroCo3DStereo
     from dust3r_amd.synthetic import MODEL_CONFIGS, OUT_GAIN, synthetic_state_dict, synthetic_views
@@ -320,7 +343,7 @@ if __name__ == '__main__':
     print(torch.cuda.get_device_name(0))
     for w in which:
         try:
-            {'gemm': gemm_probe, 'gemmtrace': gemmtrace_probe, 'tune': tune_probe, 'cache': cache_probe, 'conv': conv_probe, 'attn': attn_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
+            {'gemm': gemm_probe, 'gemmtrace': gemmtrace_probe, 'tune': tune_probe, 'cache': cache_probe, 'conv': conv_probe, 'attn': attn_probe, 'attnparts': attnparts_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
         except Exception as e:  # keep going: this is a probe
             import traceback
             traceback.print_exc()
