@@ -295,8 +295,10 @@ D3R_DEV float xor32_sum(float v) {
 
 // PROBE (measurement aid, results invalid when != 0; tools/gpu_probe.py attnparts): bit 0 drops the VALU slices (softmax, P split), bit 1 the
 // MFMAs, bit 2 the per-tile barrier, bit 3 the staging of the next tiles (global loads + LDS writes) -- what each part costs next to the others
-template <int ODT, int PROBE = 0>
-__global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
+// NW = waves per workgroup (4: 128 queries, two workgroups per CU; 8: 256 queries, one per CU -- every K / V^T tile staged once per 256
+// queries instead of 128: half the L2 -> LDS traffic per query, but nothing covers a workgroup's prologue).
+template <int ODT, int PROBE = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TR = Traits<D3R_F16X3>;
     constexpr int ROWB = 256, KROW = ROWB + 16, VROW = ROWB + 8;
@@ -304,11 +306,12 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
 
-    const int nqb = (p.Nq + 127) / 128;
+    constexpr int QPB = NW * 32;
+    const int nqb = (p.Nq + QPB - 1) / QPB;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = lid / nqb, qb = lid - bh * nqb;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qb * 128 + wave * 32;
+    const int q0 = qb * QPB + wave * 32;
 
     const char* qptr = reinterpret_cast<const char*>(p.q) + (size_t)bh * p.Nq * ROWB;
     const char* kptr = reinterpret_cast<const char*>(p.k) + (size_t)bh * p.Nk * ROWB;
@@ -326,48 +329,44 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
         }
     }
 
-    // ---- tile staging: thread t moves chunks t, t + 256, t + 512, t + 768 of the 64 x 16 chunks of a K tile and of a V^T tile
-    const int srow = tid >> 4, sch = tid & 15;          // chunk i: row srow + 16 i, 16-byte chunk sch
-    uint4 kst0, kst1, kst2, kst3, vst0, vst1, vst2, vst3;
+    // ---- tile staging: thread t moves chunks t, t + NT, ... of the 64 x 16 chunks of a K tile and of a V^T tile (NP = 1024 / NT per operand)
+    constexpr int RPP = NW * 4, NP = 64 / RPP;          // rows per pass, passes
+    const int srow = tid >> 4, sch = tid & 15;          // chunk i: row srow + RPP i, 16-byte chunk sch
+    uint4 kst[NP], vst[NP];
     // Raw buffer loads: a wave-uniform resource per operand, a per-thread 32-bit offset, the tile offset in a scalar register -- no 64-bit
     // per-thread addresses (16 VGPRs and ~50 address instructions per tile in the first version of this kernel). K rows beyond Nk
     // (ragged last tile) are out of the resource's range and read as zero (their scores are masked anyway); the row part of a K address
     // therefore sits in the VGPR offset, the only part gfx9 range-checks. V^T tiles are always inside the zero-padded ldv.
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kptr), 0, p.Nk * ROWB, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vptr), 0, 64 * p.ldv * 4, 0x00020000);
-    const int kvo = srow * ROWB + sch * 16;              // chunk i: + i * 16 rows
+    const int kvo = srow * ROWB + sch * 16;              // chunk i: + i * RPP rows
     const int vvo = srow * p.ldv * 4 + sch * 16;
-    const int vstep = 16 * p.ldv * 4;
+    const int vstep = RPP * p.ldv * 4;
     auto as_uint4 = [](const u32x4b_t& v) __attribute__((always_inline)) { return make_uint4(v[0], v[1], v[2], v[3]); };
     auto gload_k = [&](int key0) __attribute__((always_inline)) {
         const int t0 = key0 * ROWB + kvo;
-        kst0 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(krs, t0, 0, 0));
-        kst1 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(krs, t0 + 16 * ROWB, 0, 0));
-        kst2 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(krs, t0 + 32 * ROWB, 0, 0));
-        kst3 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(krs, t0 + 48 * ROWB, 0, 0));
+#pragma unroll
+        for (int i = 0; i < NP; ++i) kst[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(krs, t0 + i * RPP * ROWB, 0, 0));
     };
     auto gload_v = [&](int key0) __attribute__((always_inline)) {
         const int s0 = key0 * 4;
-        vst0 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(vrs, vvo, s0, 0));
-        vst1 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(vrs, vvo, s0 + vstep, 0));
-        vst2 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(vrs, vvo, s0 + 2 * vstep, 0));
-        vst3 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(vrs, vvo, s0 + 3 * vstep, 0));
+#pragma unroll
+        for (int i = 0; i < NP; ++i) vst[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(vrs, vvo, s0 + i * vstep, 0));
     };
     auto lds_put_k = [&](int buf) __attribute__((always_inline)) {
         char* kb = smem + buf * KT + srow * KROW + sch * 16;
-        *reinterpret_cast<uint4*>(kb) = kst0;
-        *reinterpret_cast<uint4*>(kb + 16 * KROW) = kst1;
-        *reinterpret_cast<uint4*>(kb + 32 * KROW) = kst2;
-        *reinterpret_cast<uint4*>(kb + 48 * KROW) = kst3;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) *reinterpret_cast<uint4*>(kb + i * RPP * KROW) = kst[i];
     };
     // V^T row image: [hi of the 64 keys (128 B) | lo of the 64 keys (128 B)]; memory chunk c = (8-group c >> 1, hi / lo = c & 1)
     auto lds_put_v = [&](int buf) __attribute__((always_inline)) {
         char* vb = smem + 2 * KT + buf * VT + srow * VROW + (sch & 1) * 128 + (sch >> 1) * 16;
-        auto st = [&](char* d, const uint4& v) __attribute__((always_inline)) {   // 264-byte rows are only 8-byte aligned
-            *reinterpret_cast<uint2*>(d) = make_uint2(v.x, v.y);
-            *reinterpret_cast<uint2*>(d + 8) = make_uint2(v.z, v.w);
-        };
-        st(vb, vst0); st(vb + 16 * VROW, vst1); st(vb + 32 * VROW, vst2); st(vb + 48 * VROW, vst3);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {   // 264-byte rows are only 8-byte aligned
+            char* d = vb + i * RPP * VROW;
+            *reinterpret_cast<uint2*>(d) = make_uint2(vst[i].x, vst[i].y);
+            *reinterpret_cast<uint2*>(d + 8) = make_uint2(vst[i].z, vst[i].w);
+        }
     };
 
     const int ntiles = (p.Nk + 63) / 64;
@@ -422,7 +421,11 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
                 lds_put_k(t & 1);            // K_{t+2} (at t = ntiles - 2 a second copy of the last tile: that slot is not read again)
                 lds_put_v((t + 1) & 1);      // V_{t+1}
             } else {                         // probe: loads without the LDS writes (kept alive)
-                asm volatile("" :: "v"(kst0), "v"(kst1), "v"(kst2), "v"(kst3), "v"(vst0), "v"(vst1), "v"(vst2), "v"(vst3));
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const u32x4b_t kk = {kst[i].x, kst[i].y, kst[i].z, kst[i].w}, vv = {vst[i].x, vst[i].y, vst[i].z, vst[i].w};
+                    asm volatile("" :: "v"(kk), "v"(vv));
+                }
             }
             if constexpr (!(PROBE & 32)) {
                 gload_k(min(t + 3, last) * 64);
@@ -631,18 +634,18 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     }
 }
 
-template <int ODT, int PROBE> static hipError_t launch_x3_v2p(const AttnParams& p, hipStream_t s) {
+template <int ODT, int PROBE, int NW = 4> static hipError_t launch_x3_v2p(const AttnParams& p, hipStream_t s) {
     constexpr int LDS = 2 * 64 * (256 + 16) + 2 * 64 * (256 + 8);
     static std::atomic<unsigned long long> attr_done{0};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     const unsigned long long dev_bit = 1ull << (dev_id & 63);
     if (!(attr_done.load(std::memory_order_relaxed) & dev_bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_x3_kernel<ODT, PROBE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_x3_kernel<ODT, PROBE, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done.fetch_or(dev_bit, std::memory_order_relaxed);
     }
-    const int grid = p.B * p.H * ((p.Nq + 127) / 128);
-    hipLaunchKernelGGL((attention_x3_kernel<ODT, PROBE>), dim3(grid), dim3(256), LDS, s, p);
+    const int grid = p.B * p.H * ((p.Nq + NW * 32 - 1) / (NW * 32));
+    hipLaunchKernelGGL((attention_x3_kernel<ODT, PROBE, NW>), dim3(grid), dim3(NW * 64), LDS, s, p);
     return hipGetLastError();
 }
 template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream_t s) {
@@ -662,6 +665,7 @@ template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream
             }
         }
     }
+    if (const char* e = getenv("D3R_ATTN_NW")) if (e[0] == '8') return launch_x3_v2p<ODT, 0, 8>(p, s);   // probe: 256 queries per workgroup
     return launch_x3_v2p<ODT, 0>(p, s);
 }
 

@@ -205,6 +205,16 @@ def attnparts_probe():
         ms = timeit(lambda: check(lib.d3r_attention(ptr(qp), ptr(kp), ptr(vp), ptr(out), B, H, N, N, N, 0.125, _lib.DTYPE_F16X3, current_stream()), 'attention'), warm=3, reps=20)
         print(f'  probe {probe:2d} {name:28s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s-equivalent', flush=True)
     os.environ.pop('D3R_ATTN_PROBE')
+    for nw in ('4', '8', '4', '8'):         # 128 vs 256 queries per workgroup
+        os.environ['D3R_ATTN_NW'] = nw
+        for (b, h) in ((64, 16), (32, 12)):
+            q, k = torch.randn((b, h, N, 64), device=dev) * 0.5, torch.randn((b, h, N, 64), device=dev) * 0.5
+            vt = torch.randn((b, h, 64, N), device=dev)
+            qp, kp, vp = pack_x3(q), pack_x3(k), pack_x3(vt)
+            out = torch.empty((b, N, h * 64 * 2), dtype=torch.float16, device=dev)
+            ms = timeit(lambda: check(lib.d3r_attention(ptr(qp), ptr(kp), ptr(vp), ptr(out), b, h, N, N, N, 0.125, _lib.DTYPE_F16X3, current_stream()), 'attention'), warm=3, reps=20)
+            print(f'  D3R_ATTN_NW={nw} B={b} H={h}: {ms * 1e3:8.1f} us  {4 * b * h * N * N * 64 / ms / 1e9:7.1f} TF/s', flush=True)
+    os.environ.pop('D3R_ATTN_NW')
 
 
 def forward_probe():
