@@ -405,5 +405,31 @@ D3R_DEV int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// ------------------------------------------------------------------------------ head epilogues
+// postprocess (dust3r/heads/postprocess.py:10-58) with depth_mode ('exp', -inf, inf) and
+// conf_mode ('exp', 1, inf): pts = xyz / max(|xyz|, 1e-8) * expm1(|xyz|); conf = 1 + exp(x).
+// pts / conf element strides between pixels: (3, 1) = the reference's separate pts3d / conf tensors; (8, 8) = the packed
+// [pixel][pts1 conf1 pts2 conf2] record that the multi-GPU path all-gathers as one payload.
+D3R_DEV void postprocess_store(float x, float y, float z, float cl, float* pts, float* conf, size_t pix, int ps, int cs) {
+    const float d = sqrtf(x * x + y * y + z * z);
+    const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+    pts[ps * pix + 0] = x * sc;
+    pts[ps * pix + 1] = y * sc;
+    pts[ps * pix + 2] = z * sc;
+    conf[cs * pix] = 1.0f + expf(cl);
+}
+
+// sum over the four 16-lane rows of a wave, per column (lane & 15), every lane gets the total: v_permlane32_swap exchanges rows {2, 3} of
+// its first operand with rows {0, 1} of its second, v_permlane16_swap rows {1, 3} with rows {0, 2}; with both operands = v the two
+// results add up to v[l] + v[l ^ 32] (then ^ 16). Inline asm: hipcc 7.2's permlane swap builtins return their first result twice.
+D3R_DEV float rows_sum4(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    v = a + b;
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t dt_bytes(int dt) { return (dt == D3R_F32 || dt == D3R_F16X3 || dt == D3R_F16F8) ? 4 : 2; }

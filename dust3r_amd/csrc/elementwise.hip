@@ -372,19 +372,7 @@ hipError_t launch_upsample2x(int dt, const void* in, void* out, void* out_relu, 
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------ head epilogues
-// postprocess (dust3r/heads/postprocess.py:10-58) with depth_mode ('exp', -inf, inf) and
-// conf_mode ('exp', 1, inf): pts = xyz / max(|xyz|, 1e-8) * expm1(|xyz|); conf = 1 + exp(x).
-// pts / conf element strides between pixels: (3, 1) = the reference's separate pts3d / conf tensors; (8, 8) = the packed
-// [pixel][pts1 conf1 pts2 conf2] record that the multi-GPU path all-gathers as one payload.
-D3R_DEV void postprocess_store(float x, float y, float z, float cl, float* pts, float* conf, size_t pix, int ps, int cs) {
-    const float d = sqrtf(x * x + y * y + z * z);
-    const float sc = expm1f(d) / fmaxf(d, 1e-8f);
-    pts[ps * pix + 0] = x * sc;
-    pts[ps * pix + 1] = y * sc;
-    pts[ps * pix + 2] = z * sc;
-    conf[cs * pix] = 1.0f + expf(cl);
-}
+// postprocess_store (depth_mode / conf_mode of the reference's heads): common.hpp, shared with the GEMM kernel's fused head epilogue
 
 // DPT head tail: Conv2d(last_dim, 4, 1) on the ReLU'd features + postprocess (dpt_head.py:63,
 // croco dpt_block head[3:5]). 16 lanes per pixel, 8 channels per lane per step.

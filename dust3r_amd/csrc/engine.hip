@@ -363,6 +363,29 @@ void conv(Ctx& c, const void* in, int B, int Hin, int Win, int cstride, const Co
     c.chk(launch_gemm(c.m->dt, p, c.st));
 }
 
+// 3x3 convolution (stride 1, pad 1) + ReLU + Conv2d(Cout, 4, 1) + postprocess in one launch (EPI_HEAD4); false (nothing launched) when
+// the problem does not get a tile shape whose waves hold all output channels
+bool conv_head4(Ctx& c, const void* in, int B, int Hin, int Win, int cstride, const ConvW& w, const float* w4, const float* b4,
+                float* pts, float* conf, int pstride, int cstride_conf) {
+    GemmParams p;
+    p.amode = AMODE_CONV; p.act = in; p.wgt = w.w; p.bias = w.b;
+    p.Hin = Hin; p.Win = Win; p.Cin = w.cin_pad; p.cstride = cstride; p.ksize = w.k; p.stride = 1; p.pad = 1;
+    p.Hout = Hin; p.Wout = Win;
+    p.M = B * p.Hout * p.Wout; p.K = w.K; p.n_pad = w.n_pad; p.n_rows = w.n_rows; p.n_store = w.Cout;
+    p.zero_page = c.m->zero_page;
+    p.epi = EPI_HEAD4; p.flags = GF_RELU; p.out = pts; p.ldo = pstride; p.out2 = conf; p.ldo2 = cstride_conf; p.res1 = w4; p.res2 = b4;
+    if (w.k != 3 || w.Cout > 128 || w.Cout % 4 != 0) return false;
+    int cfg = gemm_pick_config(p, c.m->dt);
+    if (cfg == GEMM_CFG_256x128) {      // fewer pixels (one or two images): the same tile by four waves stacked along m
+        p.force_cfg = GEMM_CFG_256x128R;
+        cfg = gemm_pick_config(p, c.m->dt);
+    }
+    if (cfg != GEMM_CFG_512x128 && cfg != GEMM_CFG_256x128R) return false;
+    c.mark(prf_kind(PRF_CONV, cfg), 2.0 * p.M * (double)w.Cout * w.k * w.k * w.Cin, p.M, w.Cout, w.k * w.k * w.Cin);
+    c.chk(launch_gemm(c.m->dt, p, c.st));
+    return true;
+}
+
 struct Arena {
     char* base; size_t off = 0, cap;
     Arena(void* b, size_t c) : base((char*)b), cap(c) {}
@@ -615,8 +638,18 @@ void run_dpt(Ctx& c, const DptHead& D, Arena ar, const void* const hooks[4], con
     void* h1 = ar.take((size_t)B * 4 * H8 * W8 * 128 * eb);
     D3R_OTHER(launch_upsample2x(m->dt, h0, h1, nullptr, B, H8, W8, 128, 128, 2 * H8, 2 * W8, c.st));
     void* h2 = ar.take((size_t)B * 4 * H8 * W8 * 128 * eb);
-    conv(c, h1, B, 2 * H8, 2 * W8, 128, D.head2, 1, 1, h2, 128, GF_RELU);
-    D3R_OTHER(launch_head_final(m->dt, h2, 128, D.head4_w, D.head4_b, pts, conf, (size_t)B * 4 * H8 * W8, m->out_pstride, m->out_cstride, c.st));
+    // Split-fp16, enough pixels for the 512 x 128 tile (every wave then holds all 128 channels of its 64 pixels): the 1x1 convolution and
+    // the postprocess run in the epilogue of the last 3x3 convolution, on its fp32 accumulators -- the 128-channel full-resolution map
+    // (3.2 GB per head at 32 pairs) is neither written nor read back. D3R_HEAD_FUSE=0: the two-kernel route (test A/B).
+    bool fused = false;
+    if (m->dt == D3R_F16X3) {
+        const char* e = getenv("D3R_HEAD_FUSE");
+        if (!(e && e[0] == '0')) fused = conv_head4(c, h1, B, 2 * H8, 2 * W8, 128, D.head2, D.head4_w, D.head4_b, pts, conf, m->out_pstride, m->out_cstride);
+    }
+    if (!fused) {
+        conv(c, h1, B, 2 * H8, 2 * W8, 128, D.head2, 1, 1, h2, 128, GF_RELU);
+        D3R_OTHER(launch_head_final(m->dt, h2, 128, D.head4_w, D.head4_b, pts, conf, (size_t)B * 4 * H8 * W8, m->out_pstride, m->out_cstride, c.st));
+    }
     if (ar.base && ar.off > ar.cap) c.rc = D3R_ERR_ALLOC;
 }
 

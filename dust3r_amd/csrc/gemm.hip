@@ -897,6 +897,71 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     const int i4 = (lane >> 4) * 4;  // first of this lane's 4 consecutive i inside a fragment
     const int jl = lane & 15;
 
+    // ---- fused DPT head tail (EPI_HEAD4, kernels.hpp): this wave holds every output channel of its FJ x 16 rows --------------
+    if constexpr (DT == D3R_F16X3 && CF::NWI == 1 && FI == 8) {
+        if (p.epi == EPI_HEAD4) {
+            const float* hw = reinterpret_cast<const float*>(p.res1);
+            const float* hb = reinterpret_cast<const float*>(p.res2);
+            const float* bsrc = p.bias ? p.bias : hw;
+            const int C = p.n_store;
+            const bool has_bias = p.bias != nullptr;
+            const float floor_v = (p.flags & GF_RELU) ? 0.f : -3.0e38f;
+            float part[FJ][4];
+#pragma unroll
+            for (int fj = 0; fj < FJ; ++fj) part[fj][0] = part[fj][1] = part[fj][2] = part[fj][3] = 0.f;
+            // 1x1 weights and bias of fragment column fi: requested one fragment ahead (double buffered); the fence keeps hipcc from hoisting
+            // all 40 loads (160 registers next to the 128 accumulators) to the top
+            float4 wb[2][5];
+            auto request = [&](int fi, float4 (&d)[5]) __attribute__((always_inline)) {
+                const int n = fi * 16 + i4;                     // n0 == 0: one tile spans the channels
+                const int nc = min(n, C - 4);                   // channels >= C: zero accumulators (padded weight rows), zero 1x1 weights
+                d[4] = *reinterpret_cast<const float4*>(bsrc + nc);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) d[o] = *reinterpret_cast<const float4*>(hw + (size_t)o * C + nc);
+            };
+            request(0, wb[0]);
+#pragma unroll
+            for (int fi = 0; fi < FI; ++fi) {
+                if (fi + 1 < FI) request(fi + 1, wb[(fi + 1) & 1]);
+                const float live = fi * 16 + i4 < C ? 1.f : 0.f;
+                const float4 bt = wb[fi & 1][4];
+                const float4 bi = make_float4(has_bias ? bt.x : 0.f, has_bias ? bt.y : 0.f, has_bias ? bt.z : 0.f, has_bias ? bt.w : 0.f);
+                float4 w4[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const float4 t = wb[fi & 1][o];
+                    w4[o] = make_float4(t.x * live, t.y * live, t.z * live, t.w * live);
+                }
+#pragma unroll
+                for (int fj = 0; fj < FJ; ++fj) {
+                    const f32x4_t a = acc[fi][fj];
+                    // ReLU as a select-free maximum (a branch here splits the block and the register allocator spills around it)
+                    const float v0 = fmaxf(a[0] + bi.x, floor_v), v1 = fmaxf(a[1] + bi.y, floor_v), v2 = fmaxf(a[2] + bi.z, floor_v), v3 = fmaxf(a[3] + bi.w, floor_v);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+                        part[fj][o] = fmaf(v3, w4[o].w, fmaf(v2, w4[o].z, fmaf(v1, w4[o].y, fmaf(v0, w4[o].x, part[fj][o]))));
+                }
+                asm volatile("" ::: "memory");
+            }
+            // the four lane groups hold four quarters of a row's channels: add them up; lane group g then owns the rows of fragment g
+            const int g = lane >> 4;
+            float r4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int fj = 0; fj < FJ; ++fj)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const float t = rows_sum4(part[fj][o]);
+                    r4[o] = (fj == g) ? t : r4[o];
+                }
+            static_assert(FJ == 4, "one row fragment per lane group");
+            const int m = m0 + wj * (FJ * 16) + g * 16 + jl;
+            if (m < p.M)
+                postprocess_store(r4[0] + hb[0], r4[1] + hb[1], r4[2] + hb[2], r4[3] + hb[3], reinterpret_cast<float*>(p.out),
+                                  reinterpret_cast<float*>(p.out2), (size_t)m, p.ldo, p.ldo2);
+            return;
+        }
+    }
+
     // ---- wide epilogues: accumulators -> wave-private LDS tile -> whole 128-byte rows ---------------------------------
     // An MFMA accumulator fragment gives a lane 4 consecutive columns of ONE row and 16 different rows per wave
     // instruction: stored directly that is 32 B (16-bit types) or 64 B (fp32) per row per instruction, and the store
@@ -1529,6 +1594,8 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
     if (cfg == GEMM_CFG_256x128W4 && SPLIT) cfg = GEMM_CFG_256x128;
     if (cfg == GEMM_CFG_256x128R && DT != D3R_F16X3) cfg = GEMM_CFG_256x128;      // the weights-in-registers shape exists for split-fp16 only
     if (cfg == GEMM_CFG_64 && DT != D3R_F16X3) cfg = GEMM_CFG_128;                // the 64 x 64 shape too
+    // the fused head tail needs a wave to hold every output channel of its rows: waves stacked along m, 128 columns per wave
+    if (p.epi == EPI_HEAD4 && (DT != D3R_F16X3 || !(cfg == GEMM_CFG_512x128 || cfg == GEMM_CFG_256x128R))) return hipErrorInvalidValue;
     if ((cfg == GEMM_CFG_256S4 || cfg == GEMM_CFG_256PP) && SPLIT) cfg = GEMM_CFG_256;
     // the ping-pong schedule has no operand-role swap: attention projections only through the wide V^T route
     if (cfg == GEMM_CFG_256PP && p.epi == EPI_HEADS && !((DT == D3R_BF16 || DT == D3R_F16) && (p.ntok & 63) == 0 && !(p.flags & GF_NOWIDE))) cfg = GEMM_CFG_256;
@@ -1611,6 +1678,7 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     if (p.amode == AMODE_CONV && (p.Cin % kt != 0 || p.zero_page == nullptr)) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV) p.kslice_major = conv_k_slice_major() ? 1 : 0;
     if (p.epi == EPI_HEADS && p.head_c % 128 != 0 && p.head_c < (1 << 29)) return hipErrorInvalidValue;
+    if (p.epi == EPI_HEAD4 && (p.n_store > 128 || p.n_store % 4 != 0 || !p.res1 || !p.res2 || !p.out || !p.out2)) return hipErrorInvalidValue;
     // fp16 + fp8 rows: nn.Linear operands only, whole 64-element super-groups; outputs: fp32 (+ residual), GELU / plain activation rows, heads
     if (dt == D3R_F16F8 && ((size_t)512 * p.lda * 4 >= (1ull << 32) || (size_t)512 * p.K * 4 >= (1ull << 32))) return hipErrorInvalidValue;   // 32-bit offsets inside a tile
     if (dt == D3R_F16F8 && (p.amode != AMODE_LINEAR || p.K % 64 != 0 || p.lda % 64 != 0 || p.epi == EPI_CONVT || p.res2 ||

@@ -6,7 +6,11 @@ namespace d3r {
 
 // ------------------------------------------------------------------------------ GEMM / conv
 enum { AMODE_LINEAR = 0, AMODE_CONV = 1 };
-enum { EPI_T = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_HEADS = 3, EPI_CONVT = 4 };
+enum { EPI_T = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_HEADS = 3, EPI_CONVT = 4, EPI_HEAD4 = 5 };
+// EPI_HEAD4 (split-fp16, tiles whose waves hold all <= 128 output channels of their rows: the 512 x 128 / 256 x 128 R shapes): the DPT head's
+// tail fused into its last 3x3 convolution -- bias, ReLU (GF_RELU), Conv2d(C, 4, 1) on the fp32 accumulators, postprocess, store of
+// pts / conf (dpt_head.py:63 + postprocess.py:10-58). Field reuse: out = pts (float*), ldo = its pixel stride, out2 = conf (float*),
+// ldo2 = its pixel stride, res1 = the 1x1 weights [4][n_store] fp32, res2 = its bias [4] fp32. Nothing of the C-channel map is stored.
 enum { HEAD_ROPE = 1, HEAD_VT = 2, HEAD_PLAIN = 3 };
 enum { GF_RELU = 1, GF_NOSTORE = 2, GF_NOWIDE = 4, GF_NTSTORE = 8 };   // GF_NTSTORE: wide epilogues store with the non-temporal policy (default; D3R_GEMM_NT=0 clears it)
 enum { GEMM_CFG_128 = 0, GEMM_CFG_256 = 1, GEMM_CFG_256x128 = 2, GEMM_CFG_512x128 = 3, GEMM_CFG_256x128W4 = 4, GEMM_CFG_256S4 = 5, GEMM_CFG_256PP = 6, GEMM_CFG_256x128R = 7, GEMM_CFG_64 = 8 };

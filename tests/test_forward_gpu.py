@@ -450,6 +450,27 @@ def test_sharded_inference_on_the_engine_with_rccl(gpu):
     assert torch.equal(out['pred2']['pts3d_in_other_view'], ref['pred2']['pts3d_in_other_view']) and torch.equal(out['pred2']['conf'], ref['pred2']['conf'])
 
 
+@pytest.mark.parametrize('B', [1, 2])
+def test_fused_head_tail_equals_the_two_kernel_route(gpu, B, monkeypatch):
+    """Split-fp16, BASELINE model: the DPT head's Conv2d(128, 4, 1) + postprocess run in the epilogue of the last 3x3 convolution (EPI_HEAD4,
+    on the fp32 accumulators; 512 x 128 tiles from two images per head on, the four-wave 256 x 128 tile below) instead of storing the
+    128-channel full-resolution map and reading it back (D3R_HEAD_FUSE=0). Same values up to the rounding of the map to 22 bits."""
+    from bench import build_model       # the bench's synthetic full-size weights, generated in HBM (tests/conftest.py puts the repo root on sys.path)
+    eng = build_model('fp16x3', gpu)
+    v1, v2 = synthetic_views(B, 384, 512, seed=3, device=gpu)
+    out = {}
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('D3R_HEAD_FUSE', fuse)
+        e1, e2 = eng(v1, v2)
+        out[fuse] = [t.clone() for t in (e1['pts3d'], e2['pts3d_in_other_view'], e1['conf'], e2['conf'])]
+    for a, b in zip(out['1'][:2], out['0'][:2]):
+        mx, mean = pix_rel(a, b.cpu())
+        print(f'[fused head B={B}] pointmap rel diff max {mx:.3e} mean {mean:.3e}')
+        assert mx < 2e-5 and mean < 1e-6
+    for a, b in zip(out['1'][2:], out['0'][2:]):
+        assert float(((a - b).abs() / b).max()) < 1e-5
+
+
 @pytest.mark.parametrize('precision', ['fp16x3', 'bf16'])
 def test_small_batch_graph_replay_is_bit_identical(gpu, precision):
     """One or two pairs per call (dust3r/demo.py:156 passes batch_size=1, visloc.py:88 one pair per query): from the third call with the
