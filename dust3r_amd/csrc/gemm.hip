@@ -180,7 +180,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     // ---- block -> tile: XCD-contiguous ids, then 8-wide column panels walked row by row ------------------
     const int tiles_n = (p.n_store + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    constexpr int PANEL = 8;
+    const int PANEL = p.panel;
     const int per_panel = PANEL * tiles_m;
     const int panel = lid / per_panel, rem_p = lid - panel * per_panel;
     const int width = min(PANEL, tiles_n - panel * PANEL);
@@ -1677,6 +1677,7 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     if (p.M <= 0 || p.n_pad % 128 != 0 || p.n_store > p.n_pad || p.K % kt != 0 || p.K <= 0) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV && (p.Cin % kt != 0 || p.zero_page == nullptr)) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV) p.kslice_major = conv_k_slice_major() ? 1 : 0;
+    if (const char* e = getenv("D3R_GEMM_PANEL")) { const int v = atoi(e); if (v >= 1 && v <= 64) p.panel = v; }
     if (p.epi == EPI_HEADS && p.head_c % 128 != 0 && p.head_c < (1 << 29)) return hipErrorInvalidValue;
     if (p.epi == EPI_HEAD4 && (p.n_store > 128 || p.n_store % 4 != 0 || !p.res1 || !p.res2 || !p.out || !p.out2)) return hipErrorInvalidValue;
     // fp16 + fp8 rows: nn.Linear operands only, whole 64-element super-groups; outputs: fp32 (+ residual), GELU / plain activation rows, heads

@@ -44,6 +44,7 @@ struct GemmParams {
     // first-round start stagger (set by launch_gemm): blocks with blockIdx < first_round wait stagger_ticks * slot / 32 wall-clock
     // ticks before they start, so that the epilogue bursts of the resident tiles do not all hit HBM at the same time
     int stagger_ticks = 0, first_round = 0, stagger_mode = 0;
+    int panel = 8;               // tile map: width of the column panels in tiles (launch_gemm: D3R_GEMM_PANEL probe)
     int kslice_major = 0;        // implicit-GEMM K order: 0 = (tap, channel), 1 = (channel slice of one K step, tap, channel in slice); set by launch_gemm
     // diagnostics (d3r_gemm_set_trace): 8 x uint64 per block -- wall-clock ticks at entry / K-loop start / K-loop end / epilogue
     // issued / stores drained, then HW_ID, XCC_ID, blockIdx
@@ -95,6 +96,7 @@ struct PackParams {
     const float* src = nullptr; void* dst = nullptr;
     size_t numel = 0;
     int kind = PACK_MAT, cols = 0, row_off = 0, dst_cols = 0, cin = 0, cin_pad = 0, ksize = 1, cout_pad = 0;
+    int panel = 8;               // tile map: width of the column panels in tiles (launch_gemm: D3R_GEMM_PANEL probe)
     int kslice_major = 0;        // PACK_CONV: K order of the packed rows (conv_k_slice_major())
 };
 bool conv_k_slice_major();       // process-wide K order of implicit-GEMM operands (kernel and weight packing agree on it)
