@@ -463,6 +463,9 @@ def test_fused_head_tail_equals_the_two_kernel_route(gpu, B, monkeypatch):
         monkeypatch.setenv('D3R_HEAD_FUSE', fuse)
         e1, e2 = eng(v1, v2)
         out[fuse] = [t.clone() for t in (e1['pts3d'], e2['pts3d_in_other_view'], e1['conf'], e2['conf'])]
+        pk = eng.forward_packed(v1, v2)     # the all-gather payload (B,H,W,8) = [pts1 conf1 pts2 conf2] written by the same epilogue with strides (8, 8)
+        assert torch.equal(pk[..., 0:3], e1['pts3d']) and torch.equal(pk[..., 3], e1['conf'])
+        assert torch.equal(pk[..., 4:7], e2['pts3d_in_other_view']) and torch.equal(pk[..., 7], e2['conf'])
     for a, b in zip(out['1'][:2], out['0'][:2]):
         mx, mean = pix_rel(a, b.cpu())
         print(f'[fused head B={B}] pointmap rel diff max {mx:.3e} mean {mean:.3e}')
