@@ -85,6 +85,13 @@ D3R_DEV float wave_sum_shfl(float v) {
     return v;
 }
 
+// the pred / weight planes are read exactly once per iteration (1.29 GB at the BASELINE scene: nothing to keep in L2 / MALL)
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+D3R_DEV float4 stream_ld4(const float* p) {
+    const f32x4v_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v_t*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+#define D3R_STREAM_LD4(ptr) stream_ld4(ptr)
 template <bool L2, int PF>   // PF = prefetch distance of the pred / weight stream in edges (1 or 2)
 __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
     const int nchunk = a.nslot;
@@ -145,18 +152,18 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
         {
             const int es = sh_es[0];
             const float* pp = a.pred[es & 1] + (size_t)(es >> 1) * 3 * a.maxA + pl;
-            nq0 = *reinterpret_cast<const float4*>(pp);
-            nq1 = *reinterpret_cast<const float4*>(pp + a.maxA);
-            nq2 = *reinterpret_cast<const float4*>(pp + 2 * (size_t)a.maxA);
-            nww = *reinterpret_cast<const float4*>(a.wgt[es & 1] + (size_t)(es >> 1) * a.maxA + pl);
+            nq0 = D3R_STREAM_LD4(pp);
+            nq1 = D3R_STREAM_LD4(pp + a.maxA);
+            nq2 = D3R_STREAM_LD4(pp + 2 * (size_t)a.maxA);
+            nww = D3R_STREAM_LD4(a.wgt[es & 1] + (size_t)(es >> 1) * a.maxA + pl);
         }
         if (PF == 2) {
             const int es = sh_es[nb > 1 ? 1 : 0];
             const float* pp = a.pred[es & 1] + (size_t)(es >> 1) * 3 * a.maxA + pl;
-            mq0 = *reinterpret_cast<const float4*>(pp);
-            mq1 = *reinterpret_cast<const float4*>(pp + a.maxA);
-            mq2 = *reinterpret_cast<const float4*>(pp + 2 * (size_t)a.maxA);
-            mww = *reinterpret_cast<const float4*>(a.wgt[es & 1] + (size_t)(es >> 1) * a.maxA + pl);
+            mq0 = D3R_STREAM_LD4(pp);
+            mq1 = D3R_STREAM_LD4(pp + a.maxA);
+            mq2 = D3R_STREAM_LD4(pp + 2 * (size_t)a.maxA);
+            mww = D3R_STREAM_LD4(a.wgt[es & 1] + (size_t)(es >> 1) * a.maxA + pl);
         }
         for (int j = 0; j < nb; ++j) {
             const int es = sh_es[j];
@@ -171,10 +178,10 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
                 float4& d1 = PF == 2 ? mq1 : nq1;
                 float4& d2 = PF == 2 ? mq2 : nq2;
                 float4& dw = PF == 2 ? mww : nww;
-                d0 = *reinterpret_cast<const float4*>(pp);
-                d1 = *reinterpret_cast<const float4*>(pp + a.maxA);
-                d2 = *reinterpret_cast<const float4*>(pp + 2 * (size_t)a.maxA);
-                dw = *reinterpret_cast<const float4*>(a.wgt[es2 & 1] + (size_t)(es2 >> 1) * a.maxA + pl);
+                d0 = D3R_STREAM_LD4(pp);
+                d1 = D3R_STREAM_LD4(pp + a.maxA);
+                d2 = D3R_STREAM_LD4(pp + 2 * (size_t)a.maxA);
+                dw = D3R_STREAM_LD4(a.wgt[es2 & 1] + (size_t)(es2 >> 1) * a.maxA + pl);
             }
             float M[12];
             {
