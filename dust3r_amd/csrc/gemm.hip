@@ -271,6 +271,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     const int p_row0 = wi * (FI * 16) + frow, q_row0 = wj * (FJ * 16) + frow;
 
     if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 8 + 1] = (unsigned long long)wall_clock64();
+    __builtin_amdgcn_s_setprio(2);   // K loop: ahead of a co-resident block's epilogue in the SIMD's issue arbitration
     static_assert(CF::NSTAGE >= 2 && CF::NSTAGE <= 4, "vmcnt ladder below covers up to 2 younger steps in flight");
     f32x4_t acc[FI][FJ];
 #pragma unroll
@@ -873,6 +874,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     }  // !PP
 
     // ---- epilogue ------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(0);
     if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 8 + 2] = (unsigned long long)wall_clock64();
     struct TraceEnd {   // stamps "epilogue issued" and "stores drained" on every return path
         const GemmParams& p; int tid;
