@@ -95,6 +95,9 @@ typedef GemmCfg<2, 2, 2, 2, 4> Cfg64;
 // to hide the load latency of a one-step lookahead (measured: 1 us per K step of 0.1 us of MFMA work, profiles/r03_f). Default: three slots.
 typedef GemmCfg<2, 2, 2, 2, 4, 128, 3> Cfg64s3;
 typedef GemmCfg<2, 2, 2, 2, 2, 128, 4> Cfg64s4;
+// 128 x 128 by EIGHT waves of 64 (n) x 32 (m): twice the waves per tile (16 per CU with two resident blocks) for the mid-size problems of the
+// small-batch forwards, where a K step is bound by latency rather than by the matrix pipe. Bit-identical to the four-wave shape.
+typedef GemmCfg<2, 4, 4, 2, 4> Cfg128w8;
 typedef GemmCfg<1, 4, 8, 4, 2, 64, 3> Cfg256x128w4;  // M 256 x N 128, 4 waves of 128 (n) x 64 (m), 64-byte K rows: 48 KiB LDS, TWO
                                                   // blocks per CU, three stages (72 KiB)
 
@@ -1649,6 +1652,16 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
                 case GEMM_CFG_512x128: return launch_cfg<DT, Cfg512x128il>(p, s);
                 default: return launch_cfg<DT, Cfg128il>(p, s);
             }
+        }
+    }
+    if constexpr (DT == D3R_F16X3) {
+        // 128 x 128 launches of fewer than 1100 tiles (the one- to four-pair forwards) on the eight-wave shape. Measured (profiles/r03_k):
+        // one pair 10.59 -> 10.26 ms, two 16.0 -> 15.3, four 26.3 -> 25.9; applied to the 1152-tile launches of the 32-pair step as well:
+        // -0.1 %, hence the limit. D3R_GEMM_T128W8 moves it (0 = never).
+        if (cfg == GEMM_CFG_128) {
+            const char* e = getenv("D3R_GEMM_T128W8");
+            const long t = e ? atol(e) : 1100;
+            if ((long)cdiv(p.M, 128) * cdiv(p.n_store, 128) < t) return launch_cfg<DT, Cfg128w8>(p, s);
         }
     }
     switch (cfg) {

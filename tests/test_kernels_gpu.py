@@ -52,7 +52,7 @@ def test_linear_epilogues(gpu, dtype, M, N, K):
 
 
 @pytest.mark.parametrize('sw', ['1', '0'])
-@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '7', '8'])
+@pytest.mark.parametrize('cfg', ['0', '0w8', '1', '2', '3', '7', '8'])
 @pytest.mark.parametrize('M,N,K', [(300, 192, 256), (1000, 3072, 1024), (77, 96, 768), (2100, 1032, 32), (515, 328, 64)])
 def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
     """The parity-grade precision mode (fp16x3: operands split into fp16 hi + lo, three MFMAs per product) at kernel level:
@@ -61,7 +61,8 @@ def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
     software-pipelined K loop and the plain two-stage loop, the LDS-staged wide epilogue and the direct stores; K = 32 / 64 are one- and two-step K loops (pipeline prologue / drain only). Reference =
     fp32 matmul of the SAME fp32 operands: the split keeps 22 significand bits per operand, so the result is fp32-class."""
     from dust3r_amd import ops
-    monkeypatch.setenv('D3R_GEMM_CFG', cfg)
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg[0])
+    monkeypatch.setenv('D3R_GEMM_T128W8', '1000000' if cfg.endswith('w8') else '0')     # '0w8': the 128 x 128 tile by eight waves (small-batch forwards)
     monkeypatch.setenv('D3R_GEMM_X3SW', sw)
     g = torch.Generator(device='cpu').manual_seed(M * 7 + N)
     a = torch.randn((M, K), generator=g).to(gpu)
