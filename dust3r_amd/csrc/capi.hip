@@ -61,3 +61,16 @@ extern "C" int d3r_gemm_set_trace(void* buf, size_t capacity_blocks) {
     gemm_set_trace((unsigned long long*)buf, buf ? capacity_blocks : 0);
     return D3R_OK;
 }
+
+// Diagnostics, host only (no GPU, no launch): the tile configuration the heuristic of gemm.hip picks for an nn.Linear-shaped problem
+// (same `epilogue` codes as d3r_linear; with_residual: an fp32 residual is added). The dispatch table of DESIGN.md section 4.1 as a function.
+extern "C" int d3r_gemm_tile_config(int dtype, int M, int N, int K, int epilogue, int with_residual) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 4 != 0) return D3R_ERR_INVALID;
+    static const float dummy = 0.f;
+    GemmParams p;
+    p.lda = K; p.M = M; p.K = K; p.n_pad = rup(N, 128); p.n_rows = rup(N, 256); p.n_store = N;
+    p.epi = epilogue == 1 ? EPI_F32 : (epilogue == 2 ? EPI_GELU : EPI_T);
+    p.res1 = (epilogue == 1 && with_residual) ? &dummy : nullptr;
+    return gemm_pick_config(p, dtype);
+}
+

@@ -95,6 +95,11 @@ int d3r_upsample2x_nhwc(const void* in, void* out, int B, int Hi, int Wi, int C,
  * `buf` (device memory, 8 x uint64 per block: wall-clock ticks at block entry, K-loop start, K-loop end, epilogue issued, stores
  * drained; then HW_ID, XCC_ID, blockIdx). `capacity_blocks` bounds the launches that are traced; buf = NULL switches it off. */
 int d3r_gemm_set_trace(void* buf, size_t capacity_blocks);
+/* Diagnostics, host only (no device needed): the GEMM tile configuration the engine picks for an nn.Linear-shaped problem (epilogue codes of
+ * d3r_linear; with_residual: an fp32 residual row is added). 0 = 128x128 (eight waves below 1100 tiles in split-fp16), 1 = 256x256,
+ * 2 = 256x128, 3 = 512x128, 7 = 256x128 by four waves with a K step's weights in registers (two blocks per CU), 8 = 64x64 on a three-slot
+ * ring (problems of fewer than 200 128x128 tiles, split-fp16). The D3R_GEMM_* probe variables apply. DESIGN.md section 4.1. */
+int d3r_gemm_tile_config(int dtype, int M, int N, int K, int epilogue, int with_residual);
 
 /* ------------------------------------------------------------------------------------------------
  * Model engine -- replaces AsymmetricCroCo3DStereo.forward (dust3r/model.py:199-211) including
