@@ -10,11 +10,21 @@ One step = one engine forward over `--pairs` image pairs per rank. At N > 1 rank
 (weak scaling: fixed pairs per GPU) and every step ends with the path's ONE collective, the all-gather of the
 pairwise predictions (dust3r_amd/parallel.py), issued asynchronously so that it overlaps the next step's compute.
 
-Usage: python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+Usage: python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c5]   (N > 1: launched by torch.distributed.run, one rank per GPU)
+  --workload c2 (default): BASELINE configs[1], the configuration the metric is quoted on -- what the paragraph above describes.
+  --workload c3: configs[2], 20 synthetic views -> make_pairs('complete', symmetrize=False) = 190 pairs, contiguous shards of
+                 ceil(190 / N) pairs per rank, every distinct image of a shard encoded once, ONE all-gather per step; a step = the
+                 whole 190-pair job (strong scaling: the job is fixed, value = 190 x steps / time).
+  --workload c5: configs[4], 100 views, make_pairs('swin-3', symmetrize=True) = 600 pairs: sharded forward + all-gather, then on rank 0
+                 global_aligner(PointCloudOptimizer) + compute_global_alignment(init='mst', niter=300, cosine): wall clock per job,
+                 next to a CPU figure EXTRAPOLATED by the BASELINE.md section 2 protocol (labelled as such).
+Every line carries a "parity_check" block: outputs of the timed 32-pair batch against one-pair-per-call runs of the same pairs
+(bit-equality; the one-pair call shape is what tests/ hold to the CPU oracle) and, at N = 1 with the CPU baseline on, the engine
+loaded with the CPU oracle's weights against the oracle's own output on the same pair (per-pixel relative error, bar 1e-3).
 Prints ONE JSON line on rank 0. Extra objects: "roofline" (dominant kernel, live HIP-event timing), "cpu_baseline"
 (the CPU oracle timed on this host's cores on a bounded sample, rank 0 at N=1 only), "aligner", "kernels", "fast_mode"
 (the opt-in modes fp16f8 / bf16 / fp16: throughput, their own dominant-kernel roofline block and their measured error against the headline
-engine. The headline precision is fp16x3, the engine default and the mode that meets the 1e-3 per-pixel bar on every weight set tested).
+engine. The headline precision is fp16x3, the engine default and the mode that meets the 1e-3 per-pixel bar on every plain weight seed tested; DESIGN.md section 2 for the outlier-weight figures).
 """
 import argparse
 import ctypes as C
@@ -185,6 +195,42 @@ def profile_mode(model, v1, v2, precision, quiet=False):
     return out
 
 
+def rel_stats(got, ref):
+    """per pixel ||got - ref||_2 / max(||ref||_2, 1e-8) -> max / p99.99 / p99 / mean."""
+    e = ((got.float().cpu() - ref.float().cpu()).norm(dim=-1) / ref.float().cpu().norm(dim=-1).clamp_min(1e-8)).flatten()
+    srt = e.sort().values
+    q = lambda f: float(srt[min(int(f * srt.numel()), srt.numel() - 1)])   # noqa: E731
+    return {'max': float(srt[-1]), 'p99.99': q(0.9999), 'p99': q(0.99), 'mean': float(e.mean())}
+
+
+def parity_batch_vs_single(model, v1, v2, full, picks):
+    """The timed batch's outputs (`full` = pts1, conf1, pts2, conf2 of the whole batch) against one-pair-per-call runs of pairs `picks`:
+    the call shape tests/test_forward_gpu.py::test_full_size_fp32_pair_matches_oracle holds to the CPU oracle. Bit-equality expected:
+    every kernel is batch-position independent and no tile choice changes the order of a K sum."""
+    worst, equal = 0.0, True
+    for b in picks:
+        s1 = dict(img=v1['img'][b:b + 1], true_shape=v1['true_shape'][b:b + 1], idx=[0], instance=['0'])
+        s2 = dict(img=v2['img'][b:b + 1], true_shape=v2['true_shape'][b:b + 1], idx=[1], instance=['1'])
+        o1, o2 = model(s1, s2)
+        for a, w in zip((o1['pts3d'], o1['conf'], o2['pts3d_in_other_view'], o2['conf']), full):
+            equal = equal and bool(torch.equal(a[0], w[b]))
+            worst = max(worst, float((a[0] - w[b]).abs().max()))
+    finite = all(bool(torch.isfinite(t).all()) for t in full)
+    return {'what': f'pairs {list(picks)} of the timed {full[0].shape[0]}-pair batch vs the same pairs run one per call (forward outputs pts3d / conf of both views)',
+            'bit_equal': equal, 'max_abs_diff': worst, 'all_outputs_finite': finite, 'pass': equal and finite}
+
+
+def parity_vs_cpu_oracle(model, oracle, v1, v2, ref):
+    """Engine (loaded with the CPU oracle's weights) vs the oracle's own fp32 output on the same 512x384 pair: the north-star measure
+    (per-pixel relative pointmap error, bar 1e-3). `ref` = (r1, r2) from the oracle call bench.py's cpu_baseline leg makes anyway."""
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    e1, e2 = model(v1, v2)
+    st = rel_stats(torch.cat((e1['pts3d'], e2['pts3d_in_other_view'])), torch.cat((ref[0]['pts3d'], ref[1]['pts3d_in_other_view'])))
+    cf = float(((torch.cat((e1['conf'], e2['conf'])).cpu() - torch.cat((ref[0]['conf'], ref[1]['conf']))).abs() / torch.cat((ref[0]['conf'], ref[1]['conf']))).max())
+    return {'what': f'{MODEL} one 512x384 pair, engine precision {model.precision} with the CPU oracle\'s weights vs oracle/dust3r_ref.py fp32 on this host',
+            'pointmap_rel_err': st, 'conf_rel_err_max': cf, 'tolerance': 1e-3, 'pass': st['max'] < 1e-3 and cf < 3e-3}
+
+
 def bench_aligner(device, niter=300, n_views=20):
     """configs[3]: PointCloudOptimizer, 20 synthetic views -> 190 edges, 300 iterations, cosine schedule, one GPU."""
     from dust3r_amd.cloud_opt import global_aligner
@@ -240,7 +286,7 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline_forward(reps=3):
+def cpu_baseline_forward(reps=3, keep=None):
     """SURVEY.md 8(d) protocol: the CPU oracle (fp32 PyTorch restatement of the reference path, oracle/dust3r_ref.py) on this
     host's cores, same model / image size as the GPU leg, B = 1 and B = 4 pairs per call, `reps` calls each after one untimed
     call, MEDIAN reported. `value` is the better of the two medians in pairs/s (both are in `sample`)."""
@@ -256,7 +302,9 @@ def cpu_baseline_forward(reps=3):
     with torch.no_grad():
         for B in (1, 4):
             v1, v2 = synthetic_views(B, H, W, seed=0)
-            oracle(v1, v2)                      # untimed: first-touch page faults
+            r = oracle(v1, v2)                  # untimed: first-touch page faults
+            if B == 1 and keep is not None:     # the parity_check block compares the engine with this output
+                keep.update(oracle=oracle, views=(v1, v2), ref=r)
             times = []
             for _ in range(reps):
                 t = time.time()
@@ -289,6 +337,131 @@ def cpu_baseline_aligner(scene_io, warm=2, timed=20):
                        f'{dt:.1f} s = {dt / timed:.3f} s/iter; 300 iterations extrapolate to {300 * dt / timed:.0f} s')
 
 
+ENC_GFLOP_PER_IMAGE = 523.0                  # encoder incl. patch embedding, per 512x384 image
+DEC_HEAD_GFLOP_PER_PAIR = 2 * 218.6 + 2 * 186.7   # both decoders (incl. decoder_embed) + both DPT heads, per pair
+
+
+def run_sharded(args, model, world, rank, device, one_device, backend):
+    """--workload c3 / c5 (BASELINE configs[2] / configs[4]): a FIXED job (190 / 600 pairs over 20 / 100 views) cut into contiguous
+    shards of ceil(P / N) pairs, dust3r_amd.parallel's per-rank routine (every distinct image of the shard through the encoder once,
+    the heads write the packed (pairs, H, W, 8) payload in place), ONE all-gather; c5 then aligns the gathered predictions on rank 0
+    (global_aligner + init='mst' + 300 cosine iterations, dust3r/demo.py:158-178). Images are resident in HBM before the timed region."""
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.parallel import _local_same_size, all_gather_packed, shard_bounds, unpack_predictions
+    from dust3r_amd.synthetic import synthetic_image_list
+    c5 = args.workload == 'c5'
+    n_views, graph, sym = (100, 'swin-3', True) if c5 else (20, 'complete', False)
+    imgs = synthetic_image_list(n_views, H, W, seed=0)
+    for v in imgs:
+        v['img'] = v['img'].to(device)
+    pairs = make_pairs(imgs, scene_graph=graph, prefilter=None, symmetrize=sym)
+    P = len(pairs)
+    lo, hi, per = shard_bounds(P, rank, world)
+    counts = [shard_bounds(P, r, world)[1] - shard_bounds(P, r, world)[0] for r in range(world)]
+    images_per_rank = [len({int(v['idx']) for pr in pairs[shard_bounds(P, r, world)[0]:shard_bounds(P, r, world)[1]] for v in pr}) for r in range(world)]
+    log(f'[bench] rank {rank}: {args.workload}: {P} pairs over {n_views} views, shard [{lo}, {hi}) = {hi - lo} pairs touching {images_per_rank[rank]} distinct images')
+    keep = torch.cat([torch.arange(r * per, r * per + counts[r]) for r in range(world)]).to(device)
+    gathered = torch.empty((world * per, H, W, 8), dtype=torch.float32, device=device) if world > 1 else None
+    view1 = view2 = None
+    if c5 and rank == 0:      # view metadata is rebuilt deterministically on the host, the 2 x 600 images gathered on the device (outside the timed region)
+        stack = torch.cat([v['img'] for v in imgs], dim=0)
+        mk = lambda side: dict(img=stack.index_select(0, torch.tensor([int(p[side]['idx']) for p in pairs], device=device)),   # noqa: E731
+                               true_shape=torch.tensor([[H, W]] * P, dtype=torch.int32), idx=[int(p[side]['idx']) for p in pairs],
+                               instance=[str(p[side]['instance']) for p in pairs])
+        view1, view2 = mk(0), mk(1)
+    stage = {}
+
+    def step():
+        local = _local_same_size(pairs, lo, hi, per, model, device, args.pairs, device, True, H, W)
+        if world > 1:
+            all_gather_packed(local, out=gathered)
+            allp = gathered
+        else:
+            allp = local
+        if not c5 or rank != 0:
+            return allp, None
+        from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        pred1, pred2 = unpack_predictions(allp.index_select(0, keep) if world > 1 else allp)
+        scene = global_aligner(dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None), device, mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
+        loss = scene.compute_global_alignment(init='mst', niter=300, schedule='cosine', lr=0.01)
+        poses = scene.get_im_poses()
+        torch.cuda.synchronize()
+        stage['align_s'] = time.perf_counter() - t
+        stage['loss'], stage['poses_finite'] = float(loss), bool(torch.isfinite(poses).all())
+        return allp, scene
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        return None
+    sec = dt / args.steps
+    gflop = n_views * ENC_GFLOP_PER_IMAGE + P * DEC_HEAD_GFLOP_PER_PAIR if world == 1 else sum(images_per_rank) * ENC_GFLOP_PER_IMAGE + P * DEC_HEAD_GFLOP_PER_PAIR
+    selftest = ' (SELF-TEST: all ranks on one device, backend ' + backend + ' -- not a scaling measurement)' if one_device and world > 1 else ''
+    common = dict(n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=sec * 1e3, scaling='strong', vs_baseline=None, dtype=args.precision,
+                  data='synthetic' + selftest)
+    cfg = {'workload': f'{MODEL}, {n_views} synthetic 512x384 views -> make_pairs({graph!r}, symmetrize={sym}) = {P} pairs (BASELINE configs[{4 if c5 else 2}]), contiguous shards of '
+                       f'{per} pairs per rank, each distinct image of a shard encoded once, ONE all-gather of the packed predictions per job'
+                       + ('; then global_aligner(PointCloudOptimizer) + init=mst + 300 cosine Adam iterations on rank 0' if c5 else '') + '; random-init weights, images resident in HBM',
+           'pairs': P, 'views': n_views, 'pairs_per_rank': counts, 'distinct_images_per_rank': images_per_rank, 'pairs_per_engine_call': args.pairs,
+           'parallelism': f'pair-sharded dp{world}'}
+    if not c5:
+        result = dict(metric='image_pairs_per_sec_forward_512x384_190_pairs_sharded', value=P / sec, unit='pairs/s', higher_is_better=True, config=cfg,
+                      forward_gflop_executed_per_job=gflop, forward_tflops_executed=gflop / sec / 1e3,
+                      note='encode-once: the job executes fewer flops than pairs x 1856.8 GFLOP (the pair-by-pair schedule of the reference); value counts PAIRS', **common)
+    else:
+        result = dict(metric='end_to_end_seconds_100_views_forward_plus_global_aligner', value=sec, unit='s per job', higher_is_better=False, config=cfg,
+                      stages=dict(forward_and_gather_s=sec - stage.get('align_s', 0.0), aligner_build_init_300_iters_s=stage.get('align_s'), final_loss=stage.get('loss'),
+                                  poses_finite=stage.get('poses_finite'), note='stage split from the LAST job; value is the mean over the timed jobs'),
+                      pairs_per_s_end_to_end=P / sec, forward_gflop_executed_per_job=gflop, **common)
+    # parity of the job's own outputs: sampled pairs of the gathered payload vs one-pair-per-call runs (bit-equality)
+    if not args.no_parity:
+        allp = last[0].index_select(0, keep) if world > 1 else last[0]
+        equal, worst = True, 0.0
+        picks = sorted({0, P // 3, P // 2, P - 1})
+        for k in picks:
+            a, b = pairs[k]
+            pk = model.forward_packed(dict(img=a['img']), dict(img=b['img']))
+            equal = equal and bool(torch.equal(pk[0], allp[k]))
+            worst = max(worst, float((pk[0] - allp[k]).abs().max()))
+        result['parity_check'] = {'sharded_job_vs_single_pair_calls': {'what': f'pairs {picks} of the gathered {P}-pair payload vs forward_packed of that pair alone', 'bit_equal': equal,
+                                                                       'max_abs_diff': worst, 'all_outputs_finite': bool(torch.isfinite(allp).all()), 'pass': equal}}
+        log(f"[bench] parity_check: {result['parity_check']}")
+    log(f"[bench] {args.workload}: {P} pairs per job, {sec:.3f} s per job on {world} GPU(s)" + (f", aligner stage {stage.get('align_s', 0):.3f} s, loss {stage.get('loss')}" if c5 else ''))
+    last = None
+    if c5 and world == 1 and not args.no_cpu_baseline:
+        try:      # BASELINE.md section 2: CPU wall clock EXTRAPOLATED from per-pair and per-iteration medians of the oracle on this host
+            fw = cpu_baseline_forward()
+            al_gpu, scene_io = bench_aligner(device, niter=30)
+            al = cpu_baseline_aligner(scene_io)
+            cpu_s = P / fw['value'] + 300 * (P / 190.0) / al['value']
+            result['cpu_baseline'] = dict(value=cpu_s, unit='s per job (EXTRAPOLATED)', cores=fw['cores'], cpu_model=fw['cpu_model'], kind='port',
+                                          sample=f"EXTRAPOLATED, not run: {P} pairs / ({fw['value']:.3f} pairs/s: {fw['sample']}) + 300 iterations x ({P}/190 edges) / ({al['value']:.3f} iters/s at 190 edges: {al['sample']}); "
+                                                 'the MST / PnP initialisation of the reference is not in the CPU figure',
+                                          gpu_over_cpu=cpu_s / sec)
+        except Exception as e:
+            result['cpu_baseline'] = {'error': repr(e)}
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -297,6 +470,8 @@ def main():
     ap.add_argument('--pairs', type=int, default=32, help='image pairs per GPU per step (configs[1]: 32)')
     ap.add_argument('--precision', default=os.environ.get('DUST3R_AMD_PRECISION', 'fp16x3'),
                     help='engine precision of the HEADLINE: fp16x3 (default, the engine default: meets the 1e-3 per-pixel pointmap bar); fp16f8 / bf16 / fp16 are opt-in modes reported under fast_mode')
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c5'], help='c2 (default): BASELINE configs[1], 32 pairs per GPU per step; c3: configs[2], 20 views -> 190 pairs sharded; c5: configs[4], 100 views swin-3 -> 600 pairs, forward + global_aligner end to end')
+    ap.add_argument('--no-parity', action='store_true', help='skip the parity_check block')
     ap.add_argument('--no-aligner', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
@@ -335,6 +510,15 @@ def main():
     if args.single_stream:
         model.set_two_streams(False)
     B = args.pairs
+    if args.workload != 'c2':
+        result = run_sharded(args, model, world, rank, device, one_device, backend)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if world > 1:
+            dist.barrier()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     v1, v2 = synthetic_views(B, H, W, seed=rank, device=device)      # resident in HBM before the timed region
 
     do_gather = world > 1 or force_gather
@@ -371,8 +555,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    last = None
     for i in range(args.steps):
-        step(i)
+        last = step(i)
     drain()
     torch.cuda.synchronize()
     if world > 1:
@@ -399,6 +584,22 @@ def main():
             'forward_frac_of_bf16_mfma_peak': value / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS,
         }
         log(f'[bench] {value:.2f} pairs/s on {world} GPU(s), {dt / args.steps * 1e3:.1f} ms/step')
+
+    # ---- parity of the timed configuration itself: the last timed step's outputs vs one-pair-per-call runs -----------
+    if rank == 0 and not args.no_parity and last is not None:
+        try:
+            if do_gather:
+                from dust3r_amd.parallel import unpack_predictions
+                p1, p2 = unpack_predictions(last)
+            else:
+                p1, p2 = last
+            full = (p1['pts3d'], p1['conf'], p2['pts3d_in_other_view'], p2['conf'])
+            result['parity_check'] = {'batch_vs_single_pair_calls': parity_batch_vs_single(model, v1, v2, full, sorted({0, B // 2 - 1 if B > 1 else 0, B - 1}))}
+            log(f"[bench] parity_check (timed batch vs one-pair calls): {result['parity_check']['batch_vs_single_pair_calls']}")
+            del p1, p2, full
+        except Exception as e:
+            result['parity_check'] = {'error': repr(e)}
+    last = None
 
     # ---- live per-kernel timing (HIP events on the launch stream, outside the timed region) ---------------------
     if rank == 0 and not args.no_profile:
@@ -464,8 +665,17 @@ def main():
                 result['aligner'] = {'error': repr(e)}
         if not args.no_cpu_baseline:
             try:
-                result['cpu_baseline'] = cpu_baseline_forward()
+                keep = {}
+                result['cpu_baseline'] = cpu_baseline_forward(keep=keep)
                 result['cpu_baseline']['gpu_over_cpu'] = result['value'] / result['cpu_baseline']['value']
+                if not args.no_parity and keep:
+                    try:        # the engine with the oracle's weights vs the oracle's own output (this overwrites the bench weights: every timed leg is done)
+                        pc = parity_vs_cpu_oracle(model, keep['oracle'], *keep['views'], keep['ref'])
+                        result.setdefault('parity_check', {})['vs_cpu_oracle'] = pc
+                        log(f'[bench] parity_check (engine vs CPU oracle): {pc}')
+                    except Exception as e:
+                        result.setdefault('parity_check', {})['vs_cpu_oracle'] = {'error': repr(e)}
+                    keep.clear()
                 if scene_io is not None:
                     cb = cpu_baseline_aligner(scene_io)
                     cb['gpu_over_cpu'] = result['aligner']['value'] / cb['value']

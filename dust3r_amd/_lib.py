@@ -66,6 +66,7 @@ def _load():
         'd3r_model_decode_packed': (i, [vp, vp, i, i, i, fp, vp]),
         'd3r_model_debug_read': (i, [vp, i, fp, C.c_size_t, vp]),
         'd3r_model_set_option': (i, [vp, i, i]),
+        'd3r_model_set_postprocess': (i, [vp, i, i, f, f]),
         'd3r_model_profile_read': (i, [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         'd3r_model_profile_launch': (i, [vp, i] + [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.c_double)] * 2),
         'd3r_aligner_create': (i, [C.POINTER(vp), i, i, ip, ip, ip, ip, i, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, f, f, f,

@@ -406,17 +406,31 @@ D3R_DEV int xcd_remap(int bid, int nwg) {
 }
 
 // ------------------------------------------------------------------------------ head epilogues
-// postprocess (dust3r/heads/postprocess.py:10-58) with depth_mode ('exp', -inf, inf) and
-// conf_mode ('exp', 1, inf): pts = xyz / max(|xyz|, 1e-8) * expm1(|xyz|); conf = 1 + exp(x).
+// postprocess (dust3r/heads/postprocess.py:10-58). depth_mode (reg_dense_depth :23-47; the reference asserts the bounds away, :29-30):
+//   'exp'    pts = xyz / max(|xyz|, 1e-8) * expm1(|xyz|)      (the released checkpoints, model.py:61)
+//   'linear' pts = xyz
+//   'square' pts = xyz / max(|xyz|, 1e-8) * |xyz|^2
+// conf_mode (reg_dense_conf :50-58):
+//   'exp'     conf = vmin + min(exp(x), vmax - vmin)          (released: ('exp', 1, inf) -> 1 + exp(x))
+//   'sigmoid' conf = (vmax - vmin) * sigmoid(x) + vmin
 // pts / conf element strides between pixels: (3, 1) = the reference's separate pts3d / conf tensors; (8, 8) = the packed
 // [pixel][pts1 conf1 pts2 conf2] record that the multi-GPU path all-gathers as one payload.
-D3R_DEV void postprocess_store(float x, float y, float z, float cl, float* pts, float* conf, size_t pix, int ps, int cs) {
-    const float d = sqrtf(x * x + y * y + z * z);
-    const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+enum { POST_DEPTH_EXP = 0, POST_DEPTH_LINEAR = 1, POST_DEPTH_SQUARE = 2, POST_CONF_EXP = 0, POST_CONF_SIGMOID = 1 };
+struct PostMode {
+    int depth = POST_DEPTH_EXP, conf = POST_CONF_EXP;
+    float cmin = 1.0f, cmax = __builtin_huge_valf();
+};
+D3R_DEV void postprocess_store(float x, float y, float z, float cl, float* pts, float* conf, size_t pix, int ps, int cs, const PostMode pm) {
+    float sc = 1.0f;
+    if (pm.depth != POST_DEPTH_LINEAR) {        // wave-uniform
+        const float d = sqrtf(x * x + y * y + z * z);
+        sc = (pm.depth == POST_DEPTH_EXP ? expm1f(d) : d * d) / fmaxf(d, 1e-8f);
+    }
     pts[ps * pix + 0] = x * sc;
     pts[ps * pix + 1] = y * sc;
     pts[ps * pix + 2] = z * sc;
-    conf[cs * pix] = 1.0f + expf(cl);
+    conf[cs * pix] = pm.conf == POST_CONF_EXP ? pm.cmin + fminf(expf(cl), pm.cmax - pm.cmin)
+                                              : (pm.cmax - pm.cmin) * (1.0f / (1.0f + expf(-cl))) + pm.cmin;
 }
 
 // sum over the four 16-lane rows of a wave, per column (lane & 15), every lane gets the total: v_permlane32_swap exchanges rows {2, 3} of

@@ -394,7 +394,7 @@ D3R_DEV void row_sum4_dpp(float& a0, float& a1, float& a2, float& a3) {
 template <int DT>
 __global__ __launch_bounds__(256) void head_final_kernel(const void* __restrict__ feat, int C, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ pts, float* __restrict__ conf,
-                                                         size_t npix, int pstride, int cstride) {
+                                                         size_t npix, int pstride, int cstride, PostMode post) {
     const int sub = threadIdx.x & 15;
     // this lane's slice of the 4 x C weight matrix stays in registers when C <= 128 (the DPT head: C = 128)
     float wr[4][8];
@@ -441,18 +441,18 @@ __global__ __launch_bounds__(256) void head_final_kernel(const void* __restrict_
             }
         }
         row_sum4_dpp(a0, a1, a2, a3);
-        if (sub == 0 && live) postprocess_store(a0 + b0, a1 + b1, a2 + b2, a3 + b3, pts, conf, pix, pstride, cstride);
+        if (sub == 0 && live) postprocess_store(a0 + b0, a1 + b1, a2 + b2, a3 + b3, pts, conf, pix, pstride, cstride, post);
     }
 }
 hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, const float* b, float* pts, float* conf,
-                             size_t npix, int pstride, int cstride, hipStream_t s) {
+                             size_t npix, int pstride, int cstride, PostMode post, hipStream_t s) {
     if (C % 8 != 0) return hipErrorInvalidValue;
     const int grid = (int)((npix + 15) / 16 < 65536 ? (npix + 15) / 16 : 65536);
     switch (dt) {
-        case D3R_BF16: hipLaunchKernelGGL(head_final_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride); break;
-        case D3R_F16: hipLaunchKernelGGL(head_final_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride); break;
-        case D3R_F32: hipLaunchKernelGGL(head_final_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride); break;
-        case D3R_F16X3: hipLaunchKernelGGL(head_final_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride); break;
+        case D3R_BF16: hipLaunchKernelGGL(head_final_kernel<D3R_BF16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride, post); break;
+        case D3R_F16: hipLaunchKernelGGL(head_final_kernel<D3R_F16>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride, post); break;
+        case D3R_F32: hipLaunchKernelGGL(head_final_kernel<D3R_F32>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride, post); break;
+        case D3R_F16X3: hipLaunchKernelGGL(head_final_kernel<D3R_F16X3>, dim3(grid), dim3(256), 0, s, feat, C, w, b, pts, conf, npix, pstride, cstride, post); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -461,7 +461,7 @@ hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, co
 // LinearPts3d tail (dust3r/heads/linear_head.py:36-41): pixel_shuffle(ps) of the token-major
 // projection (channel = c*ps*ps + py*ps + px) followed by postprocess.
 __global__ __launch_bounds__(256) void linear_head_post_kernel(const float* __restrict__ feat, float* __restrict__ pts,
-                                                               float* __restrict__ conf, int B, int th, int tw, int ps, int pstride, int cstride) {
+                                                               float* __restrict__ conf, int B, int th, int tw, int ps, int pstride, int cstride, PostMode post) {
     const int H = th * ps, W = tw * ps, pp = ps * ps;
     const size_t total = (size_t)B * H * W;
     for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (size_t)gridDim.x * 256) {
@@ -471,14 +471,14 @@ __global__ __launch_bounds__(256) void linear_head_post_kernel(const float* __re
         const int b = (int)(r / H);
         const int ty = y / ps, py = y - ty * ps, tx = x / ps, px = x - tx * ps;
         const float* f = feat + (((size_t)b * th + ty) * tw + tx) * (size_t)(4 * pp) + py * ps + px;
-        postprocess_store(f[0], f[pp], f[2 * pp], f[3 * pp], pts, conf, pix, pstride, cstride);
+        postprocess_store(f[0], f[pp], f[2 * pp], f[3 * pp], pts, conf, pix, pstride, cstride, post);
     }
 }
 hipError_t launch_linear_head_post(const float* feat, float* pts, float* conf, int B, int th, int tw, int ps, int pstride, int cstride,
-                                   hipStream_t s) {
+                                   PostMode post, hipStream_t s) {
     const size_t total = (size_t)B * th * tw * ps * ps;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(linear_head_post_kernel, dim3(grid), dim3(256), 0, s, feat, pts, conf, B, th, tw, ps, pstride, cstride);
+    hipLaunchKernelGGL(linear_head_post_kernel, dim3(grid), dim3(256), 0, s, feat, pts, conf, B, th, tw, ps, pstride, cstride, post);
     return hipGetLastError();
 }
 

@@ -84,6 +84,7 @@ struct d3r_model {
     hipStream_t side = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     bool two_streams = true;
+    PostMode post;                          // depth_mode / conf_mode of the heads (d3r_model_set_postprocess; default = the released checkpoints')
     int out_pstride = 3, out_cstride = 1;   // output element strides between pixels (8, 8 while d3r_model_forward_packed runs)
     // ---- hipGraph replay of small-batch forwards (d3r_model_forward* with B <= graph_max_pairs) ------------------------------------
     // One pair per call (dust3r/demo.py:156 batch_size=1, visloc.py:88) is ~700 launches of kernels that each fill a fraction of the
@@ -373,7 +374,7 @@ bool conv_head4(Ctx& c, const void* in, int B, int Hin, int Win, int cstride, co
     p.Hout = Hin; p.Wout = Win;
     p.M = B * p.Hout * p.Wout; p.K = w.K; p.n_pad = w.n_pad; p.n_rows = w.n_rows; p.n_store = w.Cout;
     p.zero_page = c.m->zero_page;
-    p.epi = EPI_HEAD4; p.flags = GF_RELU; p.out = pts; p.ldo = pstride; p.out2 = conf; p.ldo2 = cstride_conf; p.res1 = w4; p.res2 = b4;
+    p.epi = EPI_HEAD4; p.flags = GF_RELU; p.out = pts; p.ldo = pstride; p.out2 = conf; p.ldo2 = cstride_conf; p.res1 = w4; p.res2 = b4; p.post = c.m->post;
     if (w.k != 3 || w.Cout > 128 || w.Cout % 4 != 0) return false;
     int cfg = gemm_pick_config(p, c.m->dt);
     if (cfg == GEMM_CFG_256x128) {      // fewer pixels (one or two images): the same tile by four waves stacked along m
@@ -520,8 +521,22 @@ extern "C" int d3r_model_set_option(d3r_model* m, int option, int value) {
     if (!m) return D3R_ERR_INVALID;
     if (option == D3R_MODEL_OPT_PROFILE) { m->prof_on = value != 0; m->prof_rec.clear(); return D3R_OK; }
     if (option == D3R_MODEL_OPT_TWO_STREAMS) { m->two_streams = value != 0; return D3R_OK; }
-    if (option == D3R_MODEL_OPT_GRAPH_MAX_PAIRS) { m->graph_max_pairs = value > 0 ? value : 0; if (!value) m->drop_graphs(); return D3R_OK; }
+    if (option == D3R_MODEL_OPT_GRAPH_MAX_PAIRS) {
+        m->graph_max_pairs = value > 0 ? value : 0;
+        if (value <= 0) { hipDeviceSynchronize(); m->drop_graphs(); }     // a replay of the previous call may still be in flight
+        return D3R_OK;
+    }
     return D3R_ERR_INVALID;
+}
+
+// depth_mode / conf_mode of the heads' postprocess (dust3r/heads/postprocess.py:23-58; model.py:58-62 constructor keywords)
+extern "C" int d3r_model_set_postprocess(d3r_model* m, int depth_mode, int conf_mode, float conf_vmin, float conf_vmax) {
+    if (!m || depth_mode < POST_DEPTH_EXP || depth_mode > POST_DEPTH_SQUARE || conf_mode < POST_CONF_EXP || conf_mode > POST_CONF_SIGMOID) return D3R_ERR_INVALID;
+    if (!(conf_vmin < conf_vmax) || (conf_mode == POST_CONF_SIGMOID && !(conf_vmax < __builtin_huge_valf() && conf_vmin > -__builtin_huge_valf()))) return D3R_ERR_INVALID;
+    hipDeviceSynchronize();     // a captured graph carries the old mode in its kernel arguments
+    m->drop_graphs();
+    m->post.depth = depth_mode; m->post.conf = conf_mode; m->post.cmin = conf_vmin; m->post.cmax = conf_vmax;
+    return D3R_OK;
 }
 
 // Per-class totals of the LAST forward run with profiling on (kinds: include/dust3r_hip.h). Synchronises on the recorded events.
@@ -648,7 +663,7 @@ void run_dpt(Ctx& c, const DptHead& D, Arena ar, const void* const hooks[4], con
     }
     if (!fused) {
         conv(c, h1, B, 2 * H8, 2 * W8, 128, D.head2, 1, 1, h2, 128, GF_RELU);
-        D3R_OTHER(launch_head_final(m->dt, h2, 128, D.head4_w, D.head4_b, pts, conf, (size_t)B * 4 * H8 * W8, m->out_pstride, m->out_cstride, c.st));
+        D3R_OTHER(launch_head_final(m->dt, h2, 128, D.head4_w, D.head4_b, pts, conf, (size_t)B * 4 * H8 * W8, m->out_pstride, m->out_cstride, m->post, c.st));
     }
     if (ar.base && ar.off > ar.cap) c.rc = D3R_ERR_ALLOC;
 }
@@ -847,7 +862,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
             if (cf.head_type == 0) {
                 float* lo = lin_out + (size_t)Roff[s] * 4 * ps * ps;
                 gemm_linear(c, hook[s][2], Cd, m->lin_head[s], Ms[s], EPI_F32, lo, 4 * ps * ps);
-                D3R_OTHER(launch_linear_head_post(lo, pts[s], cnf[s], B, own.th, own.tw, ps, m->out_pstride, m->out_cstride, c.st));
+                D3R_OTHER(launch_linear_head_post(lo, pts[s], cnf[s], B, own.th, own.tw, ps, m->out_pstride, m->out_cstride, m->post, c.st));
             } else {
                 for (int b0 = 0; b0 < B; b0 += chunk) {
                     const int bc = (B - b0) < chunk ? (B - b0) : chunk;
@@ -903,7 +918,12 @@ static int run_phases(d3r_model* m, int phases, const float* img1, const float* 
         for (auto& g : m->graphs)
             if (g.key == key) { ge = &g; break; }
         if (!ge) {
-            if (m->graphs.size() >= 16) m->drop_graphs();      // a handful of (batch, size) combinations is the expected use
+            if (m->graphs.size() >= 16) {                       // a handful of (batch, size) combinations is the expected use
+                (void)hipStreamSynchronize(st);                 // a replay enqueued by the previous call (and its staging copies) may still be in flight
+                if (m->side) (void)hipStreamSynchronize(m->side);
+                if (m->cap) (void)hipStreamSynchronize(m->cap);
+                m->drop_graphs();
+            }
             m->graphs.push_back(d3r_model::GraphEntry());
             ge = &m->graphs.back();
             ge->key = key;

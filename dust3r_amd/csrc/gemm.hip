@@ -962,7 +962,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             const int m = m0 + wj * (FJ * 16) + g * 16 + jl;
             if (m < p.M)
                 postprocess_store(r4[0] + hb[0], r4[1] + hb[1], r4[2] + hb[2], r4[3] + hb[3], reinterpret_cast<float*>(p.out),
-                                  reinterpret_cast<float*>(p.out2), (size_t)m, p.ldo, p.ldo2);
+                                  reinterpret_cast<float*>(p.out2), (size_t)m, p.ldo, p.ldo2, p.post);
             return;
         }
     }
@@ -1563,7 +1563,8 @@ int gemm_pick_config(const GemmParams& p, int dt) {
     // SIMD overlap only by half, tools/issue_probe.hip) or the K loop dominates (fc2): default = those projections only.
     // D3R_GEMM_R=0: never; =1: every eligible launch (the A/B of the round).
     if (dt == D3R_F16X3 && !heads && p.epi != EPI_HEADS && p.n_store > 128) {
-        static const int r_on = [] { const char* e = getenv("D3R_GEMM_R"); return e ? atoi(e) : -1; }();
+        const char* e_r = getenv("D3R_GEMM_R");      // read per call, like the other probes (tests move it with monkeypatch)
+        const int r_on = e_r ? atoi(e_r) : -1;
         const long tiles = (long)cdiv(p.M, 256) * cdiv(p.n_store, 128);
         if (r_on == 1 && tiles >= 512) return GEMM_CFG_256x128R;
         if (r_on < 0 && p.epi == EPI_F32 && p.res1 != nullptr && p.K <= 1024 && p.amode == AMODE_LINEAR && tiles >= 1024) return GEMM_CFG_256x128R;
@@ -1586,7 +1587,8 @@ int gemm_pick_config(const GemmParams& p, int dt) {
     if (ok256 && tiles256 >= t256) {
         // nn.Linear operands: the ping-pong schedule measured 1-8 % ahead of the plain 2-stage loop (profiles/r01_call13);
         // implicit-GEMM operands: behind it (the per-tap address arithmetic sits in the load segment) -> plain loop
-        static const bool pp = [] { const char* e = getenv("D3R_GEMM_PP"); return e ? e[0] == '1' : false; }();
+        const char* e_pp = getenv("D3R_GEMM_PP");
+        const bool pp = e_pp ? e_pp[0] == '1' : false;
         return (pp && p.amode == AMODE_LINEAR) ? GEMM_CFG_256PP : GEMM_CFG_256;
     }
     if (const char* e = getenv("D3R_GEMM_MID")) if (e[0] == '2' && !heads) return GEMM_CFG_256x128;

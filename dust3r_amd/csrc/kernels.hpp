@@ -49,6 +49,7 @@ struct GemmParams {
     // diagnostics (d3r_gemm_set_trace): 8 x uint64 per block -- wall-clock ticks at entry / K-loop start / K-loop end / epilogue
     // issued / stores drained, then HW_ID, XCC_ID, blockIdx
     unsigned long long* trace = nullptr;
+    PostMode post;               // EPI_HEAD4: depth_mode / conf_mode of the head's postprocess
 };
 void gemm_set_trace(unsigned long long* buf, size_t capacity_blocks);
 
@@ -84,10 +85,10 @@ hipError_t launch_upsample2x(int dt, const void* in, void* out, void* out_relu, 
                              int Ho, int Wo, hipStream_t s);
 // final DPT stage: relu'd NHWC DT [pix][C] x W[4][C] + b -> postprocess -> pts3d [pix][3], conf [pix]
 hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, const float* b, float* pts, float* conf,
-                             size_t npix, int pstride, int cstride, hipStream_t s);
+                             size_t npix, int pstride, int cstride, PostMode post, hipStream_t s);
 // linear head: proj output fp32 [B*th*tw][(3+1)*ps*ps] -> pixel_shuffle -> postprocess
 hipError_t launch_linear_head_post(const float* feat, float* pts, float* conf, int B, int th, int tw, int ps, int pstride, int cstride,
-                                   hipStream_t s);
+                                   PostMode post, hipStream_t s);
 hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 
 // load-time weight packing on the device (fp32 PyTorch-layout source -> engine layout in DT)
@@ -96,7 +97,6 @@ struct PackParams {
     const float* src = nullptr; void* dst = nullptr;
     size_t numel = 0;
     int kind = PACK_MAT, cols = 0, row_off = 0, dst_cols = 0, cin = 0, cin_pad = 0, ksize = 1, cout_pad = 0;
-    int panel = 8;               // tile map: width of the column panels in tiles (launch_gemm: D3R_GEMM_PANEL probe)
     int kslice_major = 0;        // PACK_CONV: K order of the packed rows (conv_k_slice_major())
 };
 bool conv_k_slice_major();       // process-wide K order of implicit-GEMM operands (kernel and weight packing agree on it)

@@ -182,6 +182,12 @@ size_t d3r_model_device_bytes(const d3r_model* m);
                                          * ~700 partially filled kernels on the GPU, not by the host's launch rate (profiles/r03_a/latency.log);
                                          * the replay only frees the host thread. 0 also drops the captured graphs */
 int d3r_model_set_option(d3r_model* m, int option, int value);
+/* depth_mode / conf_mode of the heads' postprocess: the constructor keywords of dust3r/model.py:58-62, evaluated by
+ * dust3r/heads/postprocess.py:23-58. depth_mode: 0 'exp' (released checkpoints), 1 'linear', 2 'square' (the reference asserts depth
+ * bounds away, postprocess.py:29-30: always (-inf, inf)); conf_mode: 0 'exp' -> vmin + min(exp(x), vmax - vmin), 1 'sigmoid' ->
+ * (vmax - vmin) sigmoid(x) + vmin (finite bounds required). Default (0, 0, 1, +inf). Synchronises the device (captured graphs are dropped).
+ * Errors: D3R_ERR_INVALID for an unknown mode or vmin >= vmax, as the reference raises ValueError(f'bad {mode=}'). */
+int d3r_model_set_postprocess(d3r_model* m, int depth_mode, int conf_mode, float conf_vmin, float conf_vmax);
 int d3r_model_profile_read(d3r_model* m, int kind, int* launches, double* ms, double* work);
 /* launch `index` of the last profiled forward: class, GEMM shape (attention: batch*heads, queries, keys), ms, flops;
  * D3R_ERR_STATE past the last launch */

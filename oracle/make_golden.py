@@ -52,6 +52,26 @@ def forward_golden(config, B, H, W, seed):
                 conf2=r2['conf'].clone())
 
 
+POST_MODES = [(('linear', -inf, inf), ('exp', 1, inf)), (('square', -inf, inf), ('sigmoid', 0, 1)), (('exp', -inf, inf), ('exp', 0, 5)),
+              (('exp', -inf, inf), ('sigmoid', 1, 10)), (('square', -inf, inf), ('exp', 0.5, 3))]
+
+
+def forward_modes_golden(B, H, W, seed):
+    """The unmodified reference model with the head postprocess modes OTHER than the released checkpoints' (heads/postprocess.py:23-58:
+    depth 'linear' / 'square', conf 'sigmoid', finite conf bounds), DPT and linear head: what dust3r_amd.model must reproduce for them."""
+    out = []
+    v1, v2 = synthetic_views(B, H, W, seed=seed)
+    for config in ('tiny_dpt', 'tiny_linear'):
+        for depth_mode, conf_mode in POST_MODES:
+            m = AsymmetricCroCo3DStereo(output_mode='pts3d', depth_mode=depth_mode, conf_mode=conf_mode, landscape_only=False, **MODEL_CONFIGS[config]).eval()
+            m.load_state_dict(synthetic_state_dict(m.state_dict(), 0, OUT_GAIN[config]))
+            with torch.no_grad():
+                r1, r2 = m(v1, v2)
+            out.append(dict(config=config, depth_mode=depth_mode, conf_mode=conf_mode, pts3d=r1['pts3d'].clone(), conf=r1['conf'].clone(),
+                            pts3d_in_other_view=r2['pts3d_in_other_view'].clone(), conf2=r2['conf'].clone()))
+    return dict(kind='forward_modes', B=B, H=H, W=W, view_seed=seed, weight_seed=0, cases=out)
+
+
 def inference_golden(config, n_views, H, W, seed):
     """reference make_pairs + inference(batch_size=2) end to end: pins collate / output structure / edge order."""
     m = ref_model(config)
@@ -210,6 +230,7 @@ if __name__ == '__main__':
         'forward_tiny_dpt.pt': lambda: forward_golden('tiny_dpt', 2, 32, 48, seed=1),
         'forward_tiny_linear.pt': lambda: forward_golden('tiny_linear', 3, 32, 32, seed=2),
         'inference_tiny_dpt.pt': lambda: inference_golden('tiny_dpt', 3, 32, 48, seed=3),
+        'forward_post_modes.pt': lambda: forward_modes_golden(1, 32, 48, seed=7),
         'aligner_4v.pt': lambda: aligner_golden(4, 24, 32, seed=0, niter=300),
         'aligner_c4.pt': lambda: aligner_c4_golden(),
         'mst_init_8v.pt': lambda: mst_init_golden(8, 64, 96, seed=3),

@@ -140,6 +140,31 @@ def test_forward_matches_reference_golden(gpu, name):
     assert float(((e1['conf'].cpu() - g['conf']).abs() / g['conf']).max()) < 1e-3
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3', 'bf16'])
+def test_forward_postprocess_modes_match_reference_golden(gpu, precision):
+    """depth_mode 'linear' / 'square', conf_mode 'sigmoid' and finite conf bounds (heads/postprocess.py:23-58; constructor keywords of
+    model.py:58-62) on the DPT head (fused EPI_HEAD4 tail in split-fp16, head_final_kernel otherwise) and the linear head, against
+    vectors produced by the unmodified reference model in those modes (oracle/make_golden.py forward_modes_golden)."""
+    from dust3r_amd.model import AsymmetricCroCo3DStereo
+    from dust3r_amd.synthetic import OUT_GAIN, synthetic_state_dict
+    g = torch.load(os.path.join(GOLD, 'forward_post_modes.pt'), weights_only=False)
+    v1, v2 = synthetic_views(g['B'], g['H'], g['W'], seed=g['view_seed'])
+    tol, mean_tol, stat = TOLS[precision]
+    for c in g['cases']:
+        m = AsymmetricCroCo3DStereo(precision=precision, landscape_only=False, depth_mode=c['depth_mode'], conf_mode=c['conf_mode'], **MODEL_CONFIGS[c['config']])
+        m.load_state_dict(synthetic_state_dict({k: torch.empty(v, device='meta') for k, v in m._spec.items()}, g['weight_seed'], OUT_GAIN[c['config']]))
+        e1, e2 = m.to(gpu)(v1, v2)
+        tag = (c['config'], c['depth_mode'][0], c['conf_mode'])
+        for a, b in ((e1['pts3d'], c['pts3d']), (e2['pts3d_in_other_view'], c['pts3d_in_other_view'])):
+            mx, mean = pix_rel(a, b)
+            assert (mx if stat == 'max' else pix_rel_p99(a, b)) < tol and mean < mean_tol, (tag, mx, mean)
+        for a, b in ((e1['conf'], c['conf']), (e2['conf'], c['conf2'])):
+            e = ((a.cpu() - b).abs() / b.abs().clamp_min(1e-3)).flatten()
+            assert float(e.max() if stat == 'max' else e.kthvalue(int(0.99 * e.numel()))[0]) < 3 * tol, (tag, float(e.max()))
+            lo, hi = c['conf_mode'][1], c['conf_mode'][2]
+            assert float(a.min()) >= lo - 1e-6 and float(a.max()) <= hi + 1e-6
+
+
 def test_forward_batch_position_independence(gpu):
     """A pair's result must not depend on where it sits in the batch (bit-exact): this is what makes pair
     sharding across ranks and the symmetrised-batch shortcut output-identical."""

@@ -381,3 +381,23 @@ def test_gemm_tile_dispatch_table(monkeypatch):
     monkeypatch.setenv('D3R_GEMM_CFG', '2')
     assert cfg(x3, 49152, 4096, 1024, GELU) == 2
     assert lib.d3r_gemm_tile_config(x3, 0, 8, 8, 0, 0) < 0 or lib.d3r_gemm_tile_config(x3, 0, 8, 8, 0, 0) > 8     # invalid arguments: an error code, not a configuration
+
+
+def test_postprocess_mode_keywords_follow_the_reference():
+    """model.py:58-62 / heads/postprocess.py:23-58: every depth / conf mode of the reference is accepted (the engine implements them,
+    include/dust3r_hip.h d3r_model_set_postprocess), an unknown mode raises the reference's ValueError, depth bounds are asserted away."""
+    from dust3r_amd.model import AsymmetricCroCo3DStereo
+    from dust3r_amd.synthetic import MODEL_CONFIGS
+    inf = float('inf')
+    for dm in ('exp', 'linear', 'square'):
+        for cm in (('exp', 1, inf), ('exp', 0, 5), ('sigmoid', 0, 1)):
+            m = AsymmetricCroCo3DStereo(depth_mode=(dm, -inf, inf), conf_mode=cm, landscape_only=False, **MODEL_CONFIGS['tiny_dpt'])
+            assert m.depth_mode == (dm, -inf, inf) and m.conf_mode == cm
+    with pytest.raises(ValueError):
+        AsymmetricCroCo3DStereo(depth_mode=('cube', -inf, inf), landscape_only=False, **MODEL_CONFIGS['tiny_dpt'])
+    with pytest.raises(ValueError):
+        AsymmetricCroCo3DStereo(conf_mode=('tanh', 0, 1), landscape_only=False, **MODEL_CONFIGS['tiny_dpt'])
+    with pytest.raises(AssertionError):
+        AsymmetricCroCo3DStereo(depth_mode=('exp', 0, 10), landscape_only=False, **MODEL_CONFIGS['tiny_dpt'])
+    with pytest.raises(AssertionError):
+        AsymmetricCroCo3DStereo(conf_mode=('sigmoid', 0, inf), landscape_only=False, **MODEL_CONFIGS['tiny_dpt'])

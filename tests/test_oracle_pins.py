@@ -35,6 +35,24 @@ def test_forward_oracle_equals_reference_golden(name):
         assert float((a - b).abs().max() / b.abs().max()) < 1e-5
 
 
+def test_forward_oracle_postprocess_modes_equal_reference_golden():
+    """heads/postprocess.py:23-58 modes other than the released checkpoints' (depth 'linear' / 'square', conf 'sigmoid', finite bounds):
+    the oracle against the fixture the unmodified reference model produced (oracle/make_golden.py forward_modes_golden)."""
+    from oracle.dust3r_ref import DUSt3RRef
+    g = _g('forward_post_modes.pt')
+    v1, v2 = synthetic_views(g['B'], g['H'], g['W'], seed=g['view_seed'])
+    seen = set()
+    for c in g['cases']:
+        m = DUSt3RRef(depth_mode=c['depth_mode'], conf_mode=c['conf_mode'], **MODEL_CONFIGS[c['config']]).eval()
+        m.load_state_dict(synthetic_state_dict(m.state_dict(), g['weight_seed'], OUT_GAIN[c['config']]))
+        with torch.no_grad():
+            r1, r2 = m(v1, v2)
+        for a, b in ((r1['pts3d'], c['pts3d']), (r1['conf'], c['conf']), (r2['pts3d_in_other_view'], c['pts3d_in_other_view']), (r2['conf'], c['conf2'])):
+            assert a.shape == b.shape and float((a - b).abs().max() / b.abs().max()) < 1e-5, (c['config'], c['depth_mode'], c['conf_mode'])
+        seen.add((c['depth_mode'][0], c['conf_mode'][0]))
+    assert {d for d, _ in seen} == {'exp', 'linear', 'square'} and {k for _, k in seen} == {'exp', 'sigmoid'}
+
+
 def test_inference_structure_golden():
     """make_pairs + collate + output dict layout of the mirror == the reference's inference() golden."""
     from dust3r_amd.image_pairs import make_pairs

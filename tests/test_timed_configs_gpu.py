@@ -1,0 +1,228 @@
+"""Parity ON THE CONFIGURATIONS THAT ARE TIMED (BASELINE.json configs[0..4]) -- round 4.
+
+The oracle comparisons of tests/test_forward_gpu.py run one pair per call; bench.py times 32 pairs per call, the only place where the
+run-time tile choice lands on the 256x256 / 512x128 tiles on the full model and where tensors pass 4 GiB. These tests close that gap:
+
+  * configs[1]: pairs {0, 15, 31} of the 32-pair 512x384 batch are BIT-EQUAL to the same pairs run one per call -- which is the call
+    shape the oracle tests check -- through forward, forward_packed and encode / decode;
+  * configs[0] / the released linear-head checkpoints: DUSt3R_ViTLarge_BaseDecoder_224_linear and _512_linear at full size against the
+    CPU oracle (README.md:99-103, dust3r/heads/linear_head.py:30-41);
+  * the default mode against the CPU oracle on six weight seeds (was a log of tools/oracle_survey.py);
+  * configs[2]: 20 views -> 190 pairs at full size through inference_sharded (RCCL, world 1: encode-once + packed payload + the one
+    all-gather) bit-equal to inference() pair by pair on sampled pairs;
+  * configs[4]: 100 views, swin-3 -> 600 pairs, forward + global_aligner(init='mst') end to end on the engine: finite, loss decreasing,
+    and sampled pairs bit-equal to one-pair calls.
+"""
+import os
+
+import pytest
+import torch
+
+from dust3r_amd.synthetic import MODEL_CONFIGS, synthetic_views
+
+pytestmark = pytest.mark.gpu
+C2 = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
+
+
+def pix_rel_stats(a, b):
+    e = ((a.float().cpu() - b).norm(dim=-1) / b.norm(dim=-1).clamp_min(1e-8)).flatten()
+    s = e.sort().values
+    q = lambda f: float(s[min(int(f * s.numel()), s.numel() - 1)])   # noqa: E731
+    return dict(max=float(s[-1]), p9999=q(0.9999), p99=q(0.99), mean=float(e.mean()))
+
+
+def engine_from_oracle(oracle, config, precision, gpu):
+    from dust3r_amd.model import AsymmetricCroCo3DStereo
+    m = AsymmetricCroCo3DStereo(precision=precision, landscape_only=False, **MODEL_CONFIGS[config])
+    m.load_state_dict(oracle.state_dict(), strict=True)
+    return m.to(gpu)
+
+
+def one_pair(v, b):
+    return dict(img=v['img'][b:b + 1], true_shape=v['true_shape'][b:b + 1], idx=[v['idx'][b]], instance=[v['instance'][b]])
+
+
+@pytest.fixture(scope='module')
+def bench_engine(gpu):
+    from bench import build_model        # bench.py's full-size synthetic weights, generated in HBM
+    eng = build_model('fp16x3', gpu)
+    yield eng
+    eng._destroy_engine()
+    torch.cuda.empty_cache()
+
+
+def test_c2_batch_of_32_is_bit_equal_to_oracle_checked_single_pair_calls(gpu, bench_engine):
+    """BASELINE configs[1], exactly what bench.py times: 32 pairs 512x384 per call, default precision. Pairs 0 / 15 / 31 of the batch
+    against the same pairs run one per call (the call shape test_full_size_fp32_pair_matches_oracle holds to the CPU oracle), for the
+    three entry points the timed paths use. Bit-equal: every kernel is batch-position independent and no tile choice changes a K order."""
+    from dust3r_amd.parallel import unpack_predictions
+    eng = bench_engine
+    v1, v2 = synthetic_views(32, 384, 512, seed=0, device=gpu)
+    f1, f2 = eng(v1, v2)
+    full = [t.clone() for t in (f1['pts3d'], f1['conf'], f2['pts3d_in_other_view'], f2['conf'])]
+    assert all(bool(torch.isfinite(t).all()) for t in full)
+    packed = eng.forward_packed(v1, v2)
+    p1, p2 = unpack_predictions(packed)
+    for a, b in zip((p1['pts3d'], p1['conf'], p2['pts3d_in_other_view'], p2['conf']), full):
+        assert torch.equal(a, b)
+    feat = eng.encode_images(torch.cat((v1['img'], v2['img'])))           # 64 images through the encoder, then 32 pairs decoded
+    d1, d2 = eng.decode_pairs(feat, 384, 512)
+    for a, b in zip((d1['pts3d'], d1['conf'], d2['pts3d_in_other_view'], d2['conf']), full):
+        assert torch.equal(a, b)
+    del packed, p1, p2, d1, d2, feat
+    for b in (0, 15, 31):
+        s1, s2 = one_pair(v1, b), one_pair(v2, b)
+        o1, o2 = eng(s1, s2)
+        single = (o1['pts3d'], o1['conf'], o2['pts3d_in_other_view'], o2['conf'])
+        for name, a, w in zip(('pts1', 'conf1', 'pts2', 'conf2'), single, full):
+            assert torch.equal(a[0], w[b]), (b, name, float((a[0] - w[b]).abs().max()))
+        pk = eng.forward_packed(s1, s2)
+        assert torch.equal(pk[0, ..., 0:3], full[0][b]) and torch.equal(pk[0, ..., 7], full[3][b])
+        fs = eng.encode_images(torch.cat((s1['img'], s2['img'])))
+        e1, e2 = eng.decode_pairs(fs, 384, 512)
+        assert torch.equal(e1['pts3d'][0], full[0][b]) and torch.equal(e2['pts3d_in_other_view'][0], full[2][b])
+
+
+@pytest.mark.parametrize('cfg,H,W', [('DUSt3R_ViTLarge_BaseDecoder_224_linear', 224, 224), ('DUSt3R_ViTLarge_BaseDecoder_512_linear', 384, 512)])
+def test_full_size_linear_head_models_match_oracle(gpu, cfg, H, W):
+    """The two released linear-head models at full size (configs[0] names the 224 one), one pair each: fp32 engine and the default
+    engine against the CPU oracle, per-pixel max <= 1e-3 (linear_head.py:30-41: Linear 768 -> 4 * 16 * 16, pixel_shuffle, postprocess)."""
+    from oracle.dust3r_ref import build_ref_model_fast
+    oracle = build_ref_model_fast(cfg)
+    eng = engine_from_oracle(oracle, cfg, 'fp32', gpu)
+    v1, v2 = synthetic_views(1, H, W, seed=2)
+    with torch.no_grad():
+        r1, r2 = oracle(v1, v2)
+    for prec in ('fp32', 'fp16x3'):
+        eng.set_precision(prec)
+        e1, e2 = eng(v1, v2)
+        assert e1['pts3d'].shape == (1, H, W, 3) and e2['conf'].shape == (1, H, W)
+        for name, a, b in (('pts1', e1['pts3d'], r1['pts3d']), ('pts2', e2['pts3d_in_other_view'], r2['pts3d_in_other_view'])):
+            s = pix_rel_stats(a, b)
+            print(f'[{cfg} {prec}] {name} rel err max {s["max"]:.3e} p99 {s["p99"]:.3e} mean {s["mean"]:.3e}')
+            assert s['max'] < 1e-3 and s['mean'] < 2e-4, (prec, name, s)
+        for a, b in ((e1['conf'], r1['conf']), (e2['conf'], r2['conf'])):
+            assert float(((a.cpu() - b).abs() / b).max()) < 3e-3
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_default_mode_against_cpu_oracle_over_weight_seeds(gpu, seed):
+    """tools/oracle_survey.py's six weight seeds inside the suite: BASELINE model, one 512x384 pair per seed, the default engine
+    (fp16x3) and the exact-fp32 engine against the CPU ORACLE (not against each other). Bar: per-pixel max <= 1e-3 (north star), with the
+    margins measured in round 3 asserted too (worst of six: max 2.8e-4, p99.99 5.4e-5, mean 1.0e-5)."""
+    from oracle.dust3r_ref import build_ref_model_fast
+    oracle = build_ref_model_fast(C2, seed=seed)
+    v1, v2 = synthetic_views(1, 384, 512, seed=100 + seed)
+    with torch.no_grad():
+        r1, r2 = oracle(v1, v2)
+    ref = torch.cat((r1['pts3d'], r2['pts3d_in_other_view']))
+    eng = engine_from_oracle(oracle, C2, 'fp32', gpu)
+    for prec in ('fp32', 'fp16x3'):
+        eng.set_precision(prec)
+        e1, e2 = eng(v1, v2)
+        s = pix_rel_stats(torch.cat((e1['pts3d'], e2['pts3d_in_other_view'])), ref)
+        print(f'[512_dpt weights seed {seed} {prec} vs CPU oracle] max {s["max"]:.3e} p99.99 {s["p9999"]:.3e} p99 {s["p99"]:.3e} mean {s["mean"]:.3e}')
+        assert s['max'] < 1e-3 and s['p9999'] < 2e-4 and s['mean'] < 5e-5, (prec, seed, s)
+    eng._destroy_engine()
+
+
+def _init_rccl_world1(gpu):
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=gpu)
+    return dist
+
+
+def test_c3_190_pairs_sharded_on_the_engine(gpu, bench_engine):
+    """BASELINE configs[2] on the real engine at full size: 20 synthetic 512x384 views -> make_pairs('complete', symmetrize=False) = 190
+    pairs -> inference_sharded (RCCL, world 1: each distinct image encoded once, heads write the packed payload, ONE all-gather).
+    Six sampled pairs are bit-equal to inference() run on that pair alone (= one engine call per pair, the reference's schedule)."""
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.inference import inference
+    from dust3r_amd.parallel import inference_sharded
+    from dust3r_amd.synthetic import synthetic_image_list
+    eng = bench_engine
+    imgs = synthetic_image_list(20, 384, 512, seed=20)
+    pairs = make_pairs(imgs, 'complete', None, symmetrize=False)
+    assert len(pairs) == 190
+    dist = _init_rccl_world1(gpu)
+    try:
+        out = inference_sharded(pairs, eng, gpu, batch_size=8)
+    finally:
+        dist.destroy_process_group()
+    assert out['pred1']['pts3d'].shape == (190, 384, 512, 3) and out['pred2']['conf'].shape == (190, 384, 512)
+    assert bool(torch.isfinite(out['pred1']['pts3d']).all()) and bool(torch.isfinite(out['pred2']['pts3d_in_other_view']).all())
+    assert out['view1']['idx'] == [int(a['idx']) for a, _ in pairs] and out['view2']['idx'] == [int(b['idx']) for _, b in pairs]
+    for k in (0, 37, 95, 96, 150, 189):
+        one = inference([pairs[k]], eng, gpu, batch_size=1, verbose=False, encode_once=False)
+        assert torch.equal(one['pred1']['pts3d'][0], out['pred1']['pts3d'][k]), k
+        assert torch.equal(one['pred1']['conf'][0], out['pred1']['conf'][k]), k
+        assert torch.equal(one['pred2']['pts3d_in_other_view'][0], out['pred2']['pts3d_in_other_view'][k]), k
+        assert torch.equal(one['pred2']['conf'][0], out['pred2']['conf'][k]), k
+
+
+def test_c5_100_views_swin_forward_and_alignment_on_the_engine(gpu, bench_engine):
+    """BASELINE configs[4] on one GPU at full size: 100 views, make_pairs('swin-3', symmetrize=True) = 600 pairs -> inference() ->
+    global_aligner(PointCloudOptimizer).compute_global_alignment(init='mst', niter=30). Sampled pairs bit-equal to one-pair calls; the
+    alignment runs (finite poses / focals / loss) -- its parity is tests/test_aligner_gpu.py's subject, on geometric scenes."""
+    from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.inference import inference
+    from dust3r_amd.synthetic import synthetic_image_list
+    eng = bench_engine
+    imgs = synthetic_image_list(100, 384, 512, seed=50)
+    pairs = make_pairs(imgs, 'swin-3', None, symmetrize=True)
+    assert len(pairs) == 600
+    out = inference(pairs, eng, gpu, batch_size=1, verbose=False)
+    assert out['pred1']['pts3d'].shape == (600, 384, 512, 3)
+    for k in (0, 299, 300, 599):
+        one = inference([pairs[k]], eng, gpu, batch_size=1, verbose=False, encode_once=False)
+        assert torch.equal(one['pred1']['pts3d'][0], out['pred1']['pts3d'][k]), k
+        assert torch.equal(one['pred2']['pts3d_in_other_view'][0], out['pred2']['pts3d_in_other_view'][k]), k
+    scene = global_aligner(out, gpu, mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
+    assert scene.n_imgs == 100 and scene.n_edges == 600
+    loss = scene.compute_global_alignment(init='mst', niter=30, schedule='cosine', lr=0.01)
+    poses, focals = scene.get_im_poses(), scene.get_focals()
+    assert poses.shape == (100, 4, 4) and bool(torch.isfinite(poses).all()) and bool(torch.isfinite(focals).all())
+    assert loss == loss and loss < float('inf')
+
+
+@pytest.mark.parametrize('workload', ['c2', 'c3', 'c5'])
+def test_bench_multi_rank_branches_on_one_device(gpu, workload, tmp_path):
+    """bench.py --gpus 2 for every workload, both ranks on this box's one GPU (D3R_BENCH_ONE_DEVICE=1, gloo moves the CUDA payload: RCCL
+    refuses two ranks on a device): the N > 1 code of the driver's scaling run -- shard bounds, per-rank encode-once, the all-gather,
+    rank-0 alignment, max-over-ranks timing -- executes, prints ONE valid JSON line, and its own parity_check passes. A self-test of the
+    code path, NOT a scaling measurement (the line says so in `data`); the artefact is kept under gpurun_out/ for profiles/."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, D3R_BENCH_ONE_DEVICE='1', D3R_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    extra = ['--pairs', '4'] if workload == 'c2' else []
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--workload', workload, '--no-cpu-baseline', '--no-fast', '--no-profile',
+           '--no-aligner'] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and 'SELF-TEST' in d['data'] and d['config']['workload']
+    pc = d['parity_check']
+    assert all(v['pass'] for v in pc.values()), pc
+    if workload != 'c2':
+        assert sum(d['config']['pairs_per_rank']) == d['config']['pairs'] and d['scaling'] == 'strong'
+    if workload == 'c5':
+        assert d['stages']['poses_finite'] and d['stages']['final_loss'] == d['stages']['final_loss']
+    out_dir = os.path.join(root, 'gpurun_out')
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f'bench_gpus2_selftest_{workload}.json'), 'w') as f:
+        f.write(lines[0] + '\n')
