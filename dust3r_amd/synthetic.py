@@ -150,7 +150,7 @@ def scene_edges(n_views, scene_graph='complete', symmetrize=False):
 
 
 def synthetic_scene(n_views, H, W, seed=0, scene_graph='complete', symmetrize=False, noise=0.01, device='cpu',
-                    perturb=True):
+                    perturb=True, device_rng=False):
     """Multi-view scene for the global aligner: cameras on a circle of radius 2
     looking at the origin, focal 1.2 W, depth 2 + 0.5 smooth-noise; per edge the pairwise
     pointmaps are the exact geometry times a random scale U(0.5, 2) plus N(0, noise), conf =
@@ -160,6 +160,8 @@ def synthetic_scene(n_views, H, W, seed=0, scene_graph='complete', symmetrize=Fa
                      perturbed (rotations <=5 deg, translations 10 %, log-depth N(0, .05)), to be
                      loaded into oracle and engine alike (no RNG inside the optimisation loop)
       gt             cam2world (n,4,4), focal, depth (n,H,W)
+    `device_rng`: draw the per-edge noise / confidences with `device`'s generator instead of the CPU one (same distributions, other values;
+    600 edges at 512x384 take 1 s instead of 30 s) -- for timing workloads only: the golden fixtures and parity tests use the CPU values.
     """
     rng = np.random.RandomState(seed)
     g = torch.Generator(device='cpu').manual_seed(seed)
@@ -194,13 +196,15 @@ def synthetic_scene(n_views, H, W, seed=0, scene_graph='complete', symmetrize=Fa
     pred_j = torch.empty((E, H, W, 3), dtype=torch.float32, device=device)
     conf_i = torch.empty((E, H, W), dtype=torch.float32, device=device)
     conf_j = torch.empty((E, H, W), dtype=torch.float32, device=device)
+    gd = torch.Generator(device=device).manual_seed(seed) if device_rng else None
+    rnd = (lambda shape: torch.randn(shape, generator=gd, device=device)) if device_rng else (lambda shape: torch.randn(shape, generator=g).to(device))
     for e, (i, j) in enumerate(edges):
         s = float(scales[e])
         pj = torch.einsum('ij,hwj->hwi', w2c[i, :3, :3], world[j]) + w2c[i, :3, 3]
-        pred_i[e] = s * cam_pts[i] + noise * torch.randn((H, W, 3), generator=g).to(device)
-        pred_j[e] = s * pj + noise * torch.randn((H, W, 3), generator=g).to(device)
-        conf_i[e] = 1 + torch.exp(1 + 0.5 * torch.randn((H, W), generator=g)).to(device)
-        conf_j[e] = 1 + torch.exp(1 + 0.5 * torch.randn((H, W), generator=g)).to(device)
+        pred_i[e] = s * cam_pts[i] + noise * rnd((H, W, 3))
+        pred_j[e] = s * pj + noise * rnd((H, W, 3))
+        conf_i[e] = 1 + torch.exp(1 + 0.5 * rnd((H, W)))
+        conf_j[e] = 1 + torch.exp(1 + 0.5 * rnd((H, W)))
     ts = torch.tensor([[H, W]] * E, dtype=torch.int32)
     output = dict(
         view1=dict(idx=[i for i, j in edges], instance=[str(i) for i, j in edges], true_shape=ts),

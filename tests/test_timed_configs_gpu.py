@@ -167,8 +167,8 @@ def test_c3_190_pairs_sharded_on_the_engine(gpu, bench_engine):
 
 def test_c5_100_views_swin_forward_and_alignment_on_the_engine(gpu, bench_engine):
     """BASELINE configs[4] on one GPU at full size: 100 views, make_pairs('swin-3', symmetrize=True) = 600 pairs -> inference() ->
-    global_aligner(PointCloudOptimizer).compute_global_alignment(init='mst', niter=30). Sampled pairs bit-equal to one-pair calls; the
-    alignment runs (finite poses / focals / loss) -- its parity is tests/test_aligner_gpu.py's subject, on geometric scenes."""
+    then global_aligner(PointCloudOptimizer).compute_global_alignment(init='mst', niter=300) on a consistent synthetic scene of the
+    same shape. Sampled pairs of the forward bit-equal to one-pair calls; the alignment converges (its parity is tests/test_aligner_gpu.py's subject)."""
     from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
     from dust3r_amd.image_pairs import make_pairs
     from dust3r_amd.inference import inference
@@ -183,12 +183,19 @@ def test_c5_100_views_swin_forward_and_alignment_on_the_engine(gpu, bench_engine
         one = inference([pairs[k]], eng, gpu, batch_size=1, verbose=False, encode_once=False)
         assert torch.equal(one['pred1']['pts3d'][0], out['pred1']['pts3d'][k]), k
         assert torch.equal(one['pred2']['pts3d_in_other_view'][0], out['pred2']['pts3d_in_other_view'][k]), k
-    scene = global_aligner(out, gpu, mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
+    assert bool(torch.isfinite(out['pred1']['pts3d']).all()) and bool(torch.isfinite(out['pred2']['conf']).all())
+    del out
+    # the alignment stage on a geometrically consistent scene of the same shape (random-init weights do not produce one: their pointmaps
+    # are finite but meaningless, and the MST / Procrustes / focal initialisation of such input ends in NaN)
+    from dust3r_amd.synthetic import synthetic_scene
+    sc, _, gt = synthetic_scene(100, 384, 512, seed=0, scene_graph='swin-3', symmetrize=True, noise=0.002, device=gpu, device_rng=True)
+    assert sc['view1']['idx'] == [int(a['idx']) for a, _ in pairs] and sc['view2']['idx'] == [int(b['idx']) for _, b in pairs]
+    scene = global_aligner(sc, gpu, mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
     assert scene.n_imgs == 100 and scene.n_edges == 600
-    loss = scene.compute_global_alignment(init='mst', niter=30, schedule='cosine', lr=0.01)
+    loss = scene.compute_global_alignment(init='mst', niter=300, schedule='cosine', lr=0.01)
     poses, focals = scene.get_im_poses(), scene.get_focals()
     assert poses.shape == (100, 4, 4) and bool(torch.isfinite(poses).all()) and bool(torch.isfinite(focals).all())
-    assert loss == loss and loss < float('inf')
+    assert loss < 0.05 and float((focals.detach().flatten().cpu() / gt['focal'] - 1).abs().max()) < 0.05
 
 
 @pytest.mark.parametrize('workload', ['c2', 'c3', 'c5'])
@@ -221,7 +228,7 @@ def test_bench_multi_rank_branches_on_one_device(gpu, workload, tmp_path):
     if workload != 'c2':
         assert sum(d['config']['pairs_per_rank']) == d['config']['pairs'] and d['scaling'] == 'strong'
     if workload == 'c5':
-        assert d['stages']['poses_finite'] and d['stages']['final_loss'] == d['stages']['final_loss']
+        assert d['stages']['poses_finite'] and d['stages']['final_loss'] < 0.05 and d['stages']['gathered_predictions_finite']
     out_dir = os.path.join(root, 'gpurun_out')
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, f'bench_gpus2_selftest_{workload}.json'), 'w') as f:
