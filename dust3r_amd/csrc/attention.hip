@@ -297,11 +297,18 @@ D3R_DEV float xor32_sum(float v) {
 // MFMAs, bit 2 the per-tile barrier, bit 3 the staging of the next tiles (global loads + LDS writes) -- what each part costs next to the others
 // NW = waves per workgroup (4: 128 queries, two workgroups per CU; 8: 256 queries, one per CU -- every K / V^T tile staged once per 256
 // queries instead of 128: half the L2 -> LDS traffic per query, but nothing covers a workgroup's prologue).
-template <int ODT, int PROBE = 0, int NW = 4>
+// DMA (round 4): the K and V^T tiles go L2 -> LDS with global_load_lds_dwordx4 (1 KiB per wave instruction, no VGPR round trip, no ds_write:
+// the ablation of round 3 priced the register staging -- 8 buffer loads + 12 LDS writes per thread and tile -- at 30 % of the kernel). The LDS
+// image of a DMA is lane-linear (lane l's 16 bytes land at base + 16 l), so rows cannot be padded: they are 256 bytes and the bank spread comes
+// from an XOR swizzle applied on the per-lane SOURCE address and again on the fragment reads -- physical 16-byte slot = logical slot ^ (row & 15):
+//   K rows   (logical slot = memory chunk: 8 groups [hi x8][lo x8]): the 16 rows of a ds_read_b128 service group hit 16 distinct slots;
+//   V^T rows (logical slot = (hi / lo plane) * 8 + 8-key group, as in the padded image): the 8-byte operand reads of 16 consecutive rows
+//            spread over all 16 slots of the 256-byte row, i.e. two rows per 128-byte bank window (2-way; the reads are ds_read_b64).
+template <int ODT, int PROBE = 0, int NW = 4, bool DMA = false>
 __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TR = Traits<D3R_F16X3>;
-    constexpr int ROWB = 256, KROW = ROWB + 16, VROW = ROWB + 8;
+    constexpr int ROWB = 256, KROW = DMA ? ROWB : ROWB + 16, VROW = DMA ? ROWB : ROWB + 8;
     constexpr int KT = 64 * KROW, VT = 64 * VROW;   // K ring: smem[0, 2 KT), V^T ring: smem[2 KT, 2 KT + 2 VT)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -369,24 +376,60 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
         }
     };
 
+    // ---- DMA staging: piece i of wave w fills rows 4 (w + NW i) .. + 3 of a tile; lane l -> row + (l >> 4), physical slot l & 15
+    constexpr int DPW = 16 / NW;                                  // 1 KiB pieces per wave, tile and operand
+    const int drow = wave * 4 + (lane >> 4);                      // + 4 NW i: the low four bits of the row (the swizzle key) do not depend on i
+    const int dlog = (lane & 15) ^ (drow & 15);                   // logical slot held by this lane's physical slot
+    const uint32_t dk_off = (uint32_t)(dlog * 16);                                        // K: logical slot = memory chunk
+    const uint32_t dv_off = (uint32_t)(drow * p.ldv * 4 + ((((dlog & 7) << 1) | (dlog >> 3)) * 16));   // V^T: plane-major logical slot -> memory chunk (group, hi / lo)
+    const uint32_t lds_w = lds_addr(smem) + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+    auto dma_piece = [&](const void* sbase, uint32_t vo, uint32_t dst) __attribute__((always_inline)) {
+        // M0 = LDS destination of the wave's 1 KiB; wave-uniform 64-bit base in an SGPR pair, 32-bit byte offset per lane. s_nop 4: an SGPR
+        // freshly written by v_readfirstlane must not be read by a VMEM instruction within five wait states (hipcc does not see inside the asm)
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sbase), "s"(dst) : "memory", "m0");
+    };
+    auto dma_k = [&](int key0, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const int key = min(key0 + drow + 4 * NW * i, p.Nk - 1);          // ragged last tile: rows beyond Nk repeat the last key (their scores are masked)
+            dma_piece(kptr, (uint32_t)(key * ROWB) + dk_off, lds_w + (uint32_t)(buf * KT + i * NW * 1024));
+        }
+    };
+    auto dma_v = [&](int key0, int buf) __attribute__((always_inline)) {   // V^T tiles are always inside the zero-padded ldv
+#pragma unroll
+        for (int i = 0; i < DPW; ++i)
+            dma_piece(vptr + (size_t)key0 * 4 + (size_t)(4 * NW * i) * p.ldv * 4, dv_off, lds_w + (uint32_t)(2 * KT + buf * VT + i * NW * 1024));
+    };
+
     const int ntiles = (p.Nk + 63) / 64;
     const float c = p.scale * 1.44269504088896340736f;  // fold log2(e): p = exp2(s c - m c)
-    const int koff = l31 * KROW + hh * 32;               // this lane's K row / group inside a 32-key block
-    const int voff = l31 * VROW + hh * 8;                // this lane's V^T row / 4-key slot
+    const int koff = DMA ? l31 * KROW : l31 * KROW + hh * 32;   // this lane's K row (/ group inside a 32-key block: padded image)
+    const int voff = DMA ? l31 * VROW : l31 * VROW + hh * 8;    // this lane's V^T row (/ 4-key slot: padded image)
+    // swizzled images: byte offsets inside the 256-byte row. K: chunk 4 ks + 2 hh + lo; V^T: logical slot 2 g (+ 1: second 8-key group, + 8: lo plane)
+    const int sx = (l31 & 15) * 16;
+    int kxo[8], vxo[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kxo[i] = (((i >> 1) * 4 + 2 * hh + (i & 1)) * 16) ^ sx;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) vxo[g] = ((2 * g * 16) ^ sx) + hh * 8;
+    // K fragment (step st = (ks, rb), half lo) and its address in both images
+    auto kfrag_ptr = [&](const char* kb, int st, int lo) __attribute__((always_inline)) -> const char* {
+        if constexpr (DMA) return kb + (st & 1) * 32 * KROW + kxo[(st >> 1) * 2 + lo];
+        else return kb + (st & 1) * 32 * KROW + (st >> 1) * 64 + lo * 16;
+    };
 
     // S^T[key][query] of one tile: 24 MFMAs; fragment reads one (ks, rb) step ahead
     auto qk_tile = [&](int kbuf, f32x16_t (&s)[2]) __attribute__((always_inline)) {
         const char* kb = smem + kbuf * KT + koff;
         s[0] = s[1] = (f32x16_t){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        uint4 kh = *reinterpret_cast<const uint4*>(kb), kl = *reinterpret_cast<const uint4*>(kb + 16);
+        uint4 kh = *reinterpret_cast<const uint4*>(kfrag_ptr(kb, 0, 0)), kl = *reinterpret_cast<const uint4*>(kfrag_ptr(kb, 0, 1));
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
             const int ks = st >> 1, rb = st & 1;
             uint4 nh = kh, nl = kl;
             if (st + 1 < 8) {
-                const char* kr = kb + ((st + 1) & 1) * 32 * KROW + ((st + 1) >> 1) * 64;
-                nh = *reinterpret_cast<const uint4*>(kr);
-                nl = *reinterpret_cast<const uint4*>(kr + 16);
+                nh = *reinterpret_cast<const uint4*>(kfrag_ptr(kb, st + 1, 0));
+                nl = *reinterpret_cast<const uint4*>(kfrag_ptr(kb, st + 1, 1));
             }
             TR::mma32x3(s[rb], kh, kl, qf[2 * ks], qf[2 * ks + 1]);
             kh = nh; kl = nl;
@@ -409,14 +452,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
     // What depends on t + 1 < ntiles is a template parameter (the last tile is a peeled instance without QK^T); tail loads are clamped.
     auto tile_step = [&](auto has_next_c, int t, f32x16_t (&s_cur)[2], f32x16_t (&s_nxt)[2]) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(has_next_c)::value;
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of K_{t+1} / V_t (issued one tile ago) have landed
         if constexpr (!(PROBE & 4)) __syncthreads();   // K_{t+1}, V_t are visible; every wave is done with K_t (ring slot t & 1) and V_{t-1} (slot (t + 1) & 1)
         const char* kb = smem + ((t + 1) & 1) * KT + koff;
         uint4 kh = make_uint4(0, 0, 0, 0), kl = kh;
         if constexpr (HAS_NEXT) {       // the first K fragment of S_{t+1}: requested right behind the barrier, used ~60 instructions later
-            kh = *reinterpret_cast<const uint4*>(kb);
-            kl = *reinterpret_cast<const uint4*>(kb + 16);
+            kh = *reinterpret_cast<const uint4*>(kfrag_ptr(kb, 0, 0));
+            kl = *reinterpret_cast<const uint4*>(kfrag_ptr(kb, 0, 1));
         }
-        if constexpr (HAS_NEXT && !(PROBE & 8)) {
+        if constexpr (HAS_NEXT && DMA) {
+            dma_k(min(t + 2, last) * 64, t & 1);       // K_{t+2} (at t = ntiles - 2 a second copy of the last tile: that slot is not read again)
+            dma_v((t + 1) * 64, (t + 1) & 1);          // V_{t+1}
+        } else if constexpr (HAS_NEXT && !(PROBE & 8)) {
             if constexpr (!(PROBE & 16)) {
                 lds_put_k(t & 1);            // K_{t+2} (at t = ntiles - 2 a second copy of the last tile: that slot is not read again)
                 lds_put_v((t + 1) & 1);      // V_{t+1}
@@ -533,9 +580,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
                 const int ks = st >> 1, rb = st & 1;
                 uint4 nh = kh, nl = kl;
                 if (st + 1 < 8) {          // the next step's fragments, one step (3 MFMAs) ahead of their use
-                    const char* kr = kb + ((st + 1) & 1) * 32 * KROW + ((st + 1) >> 1) * 64;
-                    nh = *reinterpret_cast<const uint4*>(kr);
-                    nl = *reinterpret_cast<const uint4*>(kr + 16);
+                    nh = *reinterpret_cast<const uint4*>(kfrag_ptr(kb, st + 1, 0));
+                    nl = *reinterpret_cast<const uint4*>(kfrag_ptr(kb, st + 1, 1));
                 }
                 if constexpr (!(PROBE & 2)) s_nxt[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q8(kl), q8(qf[2 * ks]), st < 2 ? zero16 : s_nxt[rb], 0, 0, 0);
                 else if (st < 2) s_nxt[rb] = zero16;
@@ -562,9 +608,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
         auto vfrag = [&](int u, u32x4_t& vh, u32x4_t& vl) __attribute__((always_inline)) {
             const int g = u >> 1, db = u & 1, rb = g >> 1, sh = g & 1;
             // keys kbase .. + 3 and kbase + 8 .. + 11 of this lane half (the 4 hh part sits in voff): hi plane byte 2 kbase, lo plane + 128
-            const char* vd = vb + (rb * 32 + 16 * sh) * 2 + db * 32 * VROW;
-            const uint2 h0 = *reinterpret_cast<const uint2*>(vd), h1 = *reinterpret_cast<const uint2*>(vd + 16);
-            const uint2 l0 = *reinterpret_cast<const uint2*>(vd + 128), l1 = *reinterpret_cast<const uint2*>(vd + 144);
+            uint2 h0, h1, l0, l1;
+            if constexpr (DMA) {            // swizzled image: logical slots 2 g, 2 g + 1 (hi plane) and + 8 (lo plane), XORed with the row key
+                const char* vr = vb + db * 32 * VROW;
+                const int a0 = vxo[g];
+                h0 = *reinterpret_cast<const uint2*>(vr + a0); h1 = *reinterpret_cast<const uint2*>(vr + (a0 ^ 16));
+                l0 = *reinterpret_cast<const uint2*>(vr + (a0 ^ 128)); l1 = *reinterpret_cast<const uint2*>(vr + (a0 ^ 144));
+            } else {
+                const char* vd = vb + (rb * 32 + 16 * sh) * 2 + db * 32 * VROW;
+                h0 = *reinterpret_cast<const uint2*>(vd); h1 = *reinterpret_cast<const uint2*>(vd + 16);
+                l0 = *reinterpret_cast<const uint2*>(vd + 128); l1 = *reinterpret_cast<const uint2*>(vd + 144);
+            }
             vh = (u32x4_t){h0.x, h0.y, h1.x, h1.y};
             vl = (u32x4_t){l0.x, l0.y, l1.x, l1.y};
         };
@@ -595,17 +649,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
     const std::false_type is_last{};
 
     // ---- prologue: K_0, V_0 -> LDS; K_1 -> LDS; K_2 / V_1 in flight; S_0 ---------------------------------------------------
+    f32x16_t sa[2], sb[2];
+    if constexpr (DMA) {
+        dma_k(0, 0);
+        dma_v(0, 0);
+        dma_k(min(1, last) * 64, 1);     // K_1 (ntiles == 1: a second copy of K_0, never read)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        qk_tile(0, sa);
+    } else {
     gload_k(0);
     gload_v(0);
     lds_put_k(0);
     lds_put_v(0);
     gload_k(min(1, last) * 64);
     __syncthreads();
-    f32x16_t sa[2], sb[2];
     qk_tile(0, sa);
     lds_put_k(1);                        // K_1 (ntiles == 1: a second copy of K_0, never read)
     gload_k(min(2, last) * 64);
     gload_v(min(1, last) * 64);
+    }
     int t = 0;
     for (; t + 2 < ntiles; t += 2) {     // both steps have a next tile
         tile_step(has_next, t, sa, sb);
@@ -634,18 +697,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
     }
 }
 
-template <int ODT, int PROBE, int NW = 4> static hipError_t launch_x3_v2p(const AttnParams& p, hipStream_t s) {
-    constexpr int LDS = 2 * 64 * (256 + 16) + 2 * 64 * (256 + 8);
+template <int ODT, int PROBE, int NW = 4, bool DMA = false> static hipError_t launch_x3_v2p(const AttnParams& p, hipStream_t s) {
+    constexpr int LDS = DMA ? 4 * 64 * 256 : 2 * 64 * (256 + 16) + 2 * 64 * (256 + 8);
     static std::atomic<unsigned long long> attr_done{0};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     const unsigned long long dev_bit = 1ull << (dev_id & 63);
     if (!(attr_done.load(std::memory_order_relaxed) & dev_bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_x3_kernel<ODT, PROBE, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_x3_kernel<ODT, PROBE, NW, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done.fetch_or(dev_bit, std::memory_order_relaxed);
     }
     const int grid = p.B * p.H * ((p.Nq + NW * 32 - 1) / (NW * 32));
-    hipLaunchKernelGGL((attention_x3_kernel<ODT, PROBE, NW>), dim3(grid), dim3(NW * 64), LDS, s, p);
+    hipLaunchKernelGGL((attention_x3_kernel<ODT, PROBE, NW, DMA>), dim3(grid), dim3(NW * 64), LDS, s, p);
     return hipGetLastError();
 }
 template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream_t s) {
@@ -666,6 +729,8 @@ template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream
         }
     }
     if (const char* e = getenv("D3R_ATTN_NW")) if (e[0] == '8') return launch_x3_v2p<ODT, 0, 8>(p, s);   // probe: 256 queries per workgroup
+    const char* e_dma = getenv("D3R_ATTN_DMA");              // K / V^T tiles by global_load_lds DMA (swizzled 256-byte rows); read per launch
+    if (e_dma ? e_dma[0] == '1' : false) return launch_x3_v2p<ODT, 0, 4, true>(p, s);
     return launch_x3_v2p<ODT, 0>(p, s);
 }
 

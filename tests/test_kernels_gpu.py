@@ -239,15 +239,18 @@ def test_attention(gpu, dtype, B, H, Nq, Nk):
     assert relerr(out, ref) < tol
 
 
-@pytest.mark.parametrize('v1', ['0', '1'])
+@pytest.mark.parametrize('v1', ['0', '1', 'dma', 'reg'])
 @pytest.mark.parametrize('B,H,Nq,Nk', [(2, 3, 196, 196), (1, 2, 768, 768), (2, 1, 6, 6), (1, 4, 130, 70), (1, 1, 768, 196), (1, 2, 40, 129), (1, 1, 300, 64), (1, 1, 64, 128)])
 def test_attention_split_fp16(gpu, v1, B, H, Nq, Nk, monkeypatch):
-    """The split-fp16 attention of the default engine at kernel level, both kernels (D3R_ATTN_V1=1: the round-2 kernel; default: the
-    software-pipelined one): against the fp64 softmax(Q K^T / 8) V of the SAME fp32 operands. Operands keep 22 significand bits and the
-    probabilities are split too, so the result is fp32-class (3e-5 like the exact-fp32 kernel); 1 to 12 key tiles, ragged last tiles,
-    query blocks with idle lanes. A subprocess-free switch: the choice is read on every launch."""
+    """The split-fp16 attention of the default engine at kernel level, every kernel (D3R_ATTN_V1=1: the round-2 kernel; the
+    software-pipelined one with its K / V^T tiles staged through registers, D3R_ATTN_DMA=0, or by global_load_lds DMA into swizzled
+    256-byte rows, D3R_ATTN_DMA=1; '0' = whatever the default is): against the fp64 softmax(Q K^T / 8) V of the SAME fp32 operands. Operands
+    keep 22 significand bits and the probabilities are split too, so the result is fp32-class (3e-5 like the exact-fp32 kernel); 1 to 12
+    key tiles, ragged last tiles, query blocks with idle lanes. A subprocess-free switch: the choice is read on every launch."""
     from dust3r_amd import ops
-    monkeypatch.setenv('D3R_ATTN_V1', v1)
+    monkeypatch.setenv('D3R_ATTN_V1', '1' if v1 == '1' else '0')
+    if v1 in ('dma', 'reg'):
+        monkeypatch.setenv('D3R_ATTN_DMA', '1' if v1 == 'dma' else '0')
     g = torch.Generator(device='cpu').manual_seed(Nq * 5 + Nk)
     q = (torch.randn((B, H, Nq, 64), generator=g) * 1.5).to(gpu)
     k = (torch.randn((B, H, Nk, 64), generator=g) * 1.5).to(gpu)
@@ -260,10 +263,12 @@ def test_attention_split_fp16(gpu, v1, B, H, Nq, Nk, monkeypatch):
     assert err < 3e-5
 
 
-def test_attention_split_fp16_sharp_rows_and_late_maximum(gpu):
+@pytest.mark.parametrize('dma', ['0', '1'])
+def test_attention_split_fp16_sharp_rows_and_late_maximum(gpu, dma, monkeypatch):
     """Running-maximum rescale of the pipelined kernel: one key dominating by a huge margin in a LATE tile (alpha = 0 there), and rows
     whose maximum moves in every tile."""
     from dust3r_amd import ops
+    monkeypatch.setenv('D3R_ATTN_DMA', dma)
     B, H, N = 1, 2, 320
     q = torch.zeros((B, H, N, 64), device=gpu)
     k = torch.zeros((B, H, N, 64), device=gpu)
@@ -275,6 +280,22 @@ def test_attention_split_fp16_sharp_rows_and_late_maximum(gpu):
     a = (q.double() @ k.double().transpose(-1, -2)) * 0.125
     ref = (a.softmax(-1) @ v.double()).transpose(1, 2).flatten(2)
     assert float((out.double() - ref).abs().max()) < 1e-5
+
+
+def test_attention_split_fp16_dma_staging_is_bit_identical(gpu, monkeypatch):
+    """The DMA-staged kernel computes the same MFMAs on the same operands in the same order as the register-staged one: bit-identical
+    outputs (encoder and decoder shapes of the BASELINE model, a ragged key count, a cross-attention shape with Nq != Nk)."""
+    from dust3r_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(77)
+    for B, H, Nq, Nk in ((2, 16, 768, 768), (1, 12, 768, 768), (1, 3, 200, 333), (1, 2, 768, 196)):
+        q = (torch.randn((B, H, Nq, 64), generator=g) * 1.5).to(gpu)
+        k = (torch.randn((B, H, Nk, 64), generator=g) * 1.5).to(gpu)
+        v = torch.randn((B, H, Nk, 64), generator=g).to(gpu)
+        outs = []
+        for dma in ('0', '1'):
+            monkeypatch.setenv('D3R_ATTN_DMA', dma)
+            outs.append(ops.attention_x3(q, k, v, scale=0.125).clone())
+        assert torch.equal(outs[0], outs[1]), (B, H, Nq, Nk, float((outs[0] - outs[1]).abs().max()))
 
 
 def test_attention_softmax_is_stable(gpu):

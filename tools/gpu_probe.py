@@ -184,6 +184,27 @@ def attn_probe():
         print(f'  B={B} H={H} {str(dt)[6:]:9s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s')
 
 
+def attndma_probe():
+    """Split-fp16 attention: K / V^T tiles staged through registers (D3R_ATTN_DMA=0) vs by global_load_lds DMA into swizzled rows (=1), alternating,
+    encoder (64 x 16 heads) and decoder (32 x 12) launch shapes of the 32-pair step, random data."""
+    import os
+    from dust3r_amd import _lib
+    from dust3r_amd._lib import lib
+    from dust3r_amd.ops import check, current_stream, pack_x3, ptr
+    N = 768
+    print('== split-fp16 attention: register staging vs DMA staging (us per launch, TF/s algorithmic)')
+    for (b, h) in ((64, 16), (32, 12)):
+        q, k = torch.randn((b, h, N, 64), device=dev) * 0.5, torch.randn((b, h, N, 64), device=dev) * 0.5
+        vt = torch.randn((b, h, 64, N), device=dev)
+        qp, kp, vp = pack_x3(q), pack_x3(k), pack_x3(vt)
+        out = torch.empty((b, N, h * 64 * 2), dtype=torch.float16, device=dev)
+        for dma in ('0', '1', '0', '1'):
+            os.environ['D3R_ATTN_DMA'] = dma
+            ms = timeit(lambda: check(lib.d3r_attention(ptr(qp), ptr(kp), ptr(vp), ptr(out), b, h, N, N, N, 0.125, _lib.DTYPE_F16X3, current_stream()), 'attention'), warm=3, reps=20)
+            print(f'  D3R_ATTN_DMA={dma} B={b} H={h}: {ms * 1e3:8.1f} us  {4 * b * h * N * N * 64 / ms / 1e9:7.1f} TF/s', flush=True)
+    os.environ.pop('D3R_ATTN_DMA')
+
+
 def attnparts_probe():
     """The split-fp16 attention kernel with parts of its instruction stream removed (D3R_ATTN_PROBE bit mask: 1 no softmax / split VALU,
     2 no MFMAs, 4 no per-tile barrier, 8 no staging of the next tiles; results invalid): what each part costs next to the others."""
@@ -353,7 +374,7 @@ if __name__ == '__main__':
     print(torch.cuda.get_device_name(0))
     for w in which:
         try:
-            {'gemm': gemm_probe, 'gemmtrace': gemmtrace_probe, 'tune': tune_probe, 'cache': cache_probe, 'conv': conv_probe, 'attn': attn_probe, 'attnparts': attnparts_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
+            {'gemm': gemm_probe, 'gemmtrace': gemmtrace_probe, 'tune': tune_probe, 'cache': cache_probe, 'conv': conv_probe, 'attn': attn_probe, 'attnparts': attnparts_probe, 'attndma': attndma_probe, 'forward': forward_probe, 'aligner': aligner_probe}[w]()
         except Exception as e:  # keep going: this is a probe
             import traceback
             traceback.print_exc()
