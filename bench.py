@@ -378,7 +378,7 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
     scene_out = None
     if c5 and rank == 0:
         # Stage B's input. Random-init weights do not produce a scene (the pointmaps of the timed forward are finite but geometrically
-        # meaningless, and the MST / Procrustes / focal initialisation of such input ends in NaN here), so the alignment runs on a
+        # meaningless, and the MST / Procrustes / focal initialisation of such input ends in NaN -- in the unmodified reference too: checked on the tiny model, its Weiszfeld focal is 0 and log(0) follows), so the alignment runs on a
         # geometrically consistent synthetic scene OF THE SAME SHAPE (same 100 views, same 600 edges in make_pairs' order, 512x384, resident in
         # HBM like the gathered predictions) -- what tools/e2e_pipeline.py has always done; its cost does not depend on the values.
         from dust3r_amd.synthetic import synthetic_scene
