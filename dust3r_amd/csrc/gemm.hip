@@ -680,6 +680,10 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                             const uint4 pf = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + fi * 16) * KTB + coff);
 #pragma unroll
                             for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], pf, qf[fj]);
+                            if (p.f8_proxy) {
+#pragma unroll
+                                for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], pf, qf[fj]);
+                            }
                         }
                     } else {
                         uint4 cur = *reinterpret_cast<const uint4*>(sb + p_off + p_row0 * KTB + coff);
@@ -689,6 +693,10 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                             if (fi + 1 < FI) nxt = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + (fi + 1) * 16) * KTB + coff);
 #pragma unroll
                             for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], cur, qf[fj]);
+                            if (p.f8_proxy) {     // MEASUREMENT AID (results invalid): the MFMA mix of a 2.5-unit scheme, see launch_gemm
+#pragma unroll
+                                for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], cur, qf[fj]);
+                            }
                             if (ks == 0) {
 #pragma unroll
                                 for (int i = fi * PPR_HI; i < (fi + 1) * PPR_HI && i < LPS; ++i) piece8(i, kt + 1, 1);
@@ -718,8 +726,10 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                     for (int fi = 0; fi < FI; ++fi) {
                         const char* pr = sb + p_off + (p_row0 + fi * 16) * KTB;
                         const uint4 pa = *reinterpret_cast<const uint4*>(pr + ca), pb = *reinterpret_cast<const uint4*>(pr + cb);
+                        if (!p.f8_proxy || (kt & 2)) {
 #pragma unroll
                         for (int fj = 0; fj < FJ; ++fj) TR::mma16_f8(acc[fi][fj], pa, pb, qa[fj], qb[fj]);
+                        }
                     }
                 } else {
                     const char* pr0 = sb + p_off + p_row0 * KTB;
@@ -732,8 +742,10 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                             na = *reinterpret_cast<const uint4*>(pr + ca);
                             nb = *reinterpret_cast<const uint4*>(pr + cb);
                         }
+                        if (!p.f8_proxy || (kt & 2)) {
 #pragma unroll
                         for (int fj = 0; fj < FJ; ++fj) TR::mma16_f8(acc[fi][fj], ca0, cb0, qa[fj], qb[fj]);
+                        }
                         if (more && fi < FI / 2) {
 #pragma unroll
                             for (int i = fi * PPR_F8; i < (fi + 1) * PPR_F8 && i < LPS; ++i) piece8(i, kt + 2, 0);
@@ -1688,6 +1700,9 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     if (g_trace_buf && (size_t)cdiv(p.M, 128) * cdiv(p.n_store, 128) <= g_trace_cap) p.trace = g_trace_buf;   // capacity for the smallest tile
     if (const char* e = getenv("D3R_GEMM_NOSTORE")) if (e[0] == '1') p.flags |= GF_NOSTORE;
     if (const char* e = getenv("D3R_GEMM_NOWIDE")) if (e[0] == '1') p.flags |= GF_NOWIDE;
+    // measurement aid (results INVALID): the fp16 + fp8 K loop issues the MFMA mix of a 2.5-unit scheme -- per 64 k four f16 MFMAs (hi.hi and
+    // hi.w_lo on the f16 pipe) and half an e4m3 MFMA (a_lo.w_hi, K = 128 spans two groups) = 80 MFMA cycles instead of 64 (fp16f8) / 96 (fp16x3)
+    if (const char* e = getenv("D3R_F8_PROXY")) if (e[0] == '1') p.f8_proxy = 1;
     // wide epilogues store with the non-temporal policy (measured +3..10 % on isolated GEMMs, +1 % on the forward); D3R_GEMM_NT=0: plain stores
     { const char* e = getenv("D3R_GEMM_NT"); if (!e || e[0] != '0') p.flags |= GF_NTSTORE; }
     const int kt = 128 / (int)dt_bytes(dt);

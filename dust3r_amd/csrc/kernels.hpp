@@ -50,6 +50,7 @@ struct GemmParams {
     // issued / stores drained, then HW_ID, XCC_ID, blockIdx
     unsigned long long* trace = nullptr;
     PostMode post;               // EPI_HEAD4: depth_mode / conf_mode of the head's postprocess
+    int f8_proxy = 0;            // MEASUREMENT AID (D3R_F8_PROXY=1, results INVALID): fp16 + fp8 K loop with the MFMA mix of a 2.5-unit scheme (4 f16 + 1/2 fp8 MFMA per 64 k)
 };
 void gemm_set_trace(unsigned long long* buf, size_t capacity_blocks);
 

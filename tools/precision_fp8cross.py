@@ -180,9 +180,23 @@ if len(sys.argv) > 4 and sys.argv[4] == 'a25':
              ('f8a:mx in the block linears, head x3 (2.5 units)', dict(B3, enc='f8a:mx', dec='f8a:mx')),
              ('f8a:mx everywhere (2.5 units)', {g: 'f8a:mx' for g in ALL}),
              ('f8x:raw in the block linears (the fp16f8 engine, 2 units)', dict(B3, enc='f8x:raw', dec='f8x:raw'))]
+    cases.insert(2, ('f8a:raw in the block linears (fixed 2^11 pre-scale of the lo parts)', dict(B3, enc='f8a:raw', dec='f8a:raw')))
     state0 = {k: v.clone() for k, v in m.state_dict().items()}
-    for wseed in range(int(sys.argv[5]) if len(sys.argv) > 5 else 3):
-        if wseed:
+    nseed = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+    for wseed in list(range(nseed)) + ['out40', 'out150']:
+        if wseed in ('out40', 'out150'):     # tests/test_forward_gpu.py: sharp attention (q, k x2) + outlier channels in the MLP inputs (norm2 / norm3 gains x8, one channel x40 / x150)
+            m.load_state_dict(state0)
+            big = 40.0 if wseed == 'out40' else 150.0
+            with torch.no_grad():
+                for name, p in m.named_parameters():
+                    if name.endswith('attn.qkv.weight'):
+                        p[:2 * p.shape[1]] *= 2.0
+                    elif name.endswith('cross_attn.projq.weight') or name.endswith('cross_attn.projk.weight'):
+                        p *= 2.0
+                    elif 'blocks' in name and (name.endswith('.norm2.weight') and 'enc_blocks' in name or name.endswith('.norm3.weight')):
+                        p[5::97] *= 8.0
+                        p[3] *= big
+        elif wseed:
             g = torch.Generator().manual_seed(1000 + wseed)
             with torch.no_grad():
                 for name, p in m.named_parameters():
