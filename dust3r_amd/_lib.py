@@ -11,10 +11,10 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so that the en
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libdust3r_hip.so')
 
-DTYPE_BF16, DTYPE_F16, DTYPE_F32, DTYPE_F16X3, DTYPE_F16F8 = 0, 1, 2, 3, 4
+DTYPE_BF16, DTYPE_F16, DTYPE_F32, DTYPE_F16X3, DTYPE_F16F8, DTYPE_F16X2F8 = 0, 1, 2, 3, 4, 5
 DTYPES = {'bf16': DTYPE_BF16, 'bfloat16': DTYPE_BF16, 'f16': DTYPE_F16, 'fp16': DTYPE_F16, 'float16': DTYPE_F16,
           'f32': DTYPE_F32, 'fp32': DTYPE_F32, 'float32': DTYPE_F32, 'fp16x3': DTYPE_F16X3, 'f16x3': DTYPE_F16X3,
-          'fp16f8': DTYPE_F16F8, 'f16f8': DTYPE_F16F8}
+          'fp16f8': DTYPE_F16F8, 'f16f8': DTYPE_F16F8, 'fp16x2f8': DTYPE_F16X2F8}
 TORCH_DTYPE = {DTYPE_BF16: torch.bfloat16, DTYPE_F16: torch.float16, DTYPE_F32: torch.float32}
 
 ERRORS = {0: 'OK', -1: 'invalid argument', -2: 'allocation failed', -3: 'kernel launch failed', -4: 'unknown state-dict key',

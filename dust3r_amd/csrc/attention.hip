@@ -753,7 +753,9 @@ template <int DT, int ODT = DT> static hipError_t launch_t(const AttnParams& p, 
     return hipGetLastError();
 }
 
-hipError_t launch_attention(int dt, const AttnParams& p, hipStream_t s) {
+hipError_t launch_attention(int dt, const AttnParams& p_in, hipStream_t s) {
+    AttnParams p = p_in;
+    if (p.out_dt >= 0) p.out_dt = d3r_act_dt(p.out_dt);     // rows for a 2.5-unit proj GEMM are fp16 + fp8 activation rows
     if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0 || p.ldv % 64 != 0 || p.ldv < ((p.Nk + 63) / 64) * 64)
         return hipErrorInvalidValue;
     if (p.out_dt >= 0 && p.out_dt != dt && !(dt == D3R_F16X3 && p.out_dt == D3R_F16F8)) return hipErrorInvalidValue;

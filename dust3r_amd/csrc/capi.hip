@@ -66,7 +66,7 @@ extern "C" int d3r_gemm_set_trace(void* buf, size_t capacity_blocks) {
 // (same `epilogue` codes as d3r_linear; with_residual: an fp32 residual is added). The dispatch table of DESIGN.md section 4.1 as a function.
 extern "C" int d3r_gemm_tile_config(int dtype, int M, int N, int K, int epilogue, int with_residual) {
     if (M <= 0 || N <= 0 || K <= 0 || N % 4 != 0) return D3R_ERR_INVALID;
-    if (dtype != D3R_BF16 && dtype != D3R_F16 && dtype != D3R_F32 && dtype != D3R_F16X3 && dtype != D3R_F16F8) return D3R_ERR_INVALID;
+    if (dtype != D3R_BF16 && dtype != D3R_F16 && dtype != D3R_F32 && dtype != D3R_F16X3 && dtype != D3R_F16F8 && dtype != D3R_F16X2F8) return D3R_ERR_INVALID;
     static const float dummy = 0.f;
     GemmParams p;
     p.lda = K; p.M = M; p.K = K; p.n_pad = rup(N, 128); p.n_rows = rup(N, 256); p.n_store = N;      // the engine's weight loader allocates rows the same way (engine.hip: Lin / ConvW)

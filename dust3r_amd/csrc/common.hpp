@@ -25,6 +25,8 @@
 #define D3R_F32 2
 #define D3R_F16X3 3   // split fp16: every value is a (hi, lo) fp16 pair, products use 3 MFMAs (hi*hi + hi*lo + lo*hi)
 #define D3R_F16F8 4   // fp16 + fp8: hi*hi on the f16 MFMA, the two cross terms hi*lo + lo*hi on ONE K-concatenated fp8 (e4m3) MFMA at twice the rate
+#define D3R_F16X2F8 5 // 2.5 MFMA units per product: hi*hi and hi*w_lo on the f16 MFMA (the WEIGHTS keep their 22 bits), only a_lo*w_hi on the e4m3 MFMA.
+                      // Activation rows: the D3R_F16F8 layout (hi fp16 + b8 = e4m3(lo 2^11); the a8 copy is not read). Weight rows: Traits<D3R_F16X2F8>.
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
@@ -211,6 +213,34 @@ template <> struct Traits<D3R_F16F8> {
     }
 };
 
+// 2.5-unit arithmetic (round 4). The numerics study (tools/precision_fp8cross.py a25, profiles/r04_cpu) attributes the error of the fp16 + fp8
+// scheme to ONE of its two e4m3 cross terms: a_hi * w_lo -- the same rounded weight residue meets every token, a systematic error --, while
+// a_lo * w_hi (the rounding residue of an activation is noise-like) costs 1/3 of it. Here the harmful term stays on the f16 MFMA:
+//     x.w  ~=  a_hi * w_hi  +  a_hi * w_lo   (f16 MFMAs, fp16 w_lo: 22-bit weights)   +   e4m3(a_lo 2^11) * e4m3(w_hi 2^6) 2^-17   (fp8 MFMA)
+// A weight row of K logical elements (K % 128 == 0) is 5 K bytes: per 128 k five 128-byte chunks
+//     [w_hi k 0..63 fp16 | w_lo k 0..63 fp16 | w_hi k 64..127 | w_lo k 64..127 | h8 k 0..127 e4m3(w_hi 2^6)]
+// and the K loop walks them as five K steps per 128 k (gemm.hip): four steps of two f16 MFMA k-steps and one fp8 step whose 16x16x128 MFMA takes the
+// 128 k of b8 (activation rows, gathered from two super-groups by the DMA's source addresses) against the h8 chunk: 80 MFMA cycles per 64 k
+// instead of 96 (fp16x3) / 64 (fp16f8).
+template <> struct Traits<D3R_F16X2F8> : Traits<D3R_F16F8> {
+    D3R_DEV static size_t wrow_bytes(size_t K) { return K * 5; }
+    // one WEIGHT element (load-time packing): row r of a matrix with K logical columns, column c
+    D3R_DEV static void store1_wgt5(void* base, size_t r, size_t c, size_t K, float v) {
+        v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+        const _Float16 h = (_Float16)v;
+        const float hf = (float)h;
+        const _Float16 l = (_Float16)(v - hf);
+        const int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp8(hf * 64.f), 0.f, 0, false);
+        char* p = reinterpret_cast<char*>(base) + r * (K * 5) + (c >> 7) * 640;
+        const size_t j = c & 127, half = j >> 6, jj = j & 63;
+        *reinterpret_cast<_Float16*>(p + (2 * half) * 128 + jj * 2) = h;
+        *reinterpret_cast<_Float16*>(p + (2 * half + 1) * 128 + jj * 2) = l;
+        *reinterpret_cast<uint8_t*>(p + 512 + j) = (uint8_t)(h8 & 0xFF);
+    }
+};
+// activation-row layout of a GEMM dtype: the 2.5-unit mode shares the fp16 + fp8 rows
+__host__ __device__ constexpr int d3r_act_dt(int dt) { return dt == D3R_F16X2F8 ? D3R_F16F8 : dt; }
+
 // ---- typed 4-element (row-contiguous) loads / stores used by every epilogue -----------------
 template <int DT> D3R_DEV void store4(void* base, size_t elem_off, float a, float b, float c, float d) {
     if constexpr (DT == D3R_F32) {
@@ -223,7 +253,7 @@ template <int DT> D3R_DEV void store4(void* base, size_t elem_off, float a, floa
         char* p = reinterpret_cast<char*>(base) + TX::boff(elem_off);
         *reinterpret_cast<uint2*>(p) = h;
         *reinterpret_cast<uint2*>(p + 16) = l;
-    } else if constexpr (DT == D3R_F16F8) {   // activation encoding; elem_off % 4 == 0
+    } else if constexpr (DT == D3R_F16F8 || DT == D3R_F16X2F8) {   // activation encoding; elem_off % 4 == 0
         using TF = Traits<D3R_F16F8>;
         uint2 h; uint32_t a8, b8;
         TF::enc4<false>(a, b, c, d, h, a8, b8);
@@ -246,7 +276,7 @@ template <int DT> D3R_DEV float4 load4(const void* base, size_t elem_off) {
         const char* p = reinterpret_cast<const char*>(base) + TX::boff(elem_off);
         const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + 16);
         return make_float4(TX::join_lo(h.x, l.x), TX::join_hi(h.x, l.x), TX::join_lo(h.y, l.y), TX::join_hi(h.y, l.y));
-    } else if constexpr (DT == D3R_F16F8) {
+    } else if constexpr (DT == D3R_F16F8 || DT == D3R_F16X2F8) {
         using TF = Traits<D3R_F16F8>;
         const char* p = reinterpret_cast<const char*>(base);
         const uint2 h = *reinterpret_cast<const uint2*>(p + TF::off_hi(elem_off));
@@ -304,7 +334,7 @@ template <int DT> D3R_DEV void store1(void* base, size_t elem_off, float a) {
         char* p = reinterpret_cast<char*>(base) + TX::boff(elem_off);
         *reinterpret_cast<uint16_t*>(p) = (uint16_t)(h & 0xFFFFu);
         *reinterpret_cast<uint16_t*>(p + 16) = (uint16_t)(l & 0xFFFFu);
-    } else if constexpr (DT == D3R_F16F8) {
+    } else if constexpr (DT == D3R_F16F8 || DT == D3R_F16X2F8) {
         using TF = Traits<D3R_F16F8>;
         uint2 h; uint32_t a8, b8;
         TF::enc4<false>(a, 0.f, 0.f, 0.f, h, a8, b8);
@@ -319,7 +349,7 @@ template <int DT> D3R_DEV float load1(const void* base, size_t elem_off) {
     else if constexpr (DT == D3R_F16X3) {
         const char* p = reinterpret_cast<const char*>(base) + Traits<D3R_F16X3>::boff(elem_off);
         return (float)*reinterpret_cast<const _Float16*>(p) + (float)*reinterpret_cast<const _Float16*>(p + 16);
-    } else if constexpr (DT == D3R_F16F8) {
+    } else if constexpr (DT == D3R_F16F8 || DT == D3R_F16X2F8) {
         using TF = Traits<D3R_F16F8>;
         const char* p = reinterpret_cast<const char*>(base);
         return TF::dec(*reinterpret_cast<const uint16_t*>(p + TF::off_hi(elem_off)), (uint32_t)*reinterpret_cast<const uint8_t*>(p + TF::off_b(elem_off)), 0);
@@ -446,4 +476,5 @@ D3R_DEV float rows_sum4(float v) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-static inline size_t dt_bytes(int dt) { return (dt == D3R_F32 || dt == D3R_F16X3 || dt == D3R_F16F8) ? 4 : 2; }
+static inline size_t dt_bytes(int dt) { return (dt == D3R_F32 || dt == D3R_F16X3 || dt == D3R_F16F8 || dt == D3R_F16X2F8) ? 4 : 2; }   // bytes per logical element of an ACTIVATION row
+static inline size_t wgt_bytes(int dt) { return dt == D3R_F16X2F8 ? 5 : dt_bytes(dt); }                                                  // ... of a WEIGHT row

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 hipError_t launch_layernorm(int dt, const float* x, const float* gamma, const float* beta, void* out, int rows, int C,
                             float eps, hipStream_t s) {
     if (C % 4 != 0 || C > 2048 || rows <= 0) return hipErrorInvalidValue;
+    dt = d3r_act_dt(dt);        // the 2.5-unit GEMMs read fp16 + fp8 activation rows
     const dim3 grid(cdiv(rows, 4)), block(256);
     switch (dt) {
         case D3R_BF16: hipLaunchKernelGGL(layernorm_kernel<D3R_BF16>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
@@ -85,6 +86,7 @@ template <int DT> __global__ __launch_bounds__(256) void convert_kernel(const fl
 }
 hipError_t launch_convert(int dt, const float* x, void* out, size_t n, hipStream_t s) {
     if (n % 4 != 0) return hipErrorInvalidValue;
+    dt = d3r_act_dt(dt);
     const size_t n4 = n / 4;
     const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     switch (dt) {
@@ -514,6 +516,7 @@ template <int DT> __global__ __launch_bounds__(256) void pack_weight_kernel(Pack
         d = ((size_t)t * p.cout_pad + co) * (size_t)p.dst_cols + ci;
     }
     if constexpr (DT == D3R_F16F8) Traits<D3R_F16F8>::store1_wgt(p.dst, d, v);   // the weight encoding of the fp16 + fp8 rows
+    else if constexpr (DT == D3R_F16X2F8) Traits<D3R_F16X2F8>::store1_wgt5(p.dst, d / p.dst_cols, d % p.dst_cols, p.dst_cols, v);   // 2.5-unit rows: five chunks per 128 k
     else store1<DT>(p.dst, d, v);
 }
 hipError_t launch_pack_weight(int dt, const PackParams& p, hipStream_t s) {
@@ -527,6 +530,9 @@ hipError_t launch_pack_weight(int dt, const PackParams& p, hipStream_t s) {
         case D3R_F16F8:     // nn.Linear matrices only (the convolutions of the DPT head stay split-fp16)
             if (p.kind != PACK_MAT || p.dst_cols % 64 != 0) return hipErrorInvalidValue;
             hipLaunchKernelGGL(pack_weight_kernel<D3R_F16F8>, dim3(grid), dim3(256), 0, s, p); break;
+        case D3R_F16X2F8:   // nn.Linear matrices only, whole 128-k blocks of five chunks (5 bytes per element)
+            if (p.kind != PACK_MAT || p.dst_cols % 128 != 0) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(pack_weight_kernel<D3R_F16X2F8>, dim3(grid), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -147,7 +147,7 @@ bool reg_vec_at(d3r_model* m, const std::string& key, float* base, int off, int 
 bool alloc_lin(d3r_model* m, Lin& L, int N, int K, bool bias = true, int dt = -1) {
     L.N = N; L.K = K; L.n_pad = rup(N, 128); L.n_rows = rup(N, 256);   // rows up to a 256-wide tile stay zero
     L.dt = dt < 0 ? m->dt : dt;
-    L.w = m->dalloc((size_t)L.n_rows * K * dt_bytes(L.dt));
+    L.w = m->dalloc((size_t)L.n_rows * K * wgt_bytes(L.dt));      // 2.5-unit rows: five bytes per element
     L.b = bias ? (float*)m->dalloc((size_t)L.n_rows * sizeof(float)) : nullptr;
     return L.w && (!bias || L.b);
 }
@@ -336,7 +336,7 @@ void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi,
     p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_rows = L.n_rows;
     p.n_store = n_store >= 0 ? n_store : L.N;
     p.epi = epi; p.out = out; p.ldo = ldo; p.res1 = res1; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo2; p.flags = flags;
-    c.mark(prf_kind(L.dt == D3R_F16F8 ? PRF_GEMM_F8 : PRF_GEMM, gemm_pick_config(p, L.dt)), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
+    c.mark(prf_kind((L.dt == D3R_F16F8 || L.dt == D3R_F16X2F8) ? PRF_GEMM_F8 : PRF_GEMM, gemm_pick_config(p, L.dt)), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(L.dt, p, c.st));
 }
 
@@ -347,7 +347,7 @@ void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_
     p.epi = EPI_HEADS; p.head_c = head_c;
     for (int i = 0; i < nreg; ++i) { p.head_kind[i] = kinds[i]; p.head_dst[i] = dsts[i]; }
     p.heads = heads; p.ntok = ntok; p.tok_w = tok_w; p.ldv = ldv; p.rope_table = c.m->rope_table;
-    c.mark(prf_kind(L.dt == D3R_F16F8 ? PRF_GEMM_F8 : PRF_GEMM, gemm_pick_config(p, L.dt)), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
+    c.mark(prf_kind((L.dt == D3R_F16F8 || L.dt == D3R_F16X2F8) ? PRF_GEMM_F8 : PRF_GEMM, gemm_pick_config(p, L.dt)), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(L.dt, p, c.st));
 }
 
@@ -415,13 +415,16 @@ extern "C" int d3r_device_check(void) {
 
 extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     if (!out || !cfg) return D3R_ERR_INVALID;
-    if (cfg->dtype < 0 || cfg->dtype > 4 || cfg->patch_size % 4 != 0) return D3R_ERR_INVALID;
+    if (cfg->dtype < 0 || cfg->dtype > D3R_F16X2F8 || cfg->patch_size % 4 != 0) return D3R_ERR_INVALID;
+    if (cfg->dtype == D3R_F16X2F8 && (cfg->enc_embed_dim % 128 || cfg->dec_embed_dim % 128)) return D3R_ERR_INVALID;   // whole 128-k blocks of five weight chunks
     if (cfg->enc_embed_dim != cfg->enc_num_heads * 64 || cfg->dec_embed_dim != cfg->dec_num_heads * 64) return D3R_ERR_INVALID;  // head dim 64
     d3r_model* m = new (std::nothrow) d3r_model();
     if (!m) return D3R_ERR_ALLOC;
     // D3R_DTYPE_F16F8: the transformer blocks' linears on fp16 + fp8 operand rows, everything else (patch embedding, decoder_embed,
     // attention operands, DPT / linear heads) in split-fp16
-    m->cfg = *cfg; m->dt = cfg->dtype == D3R_F16F8 ? D3R_F16X3 : cfg->dtype; m->bdt = cfg->dtype == D3R_F16F8 ? D3R_F16F8 : m->dt;
+    // D3R_DTYPE_F16X2F8: the same split of the network, the blocks' linears on the 2.5-unit arithmetic (activation rows as above, five-chunk weight rows)
+    const bool f8blocks = cfg->dtype == D3R_F16F8 || cfg->dtype == D3R_F16X2F8;
+    m->cfg = *cfg; m->dt = f8blocks ? D3R_F16X3 : cfg->dtype; m->bdt = f8blocks ? cfg->dtype : m->dt;
     m->ktile = 128 / (int)dt_bytes(m->dt);
     if (cfg->enc_embed_dim % m->ktile || cfg->dec_embed_dim % m->ktile || (3 * cfg->patch_size * cfg->patch_size) % m->ktile ||
         (cfg->head_type == 1 && (cfg->dec_depth <= 9 || cfg->patch_size != 16))) { delete m; return D3R_ERR_INVALID; }   // run_dpt assumes 16 x th == H

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
 #pragma unroll
                     for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], pf, pl, qf[fj], ql[fj]);
                 }
-            } else if constexpr (DT != D3R_F16F8) {
+            } else if constexpr (DT != D3R_F16F8 && DT != D3R_F16X2F8) {
 #pragma unroll
                 for (int ks = 0; ks < KTB / 64; ++ks) {
                     const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
@@ -616,6 +616,91 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             }
             b = b1;
         }
+    } else if constexpr (DT == D3R_F16X2F8) {
+        // ---- 2.5-unit rows (common.hpp, Traits<D3R_F16X2F8>): five K steps per 128 logical k ------------------------------------------------
+        //   step s     activation slot (BM x 128 B)                                   weight slot (BN x 128 B)          MFMAs per fragment pair
+        //   0          hi of k 0..63      (chunk 0 of super-group 2b)                 w_hi k 0..63     (chunk 5b)       2 x f16   a_hi . w_hi
+        //   1          the same chunk again                                           w_lo k 0..63     (chunk 5b + 1)   2 x f16   a_hi . w_lo
+        //   2          hi of k 64..127    (chunk 0 of super-group 2b + 1)             w_hi k 64..127   (chunk 5b + 2)   2 x f16
+        //   3          the same chunk again                                           w_lo k 64..127   (chunk 5b + 3)   2 x f16
+        //   4          b8 of k 0..63 | b8 of k 64..127 (gathered by the DMA sources)  h8 k 0..127      (chunk 5b + 4)   1 x e4m3  a_lo . w_hi  (K = 128)
+        // The hi chunk of the activations is fetched twice (an L2 hit one step later) rather than held in registers across a step: both
+        // operands keep the plain [slot | slot] stage of every other loop, so the operand-role swap of the V^T regions and every epilogue
+        // work unchanged. nn.Linear operands only; same one-offset-per-operand DMA addressing as the fp16 + fp8 loop.
+        static_assert(KTB == 128 && NS == 2, "2.5-unit rows: 128-byte K steps, two stages");
+        const bool edge = __builtin_amdgcn_readfirstlane(m0 + BM > p.M ? 1 : 0) != 0;
+        const size_t wrow = (size_t)p.K * 5;
+        const char* const tile_a = reinterpret_cast<const char*>(p.act) + (size_t)__builtin_amdgcn_readfirstlane(m0) * p.lda * EB;
+        const char* const tile_w = reinterpret_cast<const char*>(p.wgt) + (size_t)__builtin_amdgcn_readfirstlane(n0) * wrow;
+        // source byte offset of this lane's 16-byte slot inside a row: a plain chunk, or (step 4) slots 0-3 <- the b8 quarter of the first
+        // super-group's second chunk, slots 4-7 <- the b8 quarter of the second super-group's (relative to the 512-byte block of the row)
+        const uint32_t coff_plain = (uint32_t)(lchunk * 16);
+        const uint32_t coff_b8 = (uint32_t)(lchunk < 4 ? 128 + 64 + lchunk * 16 : 384 + 64 + (lchunk - 4) * 16);
+        const uint32_t arow0 = (uint32_t)(((size_t)(min(m0 + lrow, p.M - 1) - m0) * p.lda) * EB);
+        const uint32_t w0 = (uint32_t)((size_t)lrow * wrow) + coff_plain;
+        const size_t stride_a = (size_t)CF::PASS_ROWS * p.lda * EB, stride_w = (size_t)CF::PASS_ROWS * wrow;
+        auto stage5 = [&](int kb, int st, int buf) __attribute__((always_inline)) {     // st: 0..4 (a compile-time constant at every call site)
+            const uint32_t sb = lds0 + buf * STAGE_BYTES;
+            const char* ab = tile_a + (size_t)kb * 512 + (st == 2 || st == 3 ? 256 : 0);
+            const uint32_t ac = st == 4 ? coff_b8 : coff_plain;
+#pragma unroll
+            for (int q = 0; q < CF::APASS; ++q) {
+                if (!edge) {
+                    glds16_so(ab + q * stride_a, arow0 + ac, sb + q * (CF::NW * 1024));
+                } else {
+                    const int m = min(m0 + q * CF::PASS_ROWS + lrow, p.M - 1);
+                    glds16_so(ab, (uint32_t)(((size_t)(m - m0) * p.lda) * EB) + ac, sb + q * (CF::NW * 1024));
+                }
+            }
+            const char* wb = tile_w + (size_t)kb * 640 + st * 128;
+#pragma unroll
+            for (int q = 0; q < CF::WPASS; ++q) glds16_so(wb + q * stride_w, w0, sb + BM * KTB + q * (CF::NW * 1024));
+        };
+        const int nblk = p.K >> 7;
+        stage5(0, 0, 0);
+        int buf = 0;
+        for (int kb = 0; kb < nblk; ++kb) {
+#pragma unroll
+            for (int st = 0; st < 5; ++st) {
+                d3r_wait_vm0();
+                __syncthreads();
+                if (st < 4) stage5(kb, st + 1, buf ^ 1);
+                else if (kb + 1 < nblk) stage5(kb + 1, 0, buf ^ 1);
+                const char* sb = smem + buf * STAGE_BYTES;
+                if (st < 4) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
+                        uint4 qf[FJ];
+#pragma unroll
+                        for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (q_row0 + f * 16) * KTB + coff);
+#pragma unroll
+                        for (int fi = 0; fi < FI; ++fi) {
+                            const uint4 pf = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + fi * 16) * KTB + coff);
+#pragma unroll
+                            for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], pf, qf[fj]);
+                        }
+                    }
+                } else {
+                    const int ca = (fgrp ^ fsw) * 16, cb = ((4 + fgrp) ^ fsw) * 16;
+                    uint4 qa[FJ], qb[FJ];
+#pragma unroll
+                    for (int f = 0; f < FJ; ++f) {
+                        const char* qr = sb + q_off + (q_row0 + f * 16) * KTB;
+                        qa[f] = *reinterpret_cast<const uint4*>(qr + ca);
+                        qb[f] = *reinterpret_cast<const uint4*>(qr + cb);
+                    }
+#pragma unroll
+                    for (int fi = 0; fi < FI; ++fi) {
+                        const char* pr = sb + p_off + (p_row0 + fi * 16) * KTB;
+                        const uint4 pa = *reinterpret_cast<const uint4*>(pr + ca), pb = *reinterpret_cast<const uint4*>(pr + cb);
+#pragma unroll
+                        for (int fj = 0; fj < FJ; ++fj) TR::mma16_f8(acc[fi][fj], pa, pb, qa[fj], qb[fj]);
+                    }
+                }
+                buf ^= 1;
+            }
+        }
     } else if constexpr (DT == D3R_F16F8) {
         // ---- fp16 + fp8 rows: the K loop walks 256-byte super-groups [hi fp16 x64 | a8 x64 | b8 x64] (64 logical k) in two K steps --------
         // Step 2t stages the fp16 half into stage 0: two f16 MFMA k-steps, lane group g on chunks g and 4 + g. Step 2t + 1 stages the fp8
@@ -869,7 +954,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], pf, pl, qf[fj], ql[fj]);
             }
-        } else if constexpr (DT != D3R_F16F8) {
+        } else if constexpr (DT != D3R_F16F8 && DT != D3R_F16X2F8) {
 #pragma unroll
             for (int ks = 0; ks < KTB / 64; ++ks) {
                 const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
@@ -996,7 +1081,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     constexpr bool DTX3 = (DT == D3R_F16X3);
     // fp16 + fp8 GEMMs: the attention projections hand q / k / v^T to the attention kernel in the split-fp16 layout (HDT), the typed
     // copy of an fp32-residual launch (out2: the DPT hooks) is split-fp16 too (O2DT); GELU / plain outputs are fp16 + fp8 activation rows
-    constexpr bool DTF8 = (DT == D3R_F16F8);
+    constexpr bool DTF8 = (DT == D3R_F16F8 || DT == D3R_F16X2F8);   // outputs of both are fp16 + fp8 ACTIVATION rows (or split-fp16 heads / fp32)
     constexpr int HDT = DTF8 ? D3R_F16X3 : DT, O2DT = DTF8 ? D3R_F16X3 : DT;
     const bool widex3 = (DTX3 || DTF8) && !(p.flags & GF_NOWIDE) &&
                         ((DTX3 && (p.epi == EPI_GELU || (p.epi == EPI_T && !p.res1 && !p.res2 && !p.out2)) && (p.ldo & 7) == 0) ||
@@ -1594,7 +1679,7 @@ int gemm_pick_config(const GemmParams& p, int dt) {
     // fp16 + fp8 rows: the 256-wide tile is 1.3-1.6x ahead of the 128 x 128 one per tile (its K loop lost a third of its MFMA work, the small
     // tile's LDS read traffic per MFMA is twice as high), so it pays from a single round of resident blocks on: measured +1.5 % on the
     // forward with the decoder's 24576 x 768 GEMMs (288 tiles, two such launches side by side on the two streams) on it
-    long t256 = dt == D3R_F16F8 ? 250 : 700;     // probes: D3R_GEMM_T256 moves the 256x256 / 128x128 crossover, D3R_GEMM_MID=2 sends the shapes below it to 256x128
+    long t256 = (dt == D3R_F16F8 || dt == D3R_F16X2F8) ? 250 : 700;     // probes: D3R_GEMM_T256 moves the 256x256 / 128x128 crossover, D3R_GEMM_MID=2 sends the shapes below it to 256x128
     if (const char* e = getenv("D3R_GEMM_T256")) t256 = atol(e);
     if (ok256 && tiles256 >= t256) {
         // nn.Linear operands: the ping-pong schedule measured 1-8 % ahead of the plain 2-stage loop (profiles/r01_call13);
@@ -1609,7 +1694,7 @@ int gemm_pick_config(const GemmParams& p, int dt) {
 
 template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     int cfg = gemm_pick_config(p, DT);
-    constexpr bool SPLIT = (DT == D3R_F16X3 || DT == D3R_F16F8);   // split-fp16 and fp16 + fp8 rows need 128-byte K rows, two stages
+    constexpr bool SPLIT = (DT == D3R_F16X3 || DT == D3R_F16F8 || DT == D3R_F16X2F8);   // split-fp16 and fp16 + fp8 rows need 128-byte K rows, two stages
     if (cfg == GEMM_CFG_256x128W4 && SPLIT) cfg = GEMM_CFG_256x128;
     if (cfg == GEMM_CFG_256x128R && DT != D3R_F16X3) cfg = GEMM_CFG_256x128;      // the weights-in-registers shape exists for split-fp16 only
     if (cfg == GEMM_CFG_64 && DT != D3R_F16X3) cfg = GEMM_CFG_128;                // the 64 x 64 shape too
@@ -1623,7 +1708,7 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
         if (cfg == GEMM_CFG_256S4) return launch_cfg<DT, Cfg256s4>(p, s);
         if (cfg == GEMM_CFG_256PP) return launch_cfg<DT, Cfg256pp>(p, s);
     }
-    if constexpr (DT != D3R_F16F8) {
+    if constexpr (DT != D3R_F16F8 && DT != D3R_F16X2F8) {
         const char* e_a3 = getenv("D3R_GEMM_A3");
         const bool a3 = e_a3 ? e_a3[0] != '0' : false;
         if (a3 && cfg == GEMM_CFG_256) return launch_cfg<DT, Cfg256a3>(p, s);
@@ -1678,11 +1763,15 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
             if ((long)cdiv(p.M, 128) * cdiv(p.n_store, 128) < t) return launch_cfg<DT, Cfg128w8>(p, s);
         }
     }
+    if constexpr (DT == D3R_F16X2F8) {      // nn.Linear matrices of the transformer blocks only (N >= 768): the two square tiles
+        return cfg == GEMM_CFG_256 ? launch_cfg<DT, Cfg256>(p, s) : launch_cfg<DT, Cfg128>(p, s);
+    } else {
     switch (cfg) {
         case GEMM_CFG_256: return launch_cfg<DT, Cfg256>(p, s);
         case GEMM_CFG_256x128: return launch_cfg<DT, Cfg256x128>(p, s);
         case GEMM_CFG_512x128: return launch_cfg<DT, Cfg512x128>(p, s);
         default: return launch_cfg<DT, Cfg128>(p, s);
+    }
     }
 }
 
@@ -1713,8 +1802,10 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     if (p.epi == EPI_HEADS && p.head_c % 128 != 0 && p.head_c < (1 << 29)) return hipErrorInvalidValue;
     if (p.epi == EPI_HEAD4 && (p.n_store > 128 || p.n_store % 4 != 0 || !p.res1 || !p.res2 || !p.out || !p.out2)) return hipErrorInvalidValue;
     // fp16 + fp8 rows: nn.Linear operands only, whole 64-element super-groups; outputs: fp32 (+ residual), GELU / plain activation rows, heads
-    if (dt == D3R_F16F8 && ((size_t)512 * p.lda * 4 >= (1ull << 32) || (size_t)512 * p.K * 4 >= (1ull << 32))) return hipErrorInvalidValue;   // 32-bit offsets inside a tile
-    if (dt == D3R_F16F8 && (p.amode != AMODE_LINEAR || p.K % 64 != 0 || p.lda % 64 != 0 || p.epi == EPI_CONVT || p.res2 ||
+    const bool f8rows = dt == D3R_F16F8 || dt == D3R_F16X2F8;
+    if (f8rows && ((size_t)512 * p.lda * 4 >= (1ull << 32) || (size_t)512 * p.K * 5 >= (1ull << 32))) return hipErrorInvalidValue;   // 32-bit offsets inside a tile
+    if (dt == D3R_F16X2F8 && p.K % 128 != 0) return hipErrorInvalidValue;      // whole 128-k blocks of five chunks
+    if (f8rows && (p.amode != AMODE_LINEAR || p.K % 64 != 0 || p.lda % 64 != 0 || p.epi == EPI_CONVT || p.res2 ||
                             (p.epi == EPI_T && (p.res1 || p.out2)) || ((p.epi == EPI_T || p.epi == EPI_GELU) && (p.ldo % 64 != 0 || p.n_store % 4 != 0))))
         return hipErrorInvalidValue;
 #ifdef D3R_GEMM_ONLY_DT      // development builds (-DD3R_GEMM_ONLY_DT=4): one precision mode only, a tenth of the compile time
@@ -1726,6 +1817,7 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
         case D3R_F32: return launch_t<D3R_F32>(p, s);
         case D3R_F16X3: return launch_t<D3R_F16X3>(p, s);
         case D3R_F16F8: return launch_t<D3R_F16F8>(p, s);
+        case D3R_F16X2F8: return launch_t<D3R_F16X2F8>(p, s);
     }
 #endif
     return hipErrorInvalidValue;

@@ -149,6 +149,33 @@ def linear_f8(act, weight, bias=None, epilogue='store', residual=None):
     return out if epi == 1 else unpack_f8(out)
 
 
+def pack_w5(w):
+    """fp32 weights (N, K), K % 128 == 0 -> the 2.5-unit weight rows as uint8 (N, 5K): per 128 logical k five 128-byte chunks
+    [w_hi k 0..63 fp16 | w_lo k 0..63 fp16 | w_hi k 64..127 | w_lo k 64..127 | e4m3(w_hi 2^6) k 0..127]  (csrc/common.hpp, Traits<D3R_F16X2F8>)."""
+    w = w.float().clamp(-65504.0, 65504.0)
+    N, K = w.shape
+    assert K % 128 == 0
+    hi = w.half()
+    lo = (w - hi.float()).half()
+    h8 = _e4m3(hi.float() * 64.0)
+    hb, lb = hi.view(torch.uint8).reshape(N, K // 128, 2, 128), lo.view(torch.uint8).reshape(N, K // 128, 2, 128)
+    out = torch.cat((hb[:, :, 0], lb[:, :, 0], hb[:, :, 1], lb[:, :, 1], h8.reshape(N, K // 128, 128)), dim=-1)
+    return out.reshape(N, 5 * K).contiguous()
+
+
+def linear_x2f8(act, weight, bias=None, epilogue='store', residual=None):
+    """`linear` in the 2.5-unit mode (D3R_DTYPE_F16X2F8): fp16 + fp8 activation rows x five-chunk weight rows; K % 128 == 0."""
+    _lib.require_device()
+    M, K = act.shape
+    N = weight.shape[0]
+    ap, wp = pack_f8(act), pad_rows(pack_w5(weight))
+    bp = None if bias is None else pad_rows(bias.float())
+    epi = {'store': 0, 'f32': 1, 'gelu': 2}[epilogue]
+    out = torch.empty((M, N), dtype=torch.float32, device=act.device) if epi == 1 else torch.empty((M, 4 * N), dtype=torch.uint8, device=act.device)
+    check(lib.d3r_linear(ptr(ap), ptr(wp), ptr(bp), ptr(out), ptr(residual), M, N, K, epi, _lib.DTYPE_F16X2F8, current_stream()), 'linear(f16x2f8)')
+    return out if epi == 1 else unpack_f8(out)
+
+
 def layernorm_f8(x, gamma, beta, eps=1e-6):
     """LayerNorm into fp16 + fp8 activation rows (uint8 (rows, 4C))."""
     _lib.require_device()

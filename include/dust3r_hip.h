@@ -45,6 +45,10 @@ extern "C" {
                            * activations a8 = e4m3(hi), b8 = e4m3(lo 2^11); weights a8 = e4m3(lo 2^17), b8 = e4m3(hi 2^6).
                            * d3r_layernorm writes activation rows; d3r_linear takes activation rows x weight rows (epilogue 0 / 2 write
                            * activation rows, N % 64 == 0; epilogue 1 fp32). */
+#define D3R_DTYPE_F16X2F8 5 /* 2.5 MFMA units per product (round 4): hi.hi and hi.w_lo on the f16 MFMA -- the WEIGHTS keep 22 bits -- and only
+                             * a_lo.w_hi on the e4m3 MFMA (K = 128). Model engine: like D3R_DTYPE_F16F8, the transformer blocks' nn.Linear layers.
+                             * Activation rows: the D3R_DTYPE_F16F8 layout (the a8 copy is not read). Weight rows (K % 128 == 0): 5 K bytes, per 128 k
+                             * five 128-byte chunks [w_hi k 0..63 fp16 | w_lo k 0..63 fp16 | w_hi k 64..127 | w_lo k 64..127 | e4m3(w_hi 2^6) k 0..127]. */
 
 const char* d3r_version(void);
 /* 0 when a gfx950 device is visible to the HIP runtime, else an error code (used to fail loudly) */

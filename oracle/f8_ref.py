@@ -34,3 +34,13 @@ def f16f8_matmul(act, weight):
     wh, wl = split(weight)
     cross = e4m3(xh) @ e4m3(wl * LO_SHIFT * W_SHIFT).T + e4m3(xl * LO_SHIFT) @ e4m3(wh * W_SHIFT).T
     return xh @ wh.T + cross / (LO_SHIFT * W_SHIFT)
+
+
+def f16x2f8_matmul(act, weight):
+    """The 2.5-unit evaluation (D3R_DTYPE_F16X2F8, csrc/common.hpp Traits<D3R_F16X2F8>): the weights keep both fp16 halves on the f16 MFMA, only the
+    activations' lo halves go through e4m3:
+        x . w  ~=  hi_x . hi_w  +  hi_x . fp16(lo_w)  +  e4m3(lo_x 2^11) . e4m3(hi_w 2^6) 2^-17"""
+    xh, xl = split(act)
+    wh, wl = split(weight)
+    wl16 = wl.float().half().double()
+    return xh @ wh.T + xh @ wl16.T + (e4m3(xl * LO_SHIFT) @ e4m3(wh * W_SHIFT).T) / (LO_SHIFT * W_SHIFT)

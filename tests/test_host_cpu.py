@@ -401,3 +401,25 @@ def test_postprocess_mode_keywords_follow_the_reference():
         AsymmetricCroCo3DStereo(depth_mode=('exp', 0, 10), landscape_only=False, **MODEL_CONFIGS['tiny_dpt'])
     with pytest.raises(AssertionError):
         AsymmetricCroCo3DStereo(conf_mode=('sigmoid', 0, inf), landscape_only=False, **MODEL_CONFIGS['tiny_dpt'])
+
+
+def test_2p5_unit_weight_rows_host_packer_against_the_emulation():
+    """dust3r_amd.ops.pack_w5 (the five-chunk weight rows of D3R_DTYPE_F16X2F8) decoded chunk by chunk reproduces the factors oracle/f8_ref.py's
+    emulation uses: w_hi, fp16(w_lo) and e4m3(w_hi 2^6), in the documented positions (include/dust3r_hip.h)."""
+    import torch
+    from dust3r_amd.ops import pack_w5
+    from oracle.f8_ref import W_SHIFT, e4m3, split
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn((5, 256), generator=g) * 0.05
+    rows = pack_w5(w)
+    assert rows.shape == (5, 5 * 256) and rows.dtype == torch.uint8
+    wh, wl = split(w)
+    blk = rows.reshape(5, 2, 640)
+    for b in range(2):
+        for half in range(2):
+            k0 = b * 128 + half * 64
+            hi = blk[:, b, (2 * half) * 128:(2 * half + 1) * 128].contiguous().view(torch.float16).double()
+            lo = blk[:, b, (2 * half + 1) * 128:(2 * half + 2) * 128].contiguous().view(torch.float16).double()
+            assert torch.equal(hi, wh[:, k0:k0 + 64]) and torch.equal(lo, wl[:, k0:k0 + 64].float().half().double())
+        h8 = blk[:, b, 512:640].contiguous().view(torch.float8_e4m3fn).double()
+        assert torch.equal(h8, e4m3(wh[:, b * 128:(b + 1) * 128] * W_SHIFT))

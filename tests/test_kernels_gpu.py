@@ -120,6 +120,41 @@ def test_linear_fp16_fp8(gpu, M, N, K, cfg, monkeypatch):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize('cfg', ['0', '1'])
+@pytest.mark.parametrize('M,N,K', [(300, 192, 256), (1024, 768, 768), (515, 1024, 1024), (2048, 256, 4096), (100, 64, 128)])
+def test_linear_2p5_unit(gpu, M, N, K, cfg, monkeypatch):
+    """The 2.5-unit operand mode (D3R_DTYPE_F16X2F8) at kernel level: hi.hi and hi.w_lo on the f16 MFMA, a_lo.w_hi on the e4m3 MFMA whose 128 k of
+    b8 the DMA gathers from two super-groups. Comparator: the SAME arithmetic in fp64 (oracle/f8_ref.py f16x2f8_matmul) -- the kernel must reproduce it
+    to fp32 accumulation noise, which pins the five-chunk weight rows, the chunk schedule of the K loop, the gather and the scale --, and the distance of
+    the scheme to the exact product (weights exact to 22 bits, activations to ~15: 3x closer than fp16 + fp8)."""
+    from dust3r_amd import ops
+    from oracle.f8_ref import f16f8_matmul, f16x2f8_matmul
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg)
+    g = torch.Generator(device='cpu').manual_seed(M * 11 + N)
+    a = torch.randn((M, K), generator=g).to(gpu)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(gpu)
+    b = torch.randn(N, generator=g).to(gpu)
+    res = torch.randn((M, N), generator=g).to(gpu)
+    emu = (f16x2f8_matmul(a, w) + b.double()).float()
+    exact = (a.double() @ w.double().T + b.double()).float()
+    assert relerr(emu, exact) < 2e-5 and relerr(emu, exact) < relerr((f16f8_matmul(a, w) + b.double()).float(), exact)
+    got = {}
+    for wide in ('0', '1'):
+        monkeypatch.setenv('D3R_GEMM_NOWIDE', wide)
+        o_res = ops.linear_x2f8(a, w, b, 'f32', residual=res)
+        assert relerr(o_res, emu + res) < 3e-6, 'fp32 + residual epilogue'
+        assert relerr(ops.linear_x2f8(a, w, None, 'f32'), emu - b) < 3e-6, 'no bias'
+        if N % 64 == 0:
+            o_store, o_gelu = ops.linear_x2f8(a, w, b, 'store'), ops.linear_x2f8(a, w, b, 'gelu')
+            assert relerr(o_store, emu) < 4e-5, 'activation-row store'
+            assert relerr(o_gelu, F.gelu(emu)) < 4e-5, 'gelu epilogue'
+            got[wide] = (o_res, o_store, o_gelu)
+        else:
+            got[wide] = (o_res,)
+    for x, y in zip(got['0'], got['1']):
+        assert torch.equal(x, y)
+
+
 def test_linear_fp16_fp8_operand_beyond_4_gib(gpu):
     """The fp16 + fp8 K loop addresses its DMA sources as a wave-uniform 64-bit tile base (SGPRs) plus ONE 32-bit offset per lane: the
     offsets are relative to the tile's first row, so an activation operand larger than 4 GiB (here 280 000 x 4096 x 4 B = 4.6 GB: the
