@@ -639,66 +639,150 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         const uint32_t arow0 = (uint32_t)(((size_t)(min(m0 + lrow, p.M - 1) - m0) * p.lda) * EB);
         const uint32_t w0 = (uint32_t)((size_t)lrow * wrow) + coff_plain;
         const size_t stride_a = (size_t)CF::PASS_ROWS * p.lda * EB, stride_w = (size_t)CF::PASS_ROWS * wrow;
-        auto stage5 = [&](int kb, int st, int buf) __attribute__((always_inline)) {     // st: 0..4 (a compile-time constant at every call site)
-            const uint32_t sb = lds0 + buf * STAGE_BYTES;
-            const char* ab = tile_a + (size_t)kb * 512 + (st == 2 || st == 3 ? 256 : 0);
-            const uint32_t ac = st == 4 ? coff_b8 : coff_plain;
-#pragma unroll
-            for (int q = 0; q < CF::APASS; ++q) {
-                if (!edge) {
-                    glds16_so(ab + q * stride_a, arow0 + ac, sb + q * (CF::NW * 1024));
-                } else {
-                    const int m = min(m0 + q * CF::PASS_ROWS + lrow, p.M - 1);
-                    glds16_so(ab, (uint32_t)(((size_t)(m - m0) * p.lda) * EB) + ac, sb + q * (CF::NW * 1024));
-                }
-            }
+        // LDS: two ACTIVATION slots and two WEIGHT slots that advance independently -- a weight chunk lives for one step, an activation chunk for
+        // the two steps that pair it with w_hi and w_lo, so it is fetched ONCE (8 chunk-rows of DMA per 128 k, like split-fp16, instead of 10) and its
+        // successor has two steps to land. Slot s of the activations at s * BM * KTB, of the weights at 2 * BM * KTB + s * BN * KTB (the fragment
+        // addresses below do not use p_off / q_off: the operand-role swap of the V^T regions exchanges the two bases).
+        // The four f16 steps of a block are ONE loop body (not unrolled: five unrolled bodies with their own address arithmetic spilled), the
+        // fp8 step a second one. A pieces: indices WPASS .. LPS - 1, issued by the steps that open a pair (st even) only.
+        constexpr int ASLOT = BM * KTB, WSLOT = BN * KTB, WBASE = 2 * ASLOT;
+        static_assert(2 * ASLOT + 2 * WSLOT == 2 * STAGE_BYTES, "same LDS footprint as the two-stage loops");
+        const uint32_t a_plain = arow0 + coff_plain, a_b8 = arow0 + coff_b8;
+        // W piece q of step st of block kb -> weight slot wbuf; A piece q of chunk ac (0: hi k 0..63, 1: hi k 64..127, 2: the b8 gather) -> slot abuf
+        auto piece_w = [&](int q, int kb, int st, int wbuf) __attribute__((always_inline)) {
             const char* wb = tile_w + (size_t)kb * 640 + st * 128;
-#pragma unroll
-            for (int q = 0; q < CF::WPASS; ++q) glds16_so(wb + q * stride_w, w0, sb + BM * KTB + q * (CF::NW * 1024));
+            glds16_so(wb + q * stride_w, w0, lds0 + WBASE + wbuf * WSLOT + q * (CF::NW * 1024));
         };
+        auto piece_a = [&](int q, int kb, int ac, int abuf) __attribute__((always_inline)) {
+            const char* ab = tile_a + (size_t)kb * 512 + (ac == 1 ? 256 : 0);
+            const bool gather = ac == 2;
+            const uint32_t dst = lds0 + abuf * ASLOT + q * (CF::NW * 1024);
+            if (!edge) {
+                glds16_so(ab + q * stride_a, gather ? a_b8 : a_plain, dst);
+            } else {
+                const int m = min(m0 + q * CF::PASS_ROWS + lrow, p.M - 1);
+                glds16_so(ab, (uint32_t)(((size_t)(m - m0) * p.lda) * EB) + (gather ? coff_b8 : coff_plain), dst);
+            }
+        };
+        // IL (PP == 4), as in the fp16 + fp8 loop: the DMA of the coming steps is issued a piece at a time behind the MFMAs of the first fragment rows
+        // (fragment reads one row ahead, rows pinned with sched_barrier) instead of in one burst behind the barrier, where neither wave of a SIMD
+        // has an MFMA to issue. A step here is 64 MFMAs per wave (1024 cycles) against 96 in the split-fp16 loop: the burst weighs more
+        // (measured on the forward: 198.2 -> 202.4 pairs/s, profiles/r04_e).
+        constexpr bool IL = CF::PP == 4;
+        constexpr int PPR = (LPS + FI - 1) / FI;                  // pieces per fragment row, over the FI rows of the step's first half
         const int nblk = p.K >> 7;
-        stage5(0, 0, 0);
-        int buf = 0;
-        for (int kb = 0; kb < nblk; ++kb) {
+        // what step (kb, st) issues behind its barrier: the W chunk of the NEXT step into the other weight slot, and -- when it opens a pair or is
+        // the fp8 step -- the NEXT activation chunk into the other activation slot (chunk 1 at st 0, the gather at st 2, chunk 0 of kb + 1 at st 4)
+        auto issue = [&](int i, int kb, int st, int abuf, int wbuf) __attribute__((always_inline)) {     // i: piece index 0 .. LPS - 1
+            if (i < CF::WPASS) {
+                if (st < 4) piece_w(i, kb, st + 1, wbuf ^ 1);
+                else if (kb + 1 < nblk) piece_w(i, kb + 1, 0, wbuf ^ 1);
+            } else {
+                const int q = i - CF::WPASS;
+                if (st == 0) piece_a(q, kb, 1, abuf ^ 1);
+                else if (st == 2) piece_a(q, kb, 2, abuf ^ 1);
+                else if (st == 4 && kb + 1 < nblk) piece_a(q, kb + 1, 0, abuf ^ 1);
+            }
+        };
 #pragma unroll
-            for (int st = 0; st < 5; ++st) {
+        for (int q = 0; q < CF::APASS; ++q) piece_a(q, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < CF::WPASS; ++q) piece_w(q, 0, 0, 0);
+        int abuf = 0, wbuf = 0;
+        for (int kb = 0; kb < nblk; ++kb) {
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {          // f16 steps: (a_hi chunk, w_hi chunk), (the same a_hi, w_lo chunk), twice
                 d3r_wait_vm0();
                 __syncthreads();
-                if (st < 4) stage5(kb, st + 1, buf ^ 1);
-                else if (kb + 1 < nblk) stage5(kb + 1, 0, buf ^ 1);
-                const char* sb = smem + buf * STAGE_BYTES;
-                if (st < 4) {
+                if (!IL) {
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
-                        uint4 qf[FJ];
+                    for (int i = 0; i < LPS; ++i) issue(i, kb, st, abuf, wbuf);
+                }
+                const char* ab_ = smem + abuf * ASLOT;
+                const char* wb_ = smem + WBASE + wbuf * WSLOT;
+                const char* pb = swap ? ab_ : wb_;       // P tile supplies i (weights unless swapped), Q tile supplies j
+                const char* qb = swap ? wb_ : ab_;
 #pragma unroll
-                        for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(sb + q_off + (q_row0 + f * 16) * KTB + coff);
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int coff = ((ks * 4 + fgrp) ^ fsw) * 16;
+                    uint4 qf[FJ];
+#pragma unroll
+                    for (int f = 0; f < FJ; ++f) qf[f] = *reinterpret_cast<const uint4*>(qb + (q_row0 + f * 16) * KTB + coff);
+                    if constexpr (!IL) {
 #pragma unroll
                         for (int fi = 0; fi < FI; ++fi) {
-                            const uint4 pf = *reinterpret_cast<const uint4*>(sb + p_off + (p_row0 + fi * 16) * KTB + coff);
+                            const uint4 pf = *reinterpret_cast<const uint4*>(pb + (p_row0 + fi * 16) * KTB + coff);
 #pragma unroll
                             for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], pf, qf[fj]);
                         }
-                    }
-                } else {
-                    const int ca = (fgrp ^ fsw) * 16, cb = ((4 + fgrp) ^ fsw) * 16;
-                    uint4 qa[FJ], qb[FJ];
+                    } else {
+                        uint4 cur = *reinterpret_cast<const uint4*>(pb + p_row0 * KTB + coff);
 #pragma unroll
-                    for (int f = 0; f < FJ; ++f) {
-                        const char* qr = sb + q_off + (q_row0 + f * 16) * KTB;
-                        qa[f] = *reinterpret_cast<const uint4*>(qr + ca);
-                        qb[f] = *reinterpret_cast<const uint4*>(qr + cb);
-                    }
+                        for (int fi = 0; fi < FI; ++fi) {
+                            uint4 nxt = cur;
+                            if (fi + 1 < FI) nxt = *reinterpret_cast<const uint4*>(pb + (p_row0 + (fi + 1) * 16) * KTB + coff);
 #pragma unroll
-                    for (int fi = 0; fi < FI; ++fi) {
-                        const char* pr = sb + p_off + (p_row0 + fi * 16) * KTB;
-                        const uint4 pa = *reinterpret_cast<const uint4*>(pr + ca), pb = *reinterpret_cast<const uint4*>(pr + cb);
+                            for (int fj = 0; fj < FJ; ++fj) TR::mma16_hi(acc[fi][fj], cur, qf[fj]);
+                            if (ks == 0) {
 #pragma unroll
-                        for (int fj = 0; fj < FJ; ++fj) TR::mma16_f8(acc[fi][fj], pa, pb, qa[fj], qb[fj]);
+                                for (int i = fi * PPR; i < (fi + 1) * PPR && i < LPS; ++i) issue(i, kb, st, abuf, wbuf);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            cur = nxt;
+                        }
                     }
                 }
-                buf ^= 1;
+                wbuf ^= 1;
+                abuf ^= (st & 1);                     // the activation chunk changes after the second step of a pair
+            }
+            {                                         // fp8 step: b8 of the block's 128 k (gathered) against the h8 chunk
+                d3r_wait_vm0();
+                __syncthreads();
+                if (!IL) {
+#pragma unroll
+                    for (int i = 0; i < LPS; ++i) issue(i, kb, 4, abuf, wbuf);
+                }
+                const char* ab_ = smem + abuf * ASLOT;
+                const char* wb_ = smem + WBASE + wbuf * WSLOT;
+                const char* pb = swap ? ab_ : wb_;
+                const char* qb = swap ? wb_ : ab_;
+                const int ca = (fgrp ^ fsw) * 16, cb = ((4 + fgrp) ^ fsw) * 16;
+                uint4 qa[FJ], qbb[FJ];
+#pragma unroll
+                for (int f = 0; f < FJ; ++f) {
+                    const char* qr = qb + (q_row0 + f * 16) * KTB;
+                    qa[f] = *reinterpret_cast<const uint4*>(qr + ca);
+                    qbb[f] = *reinterpret_cast<const uint4*>(qr + cb);
+                }
+                if constexpr (!IL) {
+#pragma unroll
+                    for (int fi = 0; fi < FI; ++fi) {
+                        const char* pr = pb + (p_row0 + fi * 16) * KTB;
+                        const uint4 pa = *reinterpret_cast<const uint4*>(pr + ca), pbv = *reinterpret_cast<const uint4*>(pr + cb);
+#pragma unroll
+                        for (int fj = 0; fj < FJ; ++fj) TR::mma16_f8(acc[fi][fj], pa, pbv, qa[fj], qbb[fj]);
+                    }
+                } else {
+                    const char* pr0 = pb + p_row0 * KTB;
+                    uint4 ca0 = *reinterpret_cast<const uint4*>(pr0 + ca), cb0 = *reinterpret_cast<const uint4*>(pr0 + cb);
+#pragma unroll
+                    for (int fi = 0; fi < FI; ++fi) {
+                        uint4 na = ca0, nb = cb0;
+                        if (fi + 1 < FI) {
+                            const char* pr = pb + (p_row0 + (fi + 1) * 16) * KTB;
+                            na = *reinterpret_cast<const uint4*>(pr + ca);
+                            nb = *reinterpret_cast<const uint4*>(pr + cb);
+                        }
+#pragma unroll
+                        for (int fj = 0; fj < FJ; ++fj) TR::mma16_f8(acc[fi][fj], ca0, cb0, qa[fj], qbb[fj]);
+#pragma unroll
+                        for (int i = fi * PPR; i < (fi + 1) * PPR && i < LPS; ++i) issue(i, kb, 4, abuf, wbuf);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ca0 = na; cb0 = nb;
+                    }
+                }
+                wbuf ^= 1;
+                abuf ^= 1;
             }
         }
     } else if constexpr (DT == D3R_F16F8) {
@@ -1763,8 +1847,11 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
             if ((long)cdiv(p.M, 128) * cdiv(p.n_store, 128) < t) return launch_cfg<DT, Cfg128w8>(p, s);
         }
     }
-    if constexpr (DT == D3R_F16X2F8) {      // nn.Linear matrices of the transformer blocks only (N >= 768): the two square tiles
-        return cfg == GEMM_CFG_256 ? launch_cfg<DT, Cfg256>(p, s) : launch_cfg<DT, Cfg128>(p, s);
+    if constexpr (DT == D3R_F16X2F8) {      // nn.Linear matrices of the transformer blocks only (N >= 768): the two square tiles; D3R_GEMM_X2IL=0 / 1:
+        const char* e_il = getenv("D3R_GEMM_X2IL");     // DMA pieces of the next step in one burst behind the barrier / interleaved with the MFMA rows (default: on the 256-wide tile)
+        const int il = e_il ? (e_il[0] == '1' ? 1 : 0) : -1;
+        if (cfg == GEMM_CFG_256) return (il != 0) ? launch_cfg<DT, Cfg256il>(p, s) : launch_cfg<DT, Cfg256>(p, s);
+        return il == 1 ? launch_cfg<DT, Cfg128il>(p, s) : launch_cfg<DT, Cfg128>(p, s);
     } else {
     switch (cfg) {
         case GEMM_CFG_256: return launch_cfg<DT, Cfg256>(p, s);
