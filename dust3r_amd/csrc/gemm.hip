@@ -344,6 +344,74 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             ab = ab == 2 ? 0 : ab + 1;
             wb ^= 1;
         }
+    } else if constexpr (DT == D3R_F16X3 && CF::PP == 4) {
+        // ---- split-fp16, nn.Linear operands, DMA pieces interleaved with the MFMA rows (round 4) ---------------------------------------------
+        // The plain loop opens every K step with [vmcnt(0) | s_barrier | LPS DMA issues | first fragment reads]: a burst during which neither wave of
+        // a SIMD has an MFMA to issue. Here the pieces of step kt + 1 go out one fragment row at a time behind the MFMAs of step kt (fragment reads
+        // one row ahead, rows pinned with sched_barrier), as in the fp16 + fp8 and 2.5-unit loops. DMA addressing: a wave-uniform 64-bit tile base
+        // (SGPRs) + ONE 32-bit offset per operand (the plain loop keeps one 64-bit address per staged row: 16 VGPRs). Same MFMA order per accumulator
+        // as the plain loop: bit-identical results.
+        static_assert(KTB == 128 && NS == 2, "split-fp16 rows: 128-byte K steps, two stages");
+        const bool edge = __builtin_amdgcn_readfirstlane(m0 + BM > p.M ? 1 : 0) != 0;
+        const char* const tile_a = reinterpret_cast<const char*>(p.act) + (size_t)__builtin_amdgcn_readfirstlane(m0) * p.lda * EB;
+        const char* const tile_w = reinterpret_cast<const char*>(p.wgt) + (size_t)__builtin_amdgcn_readfirstlane(n0) * p.K * EB;
+        const uint32_t a0 = (uint32_t)(((size_t)(min(m0 + lrow, p.M - 1) - m0) * p.lda) * EB + lchunk * 16);
+        const uint32_t w0 = (uint32_t)(((size_t)lrow * p.K) * EB + lchunk * 16);
+        const size_t stride_a = (size_t)CF::PASS_ROWS * p.lda * EB, stride_w = (size_t)CF::PASS_ROWS * p.K * EB;
+        auto piece3 = [&](int idx, int kt, int buf) __attribute__((always_inline)) {
+            const uint32_t sb = lds0 + buf * STAGE_BYTES;
+            if (idx < CF::APASS) {
+                const int q = idx;
+                const char* ab = tile_a + (size_t)kt * KTB;
+                if (!edge) {
+                    glds16_so(ab + q * stride_a, a0, sb + q * (CF::NW * 1024));
+                } else {
+                    const int m = min(m0 + q * CF::PASS_ROWS + lrow, p.M - 1);
+                    glds16_so(ab, (uint32_t)(((size_t)(m - m0) * p.lda) * EB + lchunk * 16), sb + q * (CF::NW * 1024));
+                }
+            } else {
+                const int q = idx - CF::APASS;
+                glds16_so(tile_w + (size_t)kt * KTB + q * stride_w, w0, sb + BM * KTB + q * (CF::NW * 1024));
+            }
+        };
+        constexpr int PPR = (LPS + FI - 1) / FI;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) piece3(i, 0, 0);
+        const int chi = (fgrp ^ fsw) * 16, clo = ((4 + fgrp) ^ fsw) * 16;   // LDS image: [hi0..hi3 | lo0..lo3]
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            d3r_wait_vm0();
+            __syncthreads();
+            const bool more = kt + 1 < nk;
+            const char* sb = smem + buf * STAGE_BYTES;
+            uint4 qf[FJ], ql[FJ];
+#pragma unroll
+            for (int f = 0; f < FJ; ++f) {
+                const char* qr = sb + q_off + (q_row0 + f * 16) * KTB;
+                qf[f] = *reinterpret_cast<const uint4*>(qr + chi);
+                ql[f] = *reinterpret_cast<const uint4*>(qr + clo);
+            }
+            const char* pr0 = sb + p_off + p_row0 * KTB;
+            uint4 cf = *reinterpret_cast<const uint4*>(pr0 + chi), cl = *reinterpret_cast<const uint4*>(pr0 + clo);
+#pragma unroll
+            for (int fi = 0; fi < FI; ++fi) {
+                uint4 nf = cf, nl = cl;
+                if (fi + 1 < FI) {
+                    const char* pr = sb + p_off + (p_row0 + (fi + 1) * 16) * KTB;
+                    nf = *reinterpret_cast<const uint4*>(pr + chi);
+                    nl = *reinterpret_cast<const uint4*>(pr + clo);
+                }
+#pragma unroll
+                for (int fj = 0; fj < FJ; ++fj) TR::mma16x3(acc[fi][fj], cf, cl, qf[fj], ql[fj]);
+                if (more) {
+#pragma unroll
+                    for (int i = fi * PPR; i < (fi + 1) * PPR && i < LPS; ++i) piece3(i, kt + 1, buf ^ 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cf = nf; cl = nl;
+            }
+            buf ^= 1;
+        }
     } else if constexpr (CF::PP == 2) {
         // ---- split-fp16, software pipelined (2 stages, ONE barrier per K step, no bubble at the step boundary) ---------------
         // The plain loop below opens every K step with [vmcnt(0) | s_barrier | 8 DMA issues | first ds_reads] during which none of
@@ -1807,6 +1875,10 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
         // split-fp16: D3R_GEMM_X3SW=1 selects the software-pipelined K loop. Measured on MI355X (profiles/r02_*): equal to the plain
         // two-stage loop on the 256-wide tiles, 10-15 % behind on the 128 x 128 tile -- the K loop is not where the time goes (the
         // same launches without their epilogue run 30 % faster in either form), so the plain loop stays the default.
+        // D3R_GEMM_X3IL=1 / 0: nn.Linear launches on the 256 x 256 tile with the DMA pieces interleaved with the MFMA rows (bit-identical)
+        const char* e_il = getenv("D3R_GEMM_X3IL");
+        const bool x3il = e_il ? e_il[0] == '1' : false;
+        if (x3il && cfg == GEMM_CFG_256 && p.amode == AMODE_LINEAR && (size_t)512 * p.lda * 4 < (1ull << 32) && (size_t)512 * p.K * 4 < (1ull << 32)) return launch_cfg<DT, Cfg256il>(p, s);
         const char* e_sw = getenv("D3R_GEMM_X3SW");
         const bool sw = e_sw ? e_sw[0] == '1' : false;
         if (sw) {

@@ -338,7 +338,7 @@ def test_full_size_default_mode_under_sharp_attention_and_outlier_channels(gpu, 
     with torch.no_grad():
         r1, r2 = oracle(v1, v2)
     worst, stats = {}, {}
-    for prec in ('fp32', 'fp16x3', 'fp16f8'):
+    for prec in ('fp32', 'fp16x3', 'fp16x2f8', 'fp16f8'):
         eng.set_precision(prec)
         e1, e2 = eng(v1, v2)
         for name, a, b in (('pts1', e1['pts3d'], r1['pts3d']), ('pts2', e2['pts3d_in_other_view'], r2['pts3d_in_other_view'])):
