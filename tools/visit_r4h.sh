@@ -13,5 +13,4 @@ timeout 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -2 $OUT/
 bash tools/gpu_round.sh bench prof pmc pmcsq > $OUT/round.log 2>&1; grep -E "pairs/s on|aligner [0-9]" $OUT/bench.log | tail -3; stamp bench-prof-pmc
 timeout 300 python tools/latency_probe.py forward-only > $OUT/latency.log 2>&1; grep -E "eager|pairs" $OUT/latency.log | tail -6; stamp latency
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log; stamp suite
-python tools/summarize_prof.py $OUT > $OUT/prof_summary.txt 2>&1
-find $OUT -type f -size +6M -delete
+# (tools/gpu_round.sh has written prof_summary.txt / pmc_latest.json and trimmed the big per-dispatch csvs)
