@@ -98,6 +98,10 @@ typedef GemmCfg<2, 2, 2, 2, 2, 128, 4> Cfg64s4;
 // 128 x 128 by EIGHT waves of 64 (n) x 32 (m): twice the waves per tile (16 per CU with two resident blocks) for the mid-size problems of the
 // small-batch forwards, where a K step is bound by latency rather than by the matrix pipe. Bit-identical to the four-wave shape.
 typedef GemmCfg<2, 4, 4, 2, 4> Cfg128w8;
+// M 384 x N 192 by eight waves stacked along m, each 192 (n) x 48 (m) = 12 x 3 fragments (144 accumulators; 147 KiB of LDS): the decoder's 24576-row GEMMs with
+// N = 768 / 1536 / 2304 / 3072 are exactly 1 / 2 / 3 / 4 rounds of 256 CUs on it (128 x 128: 1152 tiles = 2.25 rounds of 512 slots). Round 4; tile configuration 9,
+// chosen by gemm_pick_config (D3R_GEMM_T384=0: never). Same K order per output element as every other shape: bit-identical results.
+typedef GemmCfg<1, 8, 12, 3, 2> Cfg384x192;
 typedef GemmCfg<1, 4, 8, 4, 2, 64, 3> Cfg256x128w4;  // M 256 x N 128, 4 waves of 128 (n) x 64 (m), 64-byte K rows: 48 KiB LDS, TWO
                                                   // blocks per CU, three stages (72 KiB)
 
@@ -1791,8 +1795,9 @@ int gemm_pick_config(const GemmParams& p, int dt) {
     int forced = p.force_cfg;
     if (forced < 0) {   // D3R_GEMM_CFG=0|1|2|3 pins the tile configuration (parity tests, probes); infeasible choices are ignored
         const char* e = getenv("D3R_GEMM_CFG");
-        if (e && e[0] >= '0' && e[0] <= '8' && e[1] == 0) forced = e[0] - '0';
+        if (e && e[0] >= '0' && e[0] <= '9' && e[1] == 0) forced = e[0] - '0';
     }
+    if (forced == GEMM_CFG_384x192 && dt == D3R_F16X3 && !heads && p.epi != EPI_HEADS && p.epi != EPI_HEAD4 && p.amode == AMODE_LINEAR && cdiv(p.n_store, 192) * 192 <= n_rows) return forced;
     if (forced == GEMM_CFG_128 || forced == GEMM_CFG_64 || (forced == GEMM_CFG_256 && ok256) ||
         ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128 || forced == GEMM_CFG_256x128W4 || forced == GEMM_CFG_256x128R) && !heads) || ((forced == GEMM_CFG_256S4 || forced == GEMM_CFG_256PP) && ok256))
         return forced;
@@ -1804,6 +1809,20 @@ int gemm_pick_config(const GemmParams& p, int dt) {
         if (cdiv(p.M, 512) >= 512) return GEMM_CFG_512x128;
         if (cdiv(p.M, 256) >= 512) return GEMM_CFG_256x128;
         return GEMM_CFG_128;
+    }
+    // split-fp16, nn.Linear launches without attention heads whose (M / 384) x (N / 192) tiles fill whole rounds of the 256 CUs: the decoder's 24576-row
+    // GEMMs at 32 pairs per step (N = 768 / 3072 -> 256 / 1024 tiles; on the 128 x 128 tile 1152 tiles = 2.25 rounds of the 512 slots). Measured
+    // (profiles/r04_i, r04_k). In isolation, us per launch, default tile -> this one: fc2 24576 x 768 x 3072 + residual 389 -> 280, fc1 24576 x 3072 x 768
+    // + GELU 384 -> 364, plain stores 108 -> 88 / 222 -> 161 / 286 -> 224 (N = 768 / 1536 / 2304), the fp32-residual projections at K = 768 90 -> 94.
+    // On the forward the isolated gains mostly vanish (in the network the default tiles run faster than back to back on one shape, and the two decoder
+    // sides overlap their tails on the two streams): every eligible launch on it 194.55 -> 196.75 and 191.7 -> 192.7 pairs/s (two boxes, every run above every
+    // baseline run); WITHOUT the K <= 1024 projections 191.7 -> 190.9 -- so the rule is "every eligible launch". D3R_GEMM_T384=0: never; =1: not the
+    // fp32-residual projections at K <= 1024 (the probe of that A/B).
+    if (dt == D3R_F16X3 && !heads && p.epi != EPI_HEADS && p.epi != EPI_HEAD4 && p.amode == AMODE_LINEAR && p.n_store % 192 == 0 && cdiv(p.n_store, 192) * 192 <= n_rows) {
+        const char* e384 = getenv("D3R_GEMM_T384");
+        const long t384 = (long)cdiv(p.M, 384) * cdiv(p.n_store, 192);
+        const bool short_res = p.epi == EPI_F32 && p.K <= 1024;
+        if (!(e384 && e384[0] == '0') && !(short_res && e384 && e384[0] == '1') && t384 >= 230 && (t384 % 256 == 0 || t384 % 256 >= 230)) return GEMM_CFG_384x192;
     }
     // split-fp16, launches without attention heads (their V^T regions need a square tile): the two-blocks-per-CU 256 x 128 shape with the
     // weights of a K step in registers. Measured on MI355X (profiles/r03_c/gemmtrace_cfg7.log, bench_r*.log): it wins where the epilogue
@@ -1850,6 +1869,7 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
     if (cfg == GEMM_CFG_256x128W4 && SPLIT) cfg = GEMM_CFG_256x128;
     if (cfg == GEMM_CFG_256x128R && DT != D3R_F16X3) cfg = GEMM_CFG_256x128;      // the weights-in-registers shape exists for split-fp16 only
     if (cfg == GEMM_CFG_64 && DT != D3R_F16X3) cfg = GEMM_CFG_128;                // the 64 x 64 shape too
+    if (cfg == GEMM_CFG_384x192 && DT != D3R_F16X3) cfg = GEMM_CFG_128;           // and the 384 x 192 one
     // the fused head tail needs a wave to hold every output channel of its rows: waves stacked along m, 128 columns per wave
     if (p.epi == EPI_HEAD4 && (DT != D3R_F16X3 || !(cfg == GEMM_CFG_512x128 || cfg == GEMM_CFG_256x128R))) return hipErrorInvalidValue;
     if ((cfg == GEMM_CFG_256S4 || cfg == GEMM_CFG_256PP) && SPLIT) cfg = GEMM_CFG_256;
@@ -1866,6 +1886,7 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
         if (a3 && cfg == GEMM_CFG_256) return launch_cfg<DT, Cfg256a3>(p, s);
     }
     if constexpr (DT == D3R_F16X3) {
+        if (cfg == GEMM_CFG_384x192) return launch_cfg<DT, Cfg384x192>(p, s);
         if (cfg == GEMM_CFG_256x128R) return launch_cfg<DT, Cfg256x128r>(p, s);
         if (cfg == GEMM_CFG_64) {
             const char* e_ns = getenv("D3R_GEMM_64NS");     // probe: LDS ring depth of the 64 x 64 tile (2 | 3 | 4)

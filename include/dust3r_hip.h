@@ -102,7 +102,8 @@ int d3r_gemm_set_trace(void* buf, size_t capacity_blocks);
 /* Diagnostics, host only (no device needed): the GEMM tile configuration the engine picks for an nn.Linear-shaped problem (epilogue codes of
  * d3r_linear; with_residual: an fp32 residual row is added). 0 = 128x128 (eight waves below 1100 tiles in split-fp16), 1 = 256x256,
  * 2 = 256x128, 3 = 512x128, 7 = 256x128 by four waves with a K step's weights in registers (two blocks per CU), 8 = 64x64 on a three-slot
- * ring (problems of fewer than 200 128x128 tiles, split-fp16). The D3R_GEMM_* probe variables apply. DESIGN.md section 4.1. */
+ * ring (problems of fewer than 200 128x128 tiles, split-fp16), 9 = M 384 x N 192 by eight waves of 192 (n) x 48 (m) (split-fp16 nn.Linear launches without
+ * attention heads whose tiles fill whole rounds of 256 CUs: the decoder's 24576-row GEMMs of the 32-pair step). The D3R_GEMM_* probe variables apply. DESIGN.md section 4.1. */
 int d3r_gemm_tile_config(int dtype, int M, int N, int K, int epilogue, int with_residual);
 
 /* ------------------------------------------------------------------------------------------------

@@ -77,7 +77,7 @@ def test_forward_matches_oracle(gpu, precision, config, B, H, W):
     compare(eng, oracle, v1, v2, *TOLS[precision], tag=f'{config} {precision} {B}x{H}x{W}')
 
 
-@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '4', '5', '6', '7', '8'])
+@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '4', '5', '6', '7', '8', '9'])
 @pytest.mark.parametrize('precision', ['fp32', 'fp16x3', 'fp16x2f8', 'fp16f8'])
 def test_forward_with_pinned_gemm_tile(gpu, precision, cfg, monkeypatch):
     """The whole network with the GEMM tile configuration pinned (D3R_GEMM_CFG): the 256-wide tiles' q/k RoPE scatter,
@@ -101,7 +101,7 @@ def test_forward_16bit_with_pinned_gemm_tile(gpu, cfg, monkeypatch):
     compare(eng, oracle, v1, v2, *TOLS['fp16'], tag=f'tiny_dpt fp16 128x128 cfg{cfg}')
 
 
-@pytest.mark.parametrize('cfg', ['0', '0w8', '1', '2', '3', '7', '8'])
+@pytest.mark.parametrize('cfg', ['0', '0w8', '1', '2', '3', '7', '8', '9'])
 def test_forward_split_fp16_kernel_variants(gpu, cfg, monkeypatch):
     """fp16x3 (the default, parity-grade mode) at 128x128 = 64 tokens, where the attention projections take the LDS-staged
     x3 epilogue (q / k RoPE scatter, operand-swapped V^T): every (software-pipelined | plain K loop) x (wide | direct epilogue)

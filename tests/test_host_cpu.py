@@ -356,16 +356,21 @@ def test_gemm_tile_dispatch_table(monkeypatch):
     """The GEMM tile heuristic as a host function (d3r_gemm_tile_config, no device): the shapes of the BASELINE forward at 32 pairs per
     step and at one pair per call land on the tile configurations DESIGN.md section 4.1 / 6 report, and the probe variables move them."""
     from dust3r_amd._lib import DTYPE_BF16, DTYPE_F16F8, DTYPE_F16X3, lib
-    for v in ('D3R_GEMM_CFG', 'D3R_GEMM_T64', 'D3R_GEMM_T256', 'D3R_GEMM_R', 'D3R_GEMM_MID', 'D3R_GEMM_F32CFG', 'D3R_GEMM_PP'):
+    for v in ('D3R_GEMM_CFG', 'D3R_GEMM_T64', 'D3R_GEMM_T256', 'D3R_GEMM_R', 'D3R_GEMM_MID', 'D3R_GEMM_F32CFG', 'D3R_GEMM_PP', 'D3R_GEMM_T384'):
         monkeypatch.delenv(v, raising=False)
     PLAIN, F32, GELU = 0, 1, 2
     cfg = lambda dt, M, N, K, epi=PLAIN, res=0: lib.d3r_gemm_tile_config(dt, M, N, K, epi, res)   # noqa: E731
     x3 = DTYPE_F16X3
     # 32 pairs = 64 images x 768 tokens: the encoder's four linears, the decoder's 768-wide ones (one side = 24576 rows)
-    assert cfg(x3, 49152, 3072, 1024) == 1 and cfg(x3, 49152, 4096, 1024, GELU) == 1 and cfg(x3, 49152, 1024, 4096, F32, 1) == 1
+    assert cfg(x3, 49152, 4096, 1024, GELU) == 1 and cfg(x3, 49152, 1024, 4096, F32, 1) == 1 and cfg(x3, 49152, 1024, 1024) == 1
     assert cfg(x3, 49152, 1024, 1024, F32, 1) == 7           # fp32-residual projection at K <= 1024: two blocks per CU, weights in registers
     assert cfg(x3, 49152, 1024, 1024, F32, 0) == 1           # ... only with a residual
-    assert cfg(x3, 24576, 768, 768, F32, 1) == 0 and cfg(x3, 24576, 2304, 768) == 1 and cfg(x3, 24576, 3072, 768, GELU) == 1
+    # round 4: the decoder's 24576-row GEMMs whose (M / 384) x (N / 192) tiles fill whole rounds of 256 CUs take the 384 x 192 tile (configuration 9)
+    assert cfg(x3, 24576, 768, 3072, F32, 1) == 9 and cfg(x3, 24576, 3072, 768, GELU) == 9 and cfg(x3, 24576, 2304, 768) == 9 and cfg(x3, 24576, 768, 768, F32, 1) == 9
+    assert cfg(DTYPE_BF16, 24576, 768, 3072, F32, 1) != 9 and cfg(x3, 24576 - 384 * 20, 768, 3072, F32, 1) != 9      # split-fp16 only; 176 tiles do not fill the chip
+    monkeypatch.setenv('D3R_GEMM_T384', '0')
+    assert cfg(x3, 24576, 768, 3072, F32, 1) == 0 and cfg(x3, 24576, 3072, 768, GELU) == 1 and cfg(x3, 24576, 768, 768, F32, 1) == 0
+    monkeypatch.delenv('D3R_GEMM_T384')
     assert cfg(x3, 6291456, 128, 1152) == 3 and cfg(x3, 196608, 128, 1152) == 2 and cfg(x3, 1000, 96, 768) == 0   # N <= 128: the head's shapes
     # one pair per call = 1536 encoder rows / 768 decoder rows per side: small problems on the 64 x 64 tile, mid-size ones stay on 128 x 128
     assert cfg(x3, 1536, 1024, 4096, F32, 1) == 8 and cfg(x3, 1536, 1024, 1024, F32, 1) == 8 and cfg(x3, 768, 768, 768, F32, 1) == 8

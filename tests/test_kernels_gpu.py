@@ -52,7 +52,7 @@ def test_linear_epilogues(gpu, dtype, M, N, K):
 
 
 @pytest.mark.parametrize('sw', ['1', '0'])
-@pytest.mark.parametrize('cfg', ['0', '0w8', '1', '2', '3', '7', '8'])
+@pytest.mark.parametrize('cfg', ['0', '0w8', '1', '2', '3', '7', '8', '9'])
 @pytest.mark.parametrize('M,N,K', [(300, 192, 256), (1000, 3072, 1024), (77, 96, 768), (2100, 1032, 32), (515, 328, 64)])
 def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
     """The parity-grade precision mode (fp16x3: operands split into fp16 hi + lo, three MFMAs per product) at kernel level:
