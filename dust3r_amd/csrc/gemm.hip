@@ -19,7 +19,7 @@
 // Block -> tile map: XCD-aware (each XCD owns a contiguous range of tile ids) and panel-rasterised (8 n-tiles wide)
 // so the tiles an XCD works on concurrently share A rows and W rows inside its 4 MiB L2.
 // Precision modes share the tiles, the LDS image and the epilogues (common.hpp, Traits<DT>): one 16-bit or exact-f32 MFMA per product;
-// split-fp16 (hi + lo rows, three f16 MFMAs per product); fp16 + fp8 rows (the default engine's transformer-block linears: 128-byte K
+// split-fp16 (hi + lo rows, three f16 MFMAs per product: the default engine); fp16 + fp8 rows (opt-in engines' transformer-block linears: 128-byte K
 // steps alternate between the fp16 half and the e4m3 half of a 256-byte super-group -- two f16 MFMAs, then ONE 16x16x128 fp8 MFMA that
 // adds both cross terms, its E8M0 scale undoing the 2^17 of the encodings; DMA row addresses as one 32-bit offset per operand plus
 // scalar strides, DMA pieces interleaved with the MFMA rows on the 256-wide tiles).

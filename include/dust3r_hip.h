@@ -173,8 +173,8 @@ size_t d3r_model_device_bytes(const d3r_model* m);
  * kind 0..7 = gemm_kernel launches of tile configuration `kind` on nn.Linear operands (0 = 128x128, 1 = 256x256,
  * 2 = 256x128, 3 = 512x128, 4 = 256x128 4-wave, 5 = 256x256 4-stage), 8..15 = the same configurations on implicit-GEMM
  * convolution operands, 16 = attention_kernel, 17 = all other kernels, 18 / 19 = tile configuration 8 (64x64, the small-batch
- * forwards of a split-fp16 engine) on nn.Linear / convolution operands, 24..31 = gemm_kernel launches on fp16 + fp8 operand rows
- * (D3R_DTYPE_F16F8 engines: the transformer blocks' linears) by tile configuration.
+ * forwards of a split-fp16 engine) on nn.Linear / convolution operands, 21 = tile configuration 9 (M 384 x N 192, split-fp16 nn.Linear), 24..31 = gemm_kernel
+ * launches on fp16 + fp8 operand rows (D3R_DTYPE_F16F8 / _F16X2F8 engines: the transformer blocks' linears) by tile configuration.
  * Profiling adds event overhead: never enable it inside a timed region. */
 #define D3R_MODEL_OPT_PROFILE 1
 #define D3R_MODEL_OPT_TWO_STREAMS 2 /* 1 (default): decoder side 2 and head 2 run on an engine-owned second HIP stream, joined back
@@ -182,6 +182,8 @@ size_t d3r_model_device_bytes(const d3r_model* m);
 #define D3R_MODEL_OPT_GRAPH_MAX_PAIRS 3 /* n > 0: whole forwards (d3r_model_forward / _mixed / _packed) of at most n pairs are replayed as a hipGraph
                                          * from the third call with the same (B, image sizes, output layout) on: ~700 launches become one
                                          * graph launch + input / output copies through engine-owned staging buffers (bit-identical results).
+                                         * The D3R_* environment probes that change the launch plan (D3R_GEMM_*, D3R_HEAD_FUSE, D3R_ATTN_*) are read when a graph is CAPTURED: set them before
+                                         * the first captured call (a captured graph replays the plan it was captured with).
                                          * DEFAULT 0 = off (or D3R_GRAPH_MAX_PAIRS at create): measured on MI355X, one 512x384 pair per call
                                          * took 14.83 ms replayed vs 14.86 ms eager (before the small-problem GEMM tile: 10.4 ms now) -- the one-pair forward is bound by the dependent chain of
                                          * ~700 partially filled kernels on the GPU, not by the host's launch rate (profiles/r03_a/latency.log);
