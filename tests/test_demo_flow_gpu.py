@@ -114,3 +114,31 @@ def test_demo_body_mixed_portrait_and_landscape(gpu, tmp_path):
                                    scenegraph_type='complete')
     assert isinstance(loss, float) and [p.shape[:2] for p in out['pts3d']] == [(64, 96), (96, 64), (64, 96)]
     assert isinstance(out['output']['pred1']['pts3d'], list) and all(torch.isfinite(t).all() for t in out['output']['pred1']['pts3d'])
+
+
+def test_validate_checkpoint_tool_on_a_synthetic_checkpoint(gpu, tmp_path):
+    """tools/validate_checkpoint.py -- the one-command engine-vs-oracle harness for the day a real checkpoint is at hand -- run end to end on a
+    checkpoint FILE in the reference's format ({'args': Namespace(model="AsymmetricCroCo3DStereo(...)"), 'model': state_dict}, dust3r/model.py:27-43)
+    written from the seeded tiny DPT model: both loads report no missing / unexpected keys, every requested precision passes the 1e-3 bar
+    (exit code 0). (The --align legs need weights that produce a scene.)"""
+    import argparse
+    import subprocess
+    import sys
+    import torch
+    from dust3r_amd.synthetic import MODEL_CONFIGS
+    from oracle.dust3r_ref import build_ref_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = MODEL_CONFIGS['tiny_dpt']
+    oracle = build_ref_model('tiny_dpt')
+    state = {k: v for k, v in oracle.state_dict().items() if not k.startswith('dec_blocks2')}      # released checkpoints carry dec_blocks2 too; the loader duplicates when absent
+    model_str = ("AsymmetricCroCo3DStereo(pos_embed='RoPE100', patch_embed_cls='ManyAR_PatchEmbed', img_size=(64, 64), head_type='dpt', output_mode='pts3d', "
+                 "depth_mode=('exp', -inf, inf), conf_mode=('exp', 1, inf), enc_embed_dim=%d, enc_depth=%d, enc_num_heads=%d, dec_embed_dim=%d, dec_depth=%d, dec_num_heads=%d)"
+                 % (cfg['enc_embed_dim'], cfg['enc_depth'], cfg['enc_num_heads'], cfg['dec_embed_dim'], cfg['dec_depth'], cfg['dec_num_heads']))
+    path = str(tmp_path / 'tiny_dpt.pth')
+    torch.save({'args': argparse.Namespace(model=model_str), 'model': state}, path)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'validate_checkpoint.py'), path, '--size', '96x64', '--pairs', '2', '--precision', 'fp16x3,fp32'],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert 'missing keys [] (0), unexpected [] (0)' in r.stdout
+    assert r.stdout.count('[PASS at 1e-3]') == 2

@@ -98,7 +98,8 @@ def main():
         verdict = 'PASS' if s['max'] <= 1e-3 else 'FAIL'
         ok = ok and s['max'] <= 1e-3
         print(f'engine {prec:7s} vs oracle: pointmap rel err max {s["max"]:.3e}  p99.99 {s["p9999"]:.3e}  p99 {s["p99"]:.3e}  mean {s["mean"]:.3e};  conf rel err max {cerr:.3e}   [{verdict} at 1e-3]')
-    if a.align:
+    if a.align:       # needs weights that produce a scene (a real checkpoint): the MST / focal initialisation of a random network's output ends in NaN
+      try:
         from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
         from dust3r_amd.image_pairs import make_pairs
         from dust3r_amd.inference import inference
@@ -118,6 +119,8 @@ def main():
         scene.load_state_dict(init)
         loss = scene.compute_global_alignment(init=None, niter=300, schedule='cosine', lr=0.01)
         print(f'aligner: oracle loss after 30 of 300 iterations {ref_losses[-1]:.6f} (first {ref_losses[0]:.6f}); engine first-iteration loss {hist[0]:.6f}, after 300 iterations {loss:.6f}')
+      except Exception as e:      # the forward verdict above stands on its own
+        print(f'aligner: leg failed: {e!r}')
     sys.exit(0 if ok else 1)
 
 
