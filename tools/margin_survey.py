@@ -29,7 +29,7 @@ for seed in range(n_seeds):
     r1, r2 = m(v1, v2)
     ref = torch.cat((r1['pts3d'], r2['pts3d_in_other_view'])).clone()
     nrm = ref.norm(dim=-1).clamp_min(1e-12)
-    for prec in ('fp16f8', 'fp16x3'):
+    for prec in ('fp16f8', 'fp16x2f8', 'fp16x3'):
         m.set_precision(prec)
         e1, e2 = m(v1, v2)
         got = torch.cat((e1['pts3d'], e2['pts3d_in_other_view']))
