@@ -428,3 +428,21 @@ def test_2p5_unit_weight_rows_host_packer_against_the_emulation():
             assert torch.equal(hi, wh[:, k0:k0 + 64]) and torch.equal(lo, wl[:, k0:k0 + 64].float().half().double())
         h8 = blk[:, b, 512:640].contiguous().view(torch.float8_e4m3fn).double()
         assert torch.equal(h8, e4m3(wh[:, b * 128:(b + 1) * 128] * W_SHIFT))
+
+
+def test_bench_emits_strictly_valid_json(capsys):
+    """bench.py prints ONE line that every JSON parser accepts: non-finite floats (a NaN loss of a degenerate alignment, an infinite bound) become null."""
+    import json
+    import bench
+    bench.emit({'value': 1.5, 'stages': {'final_loss': float('nan'), 'bound': float('inf'), 'list': [1, float('-inf'), 'x']}, 'ok': True, 'none': None})
+    line = capsys.readouterr().out.strip()
+    assert '\n' not in line and 'NaN' not in line and 'Infinity' not in line
+    d = json.loads(line)
+    assert d == {'value': 1.5, 'stages': {'final_loss': None, 'bound': None, 'list': [1, None, 'x']}, 'ok': True, 'none': None}
+
+
+def test_bench_workload_flop_accounting_matches_the_survey():
+    """1856.8 GFLOP per 512x384 DPT pair = 2 x 523.0 (encoder) + 2 x 218.6 (decoder) + 2 x 186.7 (DPT head); the encode-once workloads of
+    bench.py count executed flops with the same constants."""
+    import bench
+    assert abs(2 * bench.ENC_GFLOP_PER_IMAGE + bench.DEC_HEAD_GFLOP_PER_PAIR - bench.GFLOP_PER_PAIR) < 0.5
