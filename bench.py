@@ -131,10 +131,11 @@ def read_launch_table(model):
 
 
 def pmc_digest(precision=None):
-    """The committed digest of the rocprofv3 PMC passes for this precision: profiles/pmc_<precision>.json, else profiles/pmc_latest.json
-    when it was taken in that precision (written by tools/summarize_prof.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of
-    this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). Returns (dict, repo-relative path) or (None, None)."""
-    for name in ([f'pmc_{precision}.json'] if precision else []) + ['pmc_latest.json']:
+    """The committed digest of the rocprofv3 PMC passes for this precision: profiles/pmc_latest.json (the digest of the LAST visit that ran
+    the counter passes, copied there by tools/visit.sh) when it was taken in that precision, else profiles/pmc_<precision>.json (written by
+    tools/summarize_prof.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950). Returns (dict, repo-relative path) or (None, None)."""
+    for name in ['pmc_latest.json'] + ([f'pmc_{precision}.json'] if precision else []):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 d = json.load(f)
@@ -363,7 +364,7 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
     the heads write the packed (pairs, H, W, 8) payload in place), ONE all-gather; c5 then aligns the gathered predictions on rank 0
     (global_aligner + init='mst' + 300 cosine iterations, dust3r/demo.py:158-178). Images are resident in HBM before the timed region."""
     from dust3r_amd.image_pairs import make_pairs
-    from dust3r_amd.parallel import _local_same_size, all_gather_packed, shard_bounds, unpack_predictions
+    from dust3r_amd.parallel import _local_same_size, all_gather_packed, shard_plan, unpack_predictions
     from dust3r_amd.synthetic import synthetic_image_list
     c5 = args.workload == 'c5'
     n_views, graph, sym = (100, 'swin-3', True) if c5 else (20, 'complete', False)
@@ -372,11 +373,11 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
         v['img'] = v['img'].to(device)
     pairs = make_pairs(imgs, scene_graph=graph, prefilter=None, symmetrize=sym)
     P = len(pairs)
-    lo, hi, per = shard_bounds(P, rank, world)
-    counts = [shard_bounds(P, r, world)[1] - shard_bounds(P, r, world)[0] for r in range(world)]
-    images_per_rank = [len({int(v['idx']) for pr in pairs[shard_bounds(P, r, world)[0]:shard_bounds(P, r, world)[1]] for v in pr}) for r in range(world)]
-    log(f'[bench] rank {rank}: {args.workload}: {P} pairs over {n_views} views, shard [{lo}, {hi}) = {hi - lo} pairs touching {images_per_rank[rank]} distinct images')
-    keep = torch.cat([torch.arange(r * per, r * per + counts[r]) for r in range(world)]).to(device)
+    plan = shard_plan(pairs, world, encode_once=True)        # dust3r_amd.parallel: which pairs each rank runs (cost-balanced, same on every rank)
+    per, counts, images_per_rank = plan.per, plan.counts, plan.images
+    my_pairs = [pairs[k] for k in plan.shard(rank)]
+    log(f'[bench] rank {rank}: {args.workload}: {P} pairs over {n_views} views, shard of {len(my_pairs)} pairs touching {images_per_rank[rank]} distinct images ({plan.name})')
+    keep = plan.source.to(device)
     gathered = torch.empty((world * per, H, W, 8), dtype=torch.float32, device=device) if world > 1 else None
     scene_out = None
     if c5 and rank == 0:
@@ -392,7 +393,7 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
     stage = {}
 
     def step():
-        local = _local_same_size(pairs, lo, hi, per, model, device, args.pairs, device, True, H, W)
+        local = _local_same_size(my_pairs, per, model, device, args.pairs, device, True, H, W)
         if world > 1:
             all_gather_packed(local, out=gathered)
             allp = gathered
@@ -434,17 +435,19 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    who = rank_table(world, rank, device, len(my_pairs))
     if rank != 0:
         return None
     sec = dt / args.steps
     gflop = n_views * ENC_GFLOP_PER_IMAGE + P * DEC_HEAD_GFLOP_PER_PAIR if world == 1 else sum(images_per_rank) * ENC_GFLOP_PER_IMAGE + P * DEC_HEAD_GFLOP_PER_PAIR
     selftest = ' (SELF-TEST: all ranks on one device, backend ' + backend + ' -- not a scaling measurement)' if one_device and world > 1 else ''
-    common = dict(n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=sec * 1e3, scaling='strong', vs_baseline=None, dtype=args.precision,
+    common = dict(n_gpus=world, rccl_world_size=who['rccl_world_size'], collective_backend=who['backend'], distinct_devices=who['distinct_devices'], ranks=who['ranks'], steps=args.steps, warmup=args.warmup, ms_per_step=sec * 1e3, scaling='strong', vs_baseline=None, dtype=args.precision,
                   data='synthetic' + selftest)
-    cfg = {'workload': f'{MODEL}, {n_views} synthetic 512x384 views -> make_pairs({graph!r}, symmetrize={sym}) = {P} pairs (BASELINE configs[{4 if c5 else 2}]), contiguous shards of '
-                       f'{per} pairs per rank, each distinct image of a shard encoded once, ONE all-gather of the packed predictions per job'
+    cfg = {'workload': f'{MODEL}, {n_views} synthetic 512x384 views -> make_pairs({graph!r}, symmetrize={sym}) = {P} pairs (BASELINE configs[{4 if c5 else 2}]), cost-balanced shards (dust3r_amd.parallel.shard_plan: <= '
+                       f'{per} pairs per rank), each distinct image of a shard encoded once, ONE all-gather of the packed predictions per job'
                        + ('; then global_aligner(PointCloudOptimizer) + init=mst + 300 cosine Adam iterations on rank 0 (on a consistent synthetic scene of the same shape)' if c5 else '') + '; random-init weights, images resident in HBM',
-           'pairs': P, 'views': n_views, 'pairs_per_rank': counts, 'distinct_images_per_rank': images_per_rank, 'pairs_per_engine_call': args.pairs,
+           'pairs': P, 'views': n_views, 'pairs_per_rank': counts, 'distinct_images_per_rank': images_per_rank,
+           'distinct_images_per_rank_max_min': [max(images_per_rank), min(images_per_rank)], 'shard_plan': plan.summary(), 'pairs_per_engine_call': args.pairs,
            'parallelism': f'pair-sharded dp{world}'}
     if not c5:
         result = dict(metric='image_pairs_per_sec_forward_512x384_190_pairs_sharded', value=P / sec, unit='pairs/s', higher_is_better=True, config=cfg,
@@ -487,6 +490,43 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
     return result
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no torchrun around it (WORLD_SIZE unset): re-exec this command under torch.distributed.run, one rank
+    per GPU of this node, rendezvous on 127.0.0.1 -- the same launch line the driver uses for N > 1. Does not return."""
+    import socket
+    n_dev = torch.cuda.device_count()
+    if os.environ.get('D3R_BENCH_ONE_DEVICE') != '1' and n_dev < args.gpus:
+        log(f'[bench] --gpus {args.gpus} but this node exposes {n_dev} GPU(s): one rank per GPU is the contract (D3R_BENCH_ONE_DEVICE=1 + D3R_BENCH_BACKEND=gloo '
+            'runs every rank on cuda:0 as a self-test of the code path)')
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), D3R_BENCH_SELF_LAUNCHED='1')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    log('[bench] WORLD_SIZE unset: launching ' + ' '.join(cmd))
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
+def rank_table(world, rank, device, units):
+    """What actually ran: one row per rank (device index, device name, PCI bus id when torch exposes it, units of work per step), gathered
+    over the process group, and the world size the COLLECTIVE LIBRARY reports (dist.get_world_size(), not the --gpus argument)."""
+    prop = torch.cuda.get_device_properties(device)
+    row = dict(rank=rank, device=str(device), name=prop.name, gcn_arch=getattr(prop, 'gcnArchName', None), pci_bus_id=getattr(prop, 'pci_bus_id', None),
+               uuid=str(getattr(prop, 'uuid', '')) or None, pairs_per_step=units, host=os.uname().nodename, pid=os.getpid())
+    if world > 1 and dist.is_initialized():
+        rows = [None] * world
+        dist.all_gather_object(rows, row)
+        return dict(rccl_world_size=dist.get_world_size(), backend=dist.get_backend(), ranks=rows,
+                    distinct_devices=len({(r['host'], r['device'], r.get('uuid') or r.get('pci_bus_id')) for r in rows}))
+    return dict(rccl_world_size=dist.get_world_size() if dist.is_initialized() else 1, backend=dist.get_backend() if dist.is_initialized() else None,
+                ranks=[row], distinct_devices=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -504,13 +544,16 @@ def main():
     ap.add_argument('--single-stream', action='store_true', help='keep decoder side 2 / head 2 on the main stream (serialised kernels: use under rocprofv3 so that per-kernel durations are not inflated by overlap)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args)                     # bare `python bench.py --gpus N`: becomes N ranks under torch.distributed.run
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    assert world == args.gpus or world == 1 and args.gpus == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    if world != args.gpus:                    # an external launcher decides how many ranks exist; the line reports what ran (n_gpus = WORLD_SIZE)
+        log(f'[bench] note: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s): running and reporting {world}')
     # D3R_BENCH_ONE_DEVICE=1: every rank on cuda:0 (self-test of the N > 1 code path on a one-GPU box; RCCL refuses two ranks on one
     # device, so pair it with D3R_BENCH_BACKEND=gloo -- the collective then stages through the host: NOT a measurement of anything)
     one_device = os.environ.get('D3R_BENCH_ONE_DEVICE') == '1'
@@ -593,13 +636,15 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    who = rank_table(world, rank, device, B)
 
     result = None
     if rank == 0:
         pairs_total = world * B * args.steps
         value = pairs_total / dt
         result = {
-            'metric': 'image_pairs_per_sec_forward_512x384', 'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'metric': 'image_pairs_per_sec_forward_512x384', 'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'rccl_world_size': who['rccl_world_size'],
+            'collective_backend': who['backend'], 'distinct_devices': who['distinct_devices'], 'ranks': who['ranks'], 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.precision, 'data': 'synthetic' + (' (SELF-TEST: all ranks on one device, backend ' + backend + ' -- not a scaling measurement)' if one_device and world > 1 else ''),
             'config': {'workload': f'{MODEL} AsymmetricCroCo3DStereo.forward, {B} synthetic 512x384 pairs per GPU per step (BASELINE configs[1]), '

@@ -11,6 +11,11 @@ are collected with a single `all_gather_into_tensor` -- RCCL over xGMI on the GP
 Every rank encodes only the distinct images its own shard touches (encode-once, like single-device `inference()`), and pair lists of
 several image sizes shard too (flat padded payload). Nothing here depends on the device type: the gloo tests drive the same code with
 a stand-in model.
+
+Which pairs a rank runs is decided by `shard_plan` (round 5): the pair list is put in an order that keeps the pairs of an image together
+(the reference's windowed graphs come out of a `set`, image_pairs.py:17-33, i.e. in hash order: a contiguous slice of THAT list touches
+almost every image), then cut where max over ranks of (encoder passes + decoder/head passes) is smallest. The gathered rows are put back
+in the caller's order by the same index_select that used to drop the padding rows, so the result is unchanged: still ONE collective.
 """
 import torch
 import torch.distributed as dist
@@ -23,6 +28,113 @@ def shard_bounds(n_items, rank, world_size):
     per = (n_items + world_size - 1) // world_size
     lo = min(rank * per, n_items)
     return lo, min(lo + per, n_items), per
+
+
+# SURVEY.md 8(d), GFLOP at 512x384: one encoder pass per distinct image of a shard, both decoders + both DPT heads per pair. Only the RATIO
+# matters to the plan (it scales with the pixel count on both sides).
+ENC_COST_PER_IMAGE = 523.0
+DEC_COST_PER_PAIR = 2 * 218.6 + 2 * 186.7
+
+
+def _morton(a, b):
+    z = 0
+    for k in range(20):
+        z |= ((a >> k) & 1) << (2 * k + 1) | ((b >> k) & 1) << (2 * k)
+    return z
+
+
+class ShardPlan:
+    """order: pair indices in the order the ranks' shards concatenate; bounds[r] = (lo, hi) into `order`; per = rows of the all-gather
+    payload per rank (the longest shard; shorter ones are zero padded); source[k] = row of the gathered (world * per) payload that holds
+    pair k of the caller's list; cost[r] = modelled GFLOP of rank r; images[r] = distinct images rank r encodes."""
+
+    def __init__(self, order, bounds, cost, images, name):
+        self.order, self.bounds, self.cost, self.images, self.name = order, bounds, cost, images, name
+        self.world = len(bounds)
+        self.per = max([hi - lo for lo, hi in bounds] + [0])
+        self.counts = [hi - lo for lo, hi in bounds]
+        src = [0] * len(order)
+        for r, (lo, hi) in enumerate(bounds):
+            for t in range(lo, hi):
+                src[order[t]] = r * self.per + (t - lo)
+        self.source = torch.tensor(src, dtype=torch.long)
+
+    def shard(self, rank):
+        lo, hi = self.bounds[rank]
+        return self.order[lo:hi]
+
+    def summary(self):
+        return dict(order=self.name, pairs_per_rank=self.counts, distinct_images_per_rank=self.images, modelled_gflop_per_rank=[round(c, 1) for c in self.cost],
+                    imbalance_max_over_mean=(max(self.cost) / (sum(self.cost) / len(self.cost)) if sum(self.cost) > 0 else 1.0))
+
+
+def _balanced_cuts(order, edges, area, world, enc_cost):
+    """Contiguous cuts of `order` into <= world shards minimising max over shards of enc_cost * (area-weighted distinct images) + pair
+    cost: bisection on the bound, greedy feasibility (a shard's cost only grows when it is extended, so the greedy sweep is exact)."""
+    P = len(order)
+    pair_cost = [DEC_COST_PER_PAIR * 0.5 * (area[edges[k][0]] + area[edges[k][1]]) for k in order]
+
+    def sweep(bound):
+        cuts, lo = [], 0
+        while lo < P:
+            if len(cuts) == world:
+                return None
+            seen, c, hi = set(), 0.0, lo
+            while hi < P:
+                add = pair_cost[hi] + sum(enc_cost * area[v] for v in set(edges[order[hi]]) if v not in seen)
+                if c + add > bound:
+                    break
+                seen.update(edges[order[hi]])
+                c += add
+                hi += 1
+            if hi == lo:
+                return None
+            cuts.append((lo, hi, c, len(seen)))
+            lo = hi
+        return cuts
+
+    total = sum(pair_cost) + enc_cost * sum(area[v] for v in {v for e in edges for v in e})
+    lo_b, hi_b = 0.0, total * (1 + 1e-9) + 1e-9
+    for _ in range(48):
+        mid = 0.5 * (lo_b + hi_b)
+        if sweep(mid) is None:
+            lo_b = mid
+        else:
+            hi_b = mid
+    cuts = sweep(hi_b)
+    cuts += [(P, P, 0.0, 0)] * (world - len(cuts))
+    return cuts
+
+
+def shard_plan(pairs, world, encode_once=True):
+    """The assignment of pairs to ranks (same on every rank: a pure function of the pair list's image indices and sizes).
+    Candidates: the caller's order, pairs sorted by (smaller image index, larger image index) -- (i, j) next to (j, i), an image's
+    window together -- and the Z-order curve over (larger, smaller) index (runs of it are square blocks of a dense graph's adjacency
+    matrix: ~2 sqrt(pairs) images per shard instead of a whole row). Each is cut by `_balanced_cuts`; the smallest maximum wins."""
+    edges = [(int(a['idx']), int(b['idx'])) for a, b in pairs]
+    P = len(edges)
+    area = {}
+    for (a, b), (i, j) in zip(pairs, edges):
+        for v, k in ((a, i), (b, j)):
+            if k not in area:
+                img = v.get('img') if isinstance(v, dict) else None
+                area[k] = float(img.shape[-2] * img.shape[-1]) if img is not None else 1.0
+    if area:
+        ref_area = max(area.values())
+        area = {k: a / ref_area for k, a in area.items()}
+    enc_cost = ENC_COST_PER_IMAGE if encode_once else 0.0
+    cands = [('list order', list(range(P)))]
+    if encode_once and world > 1:
+        cands.append(('sorted by (min, max) image index', sorted(range(P), key=lambda k: (min(edges[k]), max(edges[k]), k))))
+        cands.append(('Z-order over (max, min) image index', sorted(range(P), key=lambda k: (_morton(max(edges[k]), min(edges[k])), k))))
+    best = None
+    for name, order in cands:
+        cuts = _balanced_cuts(order, edges, area, world, enc_cost)
+        worst = max(c[2] for c in cuts) if cuts else 0.0
+        if best is None or worst < best[0] * (1 - 1e-12):
+            best = (worst, name, order, cuts)
+    _, name, order, cuts = best
+    return ShardPlan(order, [(lo, hi) for lo, hi, _, _ in cuts], [c for _, _, c, _ in cuts], [n for _, _, _, n in cuts], name)
 
 
 def pack_predictions(pred1, pred2):
@@ -67,11 +179,10 @@ def _unflatten_row(row, hw1, hw2):
             dict(pts3d_in_other_view=row[o[2]:o[3]].reshape(1, *hw2, 3).clone(), conf=row[o[3]:o[4]].reshape(1, *hw2).clone()))
 
 
-def _local_same_size(pairs, lo, hi, per, model, device, batch_size, gather_device, encode_once, H, W):
-    """This rank's shard of a one-size pair list -> (per, H, W, 8) packed payload (zero in the padding slots)."""
+def _local_same_size(shard, per, model, device, batch_size, gather_device, encode_once, H, W):
+    """This rank's shard (a list of pairs) of a one-size pair list -> (per, H, W, 8) packed payload (zero in the padding slots)."""
     from .inference import _encode_once_ok, loss_of_one_batch
     local = torch.zeros((per, H, W, 8), dtype=torch.float32, device=gather_device)
-    shard = pairs[lo:hi]
     if not shard:
         return local
     if encode_once and _encode_once_ok(shard, model):
@@ -110,13 +221,13 @@ def _local_same_size(pairs, lo, hi, per, model, device, batch_size, gather_devic
     return local
 
 
-def _local_mixed(pairs, shapes, lo, hi, per, slot, model, device, batch_size, gather_device):
+def _local_mixed(pairs, shapes, mine, per, slot, model, device, batch_size, gather_device):
     """This rank's shard of a pair list with SEVERAL image sizes -> (per, slot) flat payload: the shard's pairs are grouped by their two
     image sizes and every group is batched (dust3r_amd.inference does the same on one device); slot = the longest pair of the WHOLE list."""
     from .inference import loss_of_one_batch
     local = torch.zeros((per, slot), dtype=torch.float32, device=gather_device)
-    groups = {}
-    for k in range(lo, hi):
+    groups, row_of = {}, {k: t for t, k in enumerate(mine)}
+    for k in mine:
         groups.setdefault(shapes[k], []).append(k)
     for (hw1, hw2), members in groups.items():
         L = _flat_len(hw1, hw2)
@@ -124,7 +235,7 @@ def _local_mixed(pairs, shapes, lo, hi, per, slot, model, device, batch_size, ga
             chunk = members[i:i + batch_size]
             res = loss_of_one_batch(collate_with_cat([pairs[k] for k in chunk]), model, None, device)
             rows = _flatten_rows(res['pred1'], res['pred2'], len(chunk)).to(gather_device)
-            local[torch.tensor([k - lo for k in chunk], device=gather_device), :L] = rows
+            local[torch.tensor([row_of[k] for k in chunk], device=gather_device), :L] = rows
     return local
 
 
@@ -140,15 +251,18 @@ def inference_sharded(pairs, model, device, batch_size=8, verbose=False, group=N
         result has the reference's list-per-pair structure, exactly as `inference()` returns it for such a list."""
     from .inference import _engine_step, check_if_same_size
     from .utils.device import to_cpu
+    from .inference import _encode_once_ok
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    lo, hi, per = shard_bounds(len(pairs), rank, world)
     batch_size = _engine_step(model, batch_size, engine_batch)     # at least the engine's preferred pairs per call (bit-identical results)
     gather_device = torch.device(gather_device if gather_device is not None else device)
-    counts = [shard_bounds(len(pairs), r, world)[1] - shard_bounds(len(pairs), r, world)[0] for r in range(world)]
-    keep = torch.cat([torch.arange(r * per, r * per + counts[r]) for r in range(world)])      # drops the padding slots of the short last shards
-    if check_if_same_size(pairs):
+    same = check_if_same_size(pairs)
+    enc1 = (encode_once is None or bool(encode_once)) and same and len(pairs) > 0 and _encode_once_ok(pairs, model)
+    plan = shard_plan(pairs, world, encode_once=enc1)
+    mine, per = plan.shard(rank), plan.per
+    keep = plan.source                                             # caller's order <- gathered rows (also drops the padding rows of short shards)
+    if same:
         H, W = pairs[0][0]['img'].shape[-2:]
-        local = _local_same_size(pairs, lo, hi, per, model, device, batch_size, gather_device, encode_once is None or bool(encode_once), H, W)
+        local = _local_same_size([pairs[k] for k in mine], per, model, device, batch_size, gather_device, enc1, H, W)
         gathered = all_gather_packed(local, group)
         pred1, pred2 = unpack_predictions(gathered.index_select(0, keep.to(gathered.device)).cpu())
         # view metadata is rebuilt deterministically on every rank (host side), as SURVEY.md 8(e) prescribes
@@ -158,7 +272,7 @@ def inference_sharded(pairs, model, device, batch_size=8, verbose=False, group=N
         return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)
     shapes = _pair_shapes(pairs)
     slot = max(_flat_len(*s) for s in shapes)
-    local = _local_mixed(pairs, shapes, lo, hi, per, slot, model, device, batch_size, gather_device)
+    local = _local_mixed(pairs, shapes, mine, per, slot, model, device, batch_size, gather_device)
     gathered = all_gather_packed(local, group).index_select(0, keep.to(gather_device)).cpu()
     result = []
     for k, (a, b) in enumerate(pairs):

@@ -87,10 +87,11 @@ def _worker(rank, world, port, n_views, outdir, H=16, W=32, mode='plain'):
         out = inference_sharded(pairs, model, 'cpu', batch_size=2)
         if mode == 'encode_once':
             # a rank encodes the distinct images of ITS shard once: fewer encoder passes than its 2 x (pairs in the shard) view slots
-            from dust3r_amd.parallel import shard_bounds
-            lo, hi, _ = shard_bounds(len(pairs), rank, world)
-            touched = {int(v['idx']) for p in pairs[lo:hi] for v in p}
-            assert model.encoded == len(touched) < 2 * (hi - lo), (model.encoded, len(touched), hi - lo)
+            from dust3r_amd.parallel import shard_plan
+            plan = shard_plan(pairs, world, encode_once=True)
+            mine = plan.shard(rank)
+            touched = {int(v['idx']) for k in mine for v in pairs[k]}
+            assert model.encoded == len(touched) == plan.images[rank] < 2 * len(mine), (model.encoded, len(touched), len(mine))
         torch.save((rank, out['pred1']['pts3d'], out['pred1']['conf'], out['pred2']['pts3d_in_other_view'], out['pred2']['conf'],
                     out['view1']['idx'], out['view2']['idx']), os.path.join(outdir, f'rank{rank}.pt'))
         dist.barrier()
@@ -180,3 +181,46 @@ def test_shard_bounds_cover_everything_once():
                 assert hi - lo <= per
                 seen += list(range(lo, hi))
             assert seen == list(range(n))
+
+
+def _index_views(n, area=None):
+    return [dict(idx=i, instance=str(i)) for i in range(n)]
+
+
+@pytest.mark.parametrize('n_views,graph,sym', [(20, 'complete', False), (20, 'complete', True), (100, 'swin-3', True), (100, 'logwin-3', True), (7, 'oneref-2', True), (2, 'complete', False)])
+def test_shard_plan_covers_every_pair_once_and_beats_contiguous_slices(n_views, graph, sym):
+    """shard_plan (round 5): every pair on exactly one rank, `source` maps the gathered rows back to the caller's order, the plan is
+    never worse than the plain contiguous ceil(P / N) slices under its own cost model (encoder pass per distinct image + decoder/head
+    pass per pair) -- and for the windowed graphs, whose pair list comes out of a set in hash order, much better."""
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.parallel import DEC_COST_PER_PAIR, ENC_COST_PER_IMAGE, shard_bounds, shard_plan
+    pairs = make_pairs(_index_views(n_views), graph, None, symmetrize=sym)
+    P = len(pairs)
+    for world in (1, 2, 3, 4, 8):
+        plan = shard_plan(pairs, world, encode_once=True)
+        assert sorted(k for r in range(world) for k in plan.shard(r)) == list(range(P))
+        assert len(plan.bounds) == world and plan.per == max(plan.counts)
+        rows = torch.full((world * max(plan.per, 1),), -1, dtype=torch.long)      # what the all-gather delivers: rank r's rows at r * per
+        for r in range(world):
+            mine = plan.shard(r)
+            rows[r * plan.per:r * plan.per + len(mine)] = torch.tensor(mine, dtype=torch.long)
+            assert plan.images[r] == len({int(v['idx']) for k in mine for v in pairs[k]})
+            assert abs(plan.cost[r] - (ENC_COST_PER_IMAGE * plan.images[r] + DEC_COST_PER_PAIR * len(mine))) < 1e-6
+        assert rows.index_select(0, plan.source).tolist() == list(range(P))
+        contiguous = []
+        for r in range(world):
+            lo, hi, _ = shard_bounds(P, r, world)
+            contiguous.append(ENC_COST_PER_IMAGE * len({int(v['idx']) for p in pairs[lo:hi] for v in p}) + DEC_COST_PER_PAIR * (hi - lo))
+        assert max(plan.cost) <= max(contiguous) * (1 + 1e-9)
+        if graph.startswith(('swin', 'logwin')) and world == 8:
+            assert max(plan.cost) < 0.7 * max(contiguous)         # 600 hash-ordered pairs: a contiguous slice touches ~3x the images it needs
+    # pair-by-pair engines (no encode-once): equal pair counts in list order
+    plan = shard_plan(pairs, 4, encode_once=False)
+    assert plan.name == 'list order' and max(plan.counts) == -(-P // 4) and plan.order == list(range(P))
+
+
+def test_shard_plan_weights_mixed_image_sizes_by_area():
+    from dust3r_amd.parallel import shard_plan
+    pairs = _mixed_pairs()
+    plan = shard_plan(pairs, 3, encode_once=False)
+    assert sorted(k for r in range(3) for k in plan.shard(r)) == list(range(len(pairs))) and max(plan.cost) / min(plan.cost) < 1.35

@@ -214,19 +214,28 @@ def test_bench_multi_rank_branches_on_one_device(gpu, workload, tmp_path):
         port = sk.getsockname()[1]
     env = dict(os.environ, D3R_BENCH_ONE_DEVICE='1', D3R_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     extra = ['--pairs', '4'] if workload == 'c2' else []
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--workload', workload, '--no-cpu-baseline', '--no-fast', '--no-profile',
-           '--no-aligner'] + extra
+    tail = ['--gpus', '2', '--steps', '1', '--warmup', '1', '--workload', workload, '--no-cpu-baseline', '--no-fast', '--no-profile', '--no-aligner'] + extra
+    if workload == 'c2':
+        # the BARE command, as the driver writes its N = 1 line (no torchrun around it, WORLD_SIZE unset): bench.py launches its own ranks
+        env.pop('WORLD_SIZE', None), env.pop('RANK', None), env.pop('LOCAL_RANK', None)
+        cmd = [sys.executable, os.path.join(root, 'bench.py')] + tail
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+               os.path.join(root, 'bench.py')] + tail
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['value'] > 0 and 'SELF-TEST' in d['data'] and d['config']['workload']
+    # what ran, as the collective library saw it: two ranks (here on one device, which the line admits)
+    assert d['rccl_world_size'] == 2 and d['collective_backend'] == 'gloo' and [r['rank'] for r in d['ranks']] == [0, 1] and d['distinct_devices'] == 1
+    assert all(r['pairs_per_step'] > 0 and r['name'] for r in d['ranks'])
     pc = d['parity_check']
     assert all(v['pass'] for v in pc.values()), pc
     if workload != 'c2':
         assert sum(d['config']['pairs_per_rank']) == d['config']['pairs'] and d['scaling'] == 'strong'
+        assert d['config']['shard_plan']['imbalance_max_over_mean'] < 1.05 and len(d['config']['distinct_images_per_rank']) == 2
     if workload == 'c5':
         assert d['stages']['poses_finite'] and d['stages']['final_loss'] < 0.05 and d['stages']['gathered_predictions_finite']
     out_dir = os.path.join(root, 'gpurun_out')
