@@ -123,11 +123,23 @@ for name in names:
     if mm:
         cfg = CFG_OF.get(tuple(int(x) for x in mm.group(2).split(',')))
         if cfg is not None and int(mm.group(1)) == run_dt:
-            digest['gemm_cfg'][str(cfg)] = entry
+            # several instantiations share a tile-configuration id of bench.py (cfg 0 = the 128x128 tile by four waves AND by eight):
+            # dispatch-weighted mean under the id, every instantiation listed
+            prev = digest['gemm_cfg'].get(str(cfg))
+            if prev is None:
+                digest['gemm_cfg'][str(cfg)] = dict(entry, instantiations=[dict(entry)])
+            else:
+                n0, n1 = prev['dispatches'], entry['dispatches']
+                for key in ('fetch_size_kib', 'write_size_kib', 'hbm_gb_per_launch'):
+                    prev[key] = (prev[key] * n0 + entry[key] * n1) / max(n0 + n1, 1)
+                prev['dispatches'] = n0 + n1
+                prev['kernel'] = 'dispatch-weighted mean of %d instantiations' % (len(prev['instantiations']) + 1)
+                prev['instantiations'].append(dict(entry))
     elif 'aligner_main_kernel' in name:
         digest['aligner_main_kernel'] = entry
     elif 'attention_kernel<' in name or 'attention_x3_kernel<' in name:
         digest['attention_kernel'] = entry
+digest['visit'] = os.environ.get('D3R_VISIT', 'unnamed visit') + ': rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --single-stream'
 if fetch or write:
     with open(os.path.join(out, 'pmc_latest.json'), 'w') as f:
         json.dump(digest, f, indent=1)
