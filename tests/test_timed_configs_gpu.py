@@ -126,6 +126,81 @@ def test_default_mode_against_cpu_oracle_over_weight_seeds(gpu, seed):
     eng._destroy_engine()
 
 
+@pytest.fixture(scope='module')
+def c2_oracle_and_engine(gpu):
+    """ONE CPU oracle of the BASELINE model and ONE engine loaded with its weights, shared by the released-resolution cases below."""
+    from oracle import tune_threads
+    from oracle.dust3r_ref import build_ref_model_fast
+    tune_threads()
+    oracle = build_ref_model_fast(C2, seed=7)
+    eng = engine_from_oracle(oracle, C2, 'fp32', gpu)
+    yield oracle, eng
+    eng._destroy_engine()
+    torch.cuda.empty_cache()
+
+
+def _views_of(hw1, hw2, seed):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda hw, k: dict(img=torch.rand((1, 3) + hw, generator=g) * 2 - 1, true_shape=torch.tensor([hw], dtype=torch.int32), idx=[k], instance=[str(k)])   # noqa: E731
+    return mk(hw1, 0), mk(hw2, 1)
+
+
+# README.md:102-103 of the reference: the 512 checkpoints were trained at 512x384, 512x336, 512x288, 512x256, 512x160; load_images crops
+# pictures to these (utils/image.py:97-110) and a portrait picture arrives as 384x512 -> H = 512, W = 384 (model.py:142-151 runs such a
+# pair with two token grids). Token counts 768 / 672 / 576 / 512 / 320: the ragged-tile cases of the full-width model (16 / 12 heads,
+# 1024 / 768 channels) that had only ever run at kernel level and on the tiny models.
+@pytest.mark.parametrize('hw1,hw2', [((336, 512), (336, 512)), ((288, 512), (288, 512)), ((256, 512), (256, 512)), ((160, 512), (160, 512)),
+                                     ((512, 384), (384, 512)), ((384, 512), (512, 384)), ((512, 336), (288, 512))])
+def test_full_size_released_resolutions_match_oracle(gpu, c2_oracle_and_engine, hw1, hw2):
+    """DUSt3R_ViTLarge_BaseDecoder_512_dpt at every other released resolution and with a portrait image in the pair: exact-fp32 engine and the
+    default engine (fp16x3) against the CPU oracle, per-pixel max <= 1e-3 on both pointmaps (north star), confidences within 3e-3."""
+    oracle, eng = c2_oracle_and_engine
+    v1, v2 = _views_of(hw1, hw2, seed=hw1[0] * 7 + hw2[0])
+    with torch.no_grad():
+        r1, r2 = oracle(v1, v2)
+    assert r1['pts3d'].shape == (1,) + hw1 + (3,) and r2['pts3d_in_other_view'].shape == (1,) + hw2 + (3,)
+    for prec in ('fp32', 'fp16x3'):
+        eng.set_precision(prec)
+        e1, e2 = eng(v1, v2)
+        assert e1['pts3d'].shape == r1['pts3d'].shape and e2['pts3d_in_other_view'].shape == r2['pts3d_in_other_view'].shape and e2['conf'].shape == r2['conf'].shape
+        for name, a, b in (('pts1', e1['pts3d'], r1['pts3d']), ('pts2', e2['pts3d_in_other_view'], r2['pts3d_in_other_view'])):
+            st = pix_rel_stats(a, b)
+            print(f'[512_dpt {hw1[1]}x{hw1[0]} + {hw2[1]}x{hw2[0]} {prec} vs CPU oracle] {name} max {st["max"]:.3e} p99.99 {st["p9999"]:.3e} p99 {st["p99"]:.3e} mean {st["mean"]:.3e}')
+            assert st['max'] < 1e-3 and st['mean'] < 5e-5, (prec, name, st)
+        for a, b in ((e1['conf'], r1['conf']), (e2['conf'], r2['conf'])):
+            assert float(((a.cpu() - b).abs() / b).max()) < 3e-3
+    # a batch of such pairs is bit-equal to the one-pair call (the ragged token counts on the batched tiles)
+    eng.set_precision('fp16x3')
+    e1, e2 = eng(v1, v2)
+    rep = lambda v: dict(img=v['img'].repeat(3, 1, 1, 1), true_shape=v['true_shape'].repeat(3, 1), idx=v['idx'] * 3, instance=v['instance'] * 3)   # noqa: E731
+    b1, b2 = eng(rep(v1), rep(v2))
+    for k in range(3):
+        assert torch.equal(b1['pts3d'][k], e1['pts3d'][0]) and torch.equal(b2['pts3d_in_other_view'][k], e2['pts3d_in_other_view'][0]) and torch.equal(b2['conf'][k], e2['conf'][0])
+
+
+def test_full_size_224_linear_batch_of_eight_matches_oracle(gpu):
+    """configs[0]'s model, DUSt3R_ViTLarge_BaseDecoder_224_linear, EIGHT 224x224 pairs in one call (1568 encoder rows: the mid-size tiles)
+    against the CPU oracle run on the same batch: default engine and exact-fp32 engine, per-pixel max <= 1e-3."""
+    from oracle import tune_threads
+    from oracle.dust3r_ref import build_ref_model_fast
+    tune_threads()
+    cfg = 'DUSt3R_ViTLarge_BaseDecoder_224_linear'
+    oracle = build_ref_model_fast(cfg, seed=3)
+    eng = engine_from_oracle(oracle, cfg, 'fp32', gpu)
+    v1, v2 = synthetic_views(8, 224, 224, seed=8)
+    with torch.no_grad():
+        r1, r2 = oracle(v1, v2)
+    ref = torch.cat((r1['pts3d'], r2['pts3d_in_other_view']))
+    for prec in ('fp32', 'fp16x3'):
+        eng.set_precision(prec)
+        e1, e2 = eng(v1, v2)
+        st = pix_rel_stats(torch.cat((e1['pts3d'], e2['pts3d_in_other_view'])), ref)
+        print(f'[224_linear B=8 {prec} vs CPU oracle] max {st["max"]:.3e} p99.99 {st["p9999"]:.3e} mean {st["mean"]:.3e}')
+        assert st['max'] < 1e-3 and st['mean'] < 5e-5, (prec, st)
+        assert float(((torch.cat((e1['conf'], e2['conf'])).cpu() - torch.cat((r1['conf'], r2['conf']))).abs() / torch.cat((r1['conf'], r2['conf']))).max()) < 3e-3
+    eng._destroy_engine()
+
+
 def _init_rccl_world1(gpu):
     import socket
     import torch.distributed as dist
@@ -196,6 +271,45 @@ def test_c5_100_views_swin_forward_and_alignment_on_the_engine(gpu, bench_engine
     poses, focals = scene.get_im_poses(), scene.get_focals()
     assert poses.shape == (100, 4, 4) and bool(torch.isfinite(poses).all()) and bool(torch.isfinite(focals).all())
     assert loss < 0.05 and float((focals.detach().flatten().cpu() / gt['focal'] - 1).abs().max()) < 0.05
+
+
+def test_c5_alignment_consumes_the_sharded_handover_at_100_views(gpu):
+    """Engine-side pointmap format -> aligner with REAL geometry at configs[4]'s scale, without a checkpoint: the consistent 100-view /
+    600-edge scene is packed in the heads' payload format, laid out as the all-gather of an 8-rank shard plan delivers it (rank r's rows at
+    r * per, zero padding rows, the plan's pair order), brought back by inference_sharded's index_select(plan.source), unpacked by
+    unpack_predictions into the dict inference() returns, and handed to global_aligner(init='mst') + 300 iterations. The result must be
+    BIT-IDENTICAL to aligning the scene's own tensors (the route only moves values) and recover the ground-truth focals / poses."""
+    from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
+    from dust3r_amd.image_pairs import make_pairs
+    from dust3r_amd.parallel import pack_predictions, shard_plan, unpack_predictions
+    from dust3r_amd.synthetic import synthetic_scene
+    H, W, n = 384, 512, 100
+    sc, _, gt = synthetic_scene(n, H, W, seed=0, scene_graph='swin-3', symmetrize=True, noise=0.002, device=gpu, device_rng=True)
+    pairs = make_pairs([dict(idx=i, instance=str(i)) for i in range(n)], 'swin-3', None, symmetrize=True)
+    assert sc['view1']['idx'] == [a['idx'] for a, _ in pairs] and len(pairs) == 600
+
+    def align(output):
+        torch.manual_seed(0)                 # the constructor draws random pairwise poses (base_opt.py:76) before init='mst' overwrites them
+        scene = global_aligner(output, gpu, mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
+        loss = scene.compute_global_alignment(init='mst', niter=300, schedule='cosine', lr=0.01)
+        return float(loss), scene.get_im_poses().detach().clone(), scene.get_focals().detach().clone(), scene.get_pw_poses().detach().clone()
+
+    want = align(sc)
+    plan = shard_plan(pairs, 8, encode_once=True)
+    assert plan.name != 'list order' and max(plan.images) <= 20      # the hash-ordered swin list: contiguous slices would touch ~50 images each
+    payload = pack_predictions(sc['pred1'], sc['pred2'])
+    gathered = torch.zeros((8 * plan.per, H, W, 8), dtype=torch.float32, device=gpu)
+    for r in range(8):
+        mine = torch.tensor(plan.shard(r), device=gpu)
+        gathered[r * plan.per:r * plan.per + len(mine)] = payload.index_select(0, mine)      # what rank r's heads write into its local payload
+    del payload
+    handed = gathered.index_select(0, plan.source.to(gpu))
+    del gathered
+    p1, p2 = unpack_predictions(handed)
+    assert torch.equal(p1['pts3d'], sc['pred1']['pts3d']) and torch.equal(p2['conf'], sc['pred2']['conf'])
+    got = align(dict(view1=sc['view1'], view2=sc['view2'], pred1=p1, pred2=p2, loss=None))
+    assert got[0] == want[0] and all(torch.equal(a, b) for a, b in zip(got[1:], want[1:]))
+    assert got[0] < 0.05 and float((got[2].flatten().cpu() / gt['focal'] - 1).abs().max()) < 0.05
 
 
 @pytest.mark.parametrize('workload', ['c2', 'c3', 'c5'])
