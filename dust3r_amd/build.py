@@ -11,6 +11,10 @@ SOURCES = ['gemm.hip', 'attention.hip', 'elementwise.hip', 'aligner.hip', 'boots
 HEADERS = ['common.hpp', 'kernels.hpp', 'aligner_math.hpp', os.path.join('..', '..', 'include', 'dust3r_hip.h')]
 LIB = os.path.join(CSRC, 'libdust3r_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+# attention.hip: no SLP vectorisation -- its scalar-VALU softmax slices (attention_x3_kernel<..., SC = true>) must stay v_fma_f32 / v_add_f32
+# pairs; hipcc -O3 re-packs adjacent scalar fp32 operations into v_pk_* (an anti-lever beside MFMAs, MI355X_MICROARCH.md). The packed
+# variants of the same kernel use explicit 2-vectors and are not affected.
+EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():
@@ -36,7 +40,7 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', s, '-o', o])
 
     def run(cmd):
         if verbose:

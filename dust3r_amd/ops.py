@@ -34,6 +34,15 @@ def layernorm(x, gamma, beta, eps=1e-6, dtype=torch.bfloat16):
     return out
 
 
+def layernorm_x3(x, gamma, beta, eps=1e-6):
+    """LayerNorm into split-fp16 rows (the default engine's operand layout), returned unpacked as fp32 = hi + lo."""
+    _lib.require_device()
+    rows, Cc = x.shape
+    out = torch.empty((rows, 2 * Cc), dtype=torch.float16, device=x.device)
+    check(lib.d3r_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out), rows, Cc, eps, _lib.DTYPE_F16X3, current_stream()), 'layernorm(x3)')
+    return unpack_x3(out)
+
+
 def pad_rows(w, mult=256):
     n = w.shape[0]
     n_pad = (n + mult - 1) // mult * mult
