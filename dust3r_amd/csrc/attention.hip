@@ -767,9 +767,11 @@ template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream
     // rows; read per launch). Measured (profiles/r04_b/attndma.log, ab_attn_dma.txt): 64 x 16 heads 512 -> 492 us, 32 x 12 heads equal, forward
     // 193.15 -> 193.5 pairs/s; bit-identical outputs (tests/test_kernels_gpu.py::test_attention_split_fp16_dma_staging_is_bit_identical).
     const char* e_dma = getenv("D3R_ATTN_DMA");
-    // D3R_ATTN_SC=1: the scalar-VALU softmax slices (round 5 A/B; bit-identical; read per launch)
+    // The softmax / split slices on scalar fp32 VALU (default since round 5; D3R_ATTN_SC=0: the packed v_pk_* form; bit-identical; read per launch).
+    // Measured in one process on one box (tools/ab_probe.py, profiles/r05_b/ab_probe.log, three alternating repetitions of the 32-pair forward):
+    // attention 21.20 -> 20.72 ms per step, forward 171.29 -> 170.83 ms.
     const char* e_sc = getenv("D3R_ATTN_SC");
-    if ((e_dma ? e_dma[0] != '0' : true) && e_sc && e_sc[0] == '1') return launch_x3_v2p<ODT, 0, 4, true, true>(p, s);
+    if ((e_dma ? e_dma[0] != '0' : true) && !(e_sc && e_sc[0] == '0')) return launch_x3_v2p<ODT, 0, 4, true, true>(p, s);
     if (e_dma ? e_dma[0] != '0' : true) return launch_x3_v2p<ODT, 0, 4, true>(p, s);
     return launch_x3_v2p<ODT, 0>(p, s);
 }

@@ -10,7 +10,7 @@ namespace d3r {
 // ------------------------------------------------------------------------------ LayerNorm
 // croco blocks use nn.LayerNorm(eps=1e-6) on the fp32 residual stream (oracle/croco_ref/models/
 // croco.py); one wave per row, row kept in registers, two-pass mean / variance like ATen.
-template <int DT, bool PAIR = false>
+template <int DT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ out, int rows,
                                                         int C, float eps) {
@@ -47,34 +47,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
-    if constexpr (DT == D3R_F16X3 && PAIR) {
-        // Split-fp16 rows are 32-byte groups [hi x8][lo x8]; a lane normalises 4 elements = HALF a group, so the plain route stores two 8-byte
-        // pieces 16 bytes apart and a wave instruction covers every other 8 bytes of its 1 KiB. Here lanes 2k / 2k + 1 (the two halves of one
-        // group) swap one half each (one DPP quad_perm): the even lane stores the group's 16 hi bytes, the odd lane its 16 lo bytes -- every
-        // store instruction writes 1 KiB contiguous, 16 bytes per lane (C % 8 == 0; same values, same rounding as the plain route).
-        using TX = Traits<D3R_F16X3>;
-        const bool odd = lane & 1;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane + 64 * i;
-            const int cc = c < nch ? c : nch - 1;
-            const float4 g = reinterpret_cast<const float4*>(gamma)[cc];
-            const float4 b = reinterpret_cast<const float4*>(beta)[cc];
-            uint2 h, l;
-            TX::split2((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y, h.x, l.x);
-            TX::split2((v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w, h.y, l.y);
-            const uint2 give = odd ? h : l;          // the even lane keeps its hi half and hands over its lo half, the odd lane the reverse
-            uint2 take;
-            take.x = (uint32_t)__builtin_amdgcn_mov_dpp((int)give.x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: lane ^ 1
-            take.y = (uint32_t)__builtin_amdgcn_mov_dpp((int)give.y, 0xB1, 0xF, 0xF, true);
-            if (c < nch) {
-                char* pg = reinterpret_cast<char*>(out) + TX::boff((size_t)row * C + 4 * (size_t)(c & ~1));
-                const uint4 o = odd ? make_uint4(take.x, take.y, l.x, l.y) : make_uint4(h.x, h.y, take.x, take.y);
-                *reinterpret_cast<uint4*>(pg + (odd ? 16 : 0)) = o;
-            }
-        }
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
@@ -96,12 +68,7 @@ hipError_t launch_layernorm(int dt, const float* x, const float* gamma, const fl
         case D3R_BF16: hipLaunchKernelGGL(layernorm_kernel<D3R_BF16>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
         case D3R_F16: hipLaunchKernelGGL(layernorm_kernel<D3R_F16>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
         case D3R_F32: hipLaunchKernelGGL(layernorm_kernel<D3R_F32>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
-        case D3R_F16X3: {
-            // D3R_LN_PAIR=0: the plain store route (8-byte pieces); read per launch (A/B probes, parity tests run both)
-            const char* e = getenv("D3R_LN_PAIR");
-            if (C % 8 == 0 && !(e && e[0] == '0')) hipLaunchKernelGGL((layernorm_kernel<D3R_F16X3, true>), grid, block, 0, s, x, gamma, beta, out, rows, C, eps);
-            else hipLaunchKernelGGL(layernorm_kernel<D3R_F16X3>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps);
-        } break;
+        case D3R_F16X3: hipLaunchKernelGGL(layernorm_kernel<D3R_F16X3>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
         case D3R_F16F8:     // rows of 256-byte super-groups
             if (C % 64 != 0) return hipErrorInvalidValue;
             hipLaunchKernelGGL(layernorm_kernel<D3R_F16F8>, grid, block, 0, s, x, gamma, beta, out, rows, C, eps); break;
@@ -304,19 +271,10 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const void* __restrict_
 // expression of the one-pixel kernel (rows interpolated along x, then along y).
 template <int DT, bool NT>
 __global__ __launch_bounds__(256) void upsample2x_quad_kernel(const void* __restrict__ in, void* __restrict__ out, void* __restrict__ out_relu,
-                                                              int Hi, int Wi, int C, int cstride, int Ho, int Wo, int xcd_map) {
+                                                              int Hi, int Wi, int C, int cstride, int Ho, int Wo) {
     const int cn = C / 8;
     const int hp = (Ho + 1) / 2, wp = (Wo + 1) / 2;
-    // Block b runs on XCD b mod 8, each with its own 4 MiB L2. Neighbouring row pairs share two of their three input rows: with row pair =
-    // blockIdx they sit on eight different XCDs and every input row comes out of HBM / MALL ~2.7 times (PMC, profiles/r04_m: FETCH 2.7 x the
-    // input bytes). xcd_map: XCD x takes a CONTIGUOUS range of row pairs (the tile map of the GEMM kernel, in one dimension), so the rows
-    // two concurrently resident neighbours share are fetched once per XCD.
-    int lb = blockIdx.x;
-    if (xcd_map) {
-        const int G = gridDim.x, q = G >> 3, rem = G & 7, x = lb & 7, k = lb >> 3;
-        lb = x * q + (x < rem ? x : rem) + k;
-    }
-    const int b = lb / hp, r = lb - b * hp;
+    const int b = blockIdx.x / hp, r = blockIdx.x - b * hp;
     const float sh = Hi > 1 ? (float)(Hi - 1) / (float)(2 * Hi - 1) : 0.f;
     const float sw = Wi > 1 ? (float)(Wi - 1) / (float)(2 * Wi - 1) : 0.f;
     // the two output rows of this block
@@ -394,10 +352,8 @@ template <int DT> static void launch_upsample_t(const void* in, void* out, void*
     const char* e_v1 = getenv("D3R_UPSAMPLE_V1");            // 1: the one-output-pixel-per-thread kernel (A/B, parity tests); read per launch
     if (!(e_v1 && e_v1[0] == '1') && C % 8 == 0 && cstride % 8 == 0) {
         const int blocks = B * ((Ho + 1) / 2);
-        const char* e_x = getenv("D3R_UPSAMPLE_XCD");        // 0: row pair = blockIdx (A/B probe); read per launch
-        const int xm = (e_x && e_x[0] == '0') ? 0 : 1;
-        if (DT == D3R_F16X3 && nt) hipLaunchKernelGGL((upsample2x_quad_kernel<DT, true>), dim3(blocks), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo, xm);
-        else hipLaunchKernelGGL((upsample2x_quad_kernel<DT, false>), dim3(blocks), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo, xm);
+        if (DT == D3R_F16X3 && nt) hipLaunchKernelGGL((upsample2x_quad_kernel<DT, true>), dim3(blocks), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);
+        else hipLaunchKernelGGL((upsample2x_quad_kernel<DT, false>), dim3(blocks), dim3(256), 0, s, in, out, out_relu, Hi, Wi, C, cstride, Ho, Wo);
         return;
     }
     if (DT == D3R_F16X3 && nt && C % 8 == 0 && cstride % 8 == 0)

@@ -31,23 +31,17 @@ def test_layernorm(gpu, dtype, rows, C):
     assert relerr(out, ref) < OUT_TOL[dtype]
 
 
-@pytest.mark.parametrize('rows,C', [(7, 128), (1000, 768), (513, 1024), (33, 1032), (5, 2048), (9, 12)])
-def test_layernorm_split_fp16_rows(gpu, rows, C, monkeypatch):
-    """LayerNorm into the default engine's split-fp16 rows: 22 significand bits, so fp32-class against torch; the pair-exchange store route
-    (round 5: lanes 2k / 2k + 1 swap halves of their 32-byte group so that every store is 16 bytes per lane, C % 8 == 0) writes exactly the
-    bytes of the plain route (D3R_LN_PAIR=0); C = 12 has no whole groups and takes the plain route either way."""
+@pytest.mark.parametrize('rows,C', [(7, 128), (1000, 768), (513, 1024), (33, 1032), (5, 2048), (9, 16)])
+def test_layernorm_split_fp16_rows(gpu, rows, C):
+    """LayerNorm into the default engine's split-fp16 rows (hi + lo fp16 per element, 32-byte groups [hi x8][lo x8]): 22 significand bits,
+    so fp32-class against torch's fp64 LayerNorm."""
     from dust3r_amd import ops
     g = torch.Generator(device='cpu').manual_seed(rows * 3 + C)
     x = (torch.randn((rows, C), generator=g) * 3 + 0.5).to(gpu)
     gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(gpu), (0.1 * torch.randn(C, generator=g)).to(gpu)
     ref = F.layer_norm(x.double(), (C,), gamma.double(), beta.double(), eps=1e-6)
-    outs = []
-    for pair in ('1', '0'):
-        monkeypatch.setenv('D3R_LN_PAIR', pair)
-        out = ops.layernorm_x3(x, gamma, beta, eps=1e-6)
-        assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-6
-        outs.append(out.clone())
-    assert torch.equal(outs[0], outs[1])
+    out = ops.layernorm_x3(x, gamma, beta, eps=1e-6)
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -293,7 +287,7 @@ def test_attention(gpu, dtype, B, H, Nq, Nk):
     assert relerr(out, ref) < tol
 
 
-@pytest.mark.parametrize('v1', ['0', '1', 'dma', 'reg', 'sc'])
+@pytest.mark.parametrize('v1', ['0', '1', 'dma', 'reg', 'pk'])
 @pytest.mark.parametrize('B,H,Nq,Nk', [(2, 3, 196, 196), (1, 2, 768, 768), (2, 1, 6, 6), (1, 4, 130, 70), (1, 1, 768, 196), (1, 2, 40, 129), (1, 1, 300, 64), (1, 1, 64, 128)])
 def test_attention_split_fp16(gpu, v1, B, H, Nq, Nk, monkeypatch):
     """The split-fp16 attention of the default engine at kernel level, every kernel (D3R_ATTN_V1=1: the round-2 kernel; the
@@ -305,9 +299,9 @@ def test_attention_split_fp16(gpu, v1, B, H, Nq, Nk, monkeypatch):
     monkeypatch.setenv('D3R_ATTN_V1', '1' if v1 == '1' else '0')
     if v1 in ('dma', 'reg'):
         monkeypatch.setenv('D3R_ATTN_DMA', '1' if v1 == 'dma' else '0')
-    if v1 == 'sc':            # round 5: the softmax / split slices on scalar fp32 VALU instead of v_pk_* (DMA staging)
+    if v1 == 'pk':            # the softmax / split slices on packed fp32 VALU (rounds 3-4; round 5's default is the scalar form, DMA staging)
         monkeypatch.setenv('D3R_ATTN_DMA', '1')
-    monkeypatch.setenv('D3R_ATTN_SC', '1' if v1 == 'sc' else '0')
+        monkeypatch.setenv('D3R_ATTN_SC', '0')
     g = torch.Generator(device='cpu').manual_seed(Nq * 5 + Nk)
     q = (torch.randn((B, H, Nq, 64), generator=g) * 1.5).to(gpu)
     k = (torch.randn((B, H, Nk, 64), generator=g) * 1.5).to(gpu)
@@ -403,7 +397,7 @@ def test_upsample2x(gpu, dtype, B, H, W, C, crop):
     assert out.shape == ref.shape and relerr(out, ref) < OUT_TOL[dtype]
 
 
-@pytest.mark.parametrize('v1', ['0', '1', 'noxcd'])
+@pytest.mark.parametrize('v1', ['0', '1'])
 @pytest.mark.parametrize('B,H,W,C,crop', [(2, 12, 16, 256, None), (1, 24, 32, 128, None), (2, 7, 5, 64, None), (1, 12, 16, 256, (24, 31)), (1, 9, 11, 8, (17, 22)),
                                           (1, 1, 6, 16, None), (3, 6, 1, 16, None), (5, 13, 4, 8, None)])
 def test_upsample2x_split_fp16(gpu, v1, B, H, W, C, crop, monkeypatch):
@@ -411,8 +405,7 @@ def test_upsample2x_split_fp16(gpu, v1, B, H, W, C, crop, monkeypatch):
     thread; default: a 2 x 2 output block per thread from its 3 x 3 input neighbourhood): fp32-class against torch, odd / cropped output
     sizes (blocks with a missing second row or column), single-row and single-column inputs."""
     from dust3r_amd import ops
-    monkeypatch.setenv('D3R_UPSAMPLE_V1', '1' if v1 == '1' else '0')
-    monkeypatch.setenv('D3R_UPSAMPLE_XCD', '0' if v1 == 'noxcd' else '1')     # round 5: row pairs handed to the XCDs in contiguous ranges (block counts 1 .. 65, also not multiples of 8)
+    monkeypatch.setenv('D3R_UPSAMPLE_V1', v1)
     g = torch.Generator(device='cpu').manual_seed(H * W + C)
     x = torch.randn((B, H, W, C), generator=g).to(gpu)
     ref = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode='bilinear', align_corners=True).permute(0, 2, 3, 1)
