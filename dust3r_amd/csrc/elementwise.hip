@@ -492,11 +492,12 @@ hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s) { return hipMe
 template <int DT> __global__ __launch_bounds__(256) void pack_weight_kernel(PackParams p) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= p.numel) return;
-    const float v = p.src[i];
+    float v = p.src[i];
     size_t d;
     if (p.kind == PACK_MAT) {                    // [rows][cols] -> [row_off + r][c]
         const size_t r = i / p.cols, c = i - r * p.cols;
         d = (r + p.row_off) * (size_t)p.dst_cols + c;
+        if (p.kscale) v *= p.kscale[c];          // W diag(gamma): the LayerNorm in front of this nn.Linear is folded into it (kernels.hpp, GemmParams::ln_*)
     } else if (p.kind == PACK_CONV) {            // [Cout][Cin][k][k] -> [co][(ky*k+kx)*cin_pad + ci]
         const int kk = p.ksize * p.ksize;
         const size_t co = i / ((size_t)p.cin * kk);
@@ -537,6 +538,75 @@ hipError_t launch_pack_weight(int dt, const PackParams& p, hipStream_t s) {
     }
     return hipGetLastError();
 }
+// ---- folded LayerNorm (kernels.hpp GemmParams::ln_*) ----------------------------------------------------------------------------------------
+// rows x G partial (sum, sum of squares) pairs -> rstd, -mean rstd. One thread per row; the G pairs are added in index order in fp64 (a fixed
+// order: the statistics of a row do not depend on how the producing GEMM was tiled, and neither on the batch the row sits in).
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, int rows, int G, float inv_c, float eps, float* __restrict__ rstd,
+                                                          float* __restrict__ nmr) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float2* pr = part + (size_t)r * G;
+    double s = 0.0, q = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const float2 t = pr[g];
+        s += (double)t.x; q += (double)t.y;
+    }
+    const double mean = s * (double)inv_c;
+    double var = q * (double)inv_c - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    rstd[r] = rs;
+    nmr[r] = (float)(-mean) * rs;
+}
+hipError_t launch_ln_finalize(const float* part, int rows, int C, float eps, float* rstd, float* nmr, hipStream_t s) {
+    if (rows <= 0 || C % 32 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float2*>(part), rows, C / 32, 1.0f / (float)C, eps, rstd, nmr);
+    return hipGetLastError();
+}
+// one wave per weight row n: colsum[n] = sum_k r(gamma_k W_nk), bias_out[n] = bias_in[n] + sum_k beta_k W_nk (fp64 sums, lane-strided then butterfly)
+template <int DT> __global__ __launch_bounds__(256) void ln_fold_vectors_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                                const float* __restrict__ bias_in, float* __restrict__ colsum, float* __restrict__ bias_out,
+                                                                                int N, int K) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* w = W + (size_t)n * K;
+    double s = 0.0, b = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = w[k], wg = wv * gamma[k];       // the product the pack kernel rounds (same fp32 multiply)
+        float r;
+        if constexpr (DT == D3R_F16X3) {
+            uint32_t hi, lo;
+            Traits<D3R_F16X3>::split2(wg, 0.f, hi, lo);
+            r = Traits<D3R_F16X3>::join_lo(hi, lo);      // hi + lo: exact in fp32 (two 11-bit significands 11 binades apart)
+        } else if constexpr (DT == D3R_F32) {
+            r = wg;
+        } else {
+            r = Traits<DT>::unpack_lo(Traits<DT>::pack2(wg, 0.f));
+        }
+        s += (double)r;
+        b += (double)beta[k] * (double)wv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); b += __shfl_xor(b, o); }
+    if (lane == 0) {
+        colsum[n] = (float)s;
+        bias_out[n] = (float)((bias_in ? (double)bias_in[n] : 0.0) + b);
+    }
+}
+hipError_t launch_ln_fold_vectors(int dt, const float* W, const float* gamma, const float* beta, const float* bias_in, float* colsum, float* bias_out, int N, int K,
+                                  hipStream_t s) {
+    if (N <= 0 || K <= 0) return hipErrorInvalidValue;
+    const dim3 grid((N + 3) / 4), block(256);
+    switch (dt) {
+        case D3R_F16X3: hipLaunchKernelGGL(ln_fold_vectors_kernel<D3R_F16X3>, grid, block, 0, s, W, gamma, beta, bias_in, colsum, bias_out, N, K); break;
+        case D3R_F32: hipLaunchKernelGGL(ln_fold_vectors_kernel<D3R_F32>, grid, block, 0, s, W, gamma, beta, bias_in, colsum, bias_out, N, K); break;
+        case D3R_BF16: hipLaunchKernelGGL(ln_fold_vectors_kernel<D3R_BF16>, grid, block, 0, s, W, gamma, beta, bias_in, colsum, bias_out, N, K); break;
+        case D3R_F16: hipLaunchKernelGGL(ln_fold_vectors_kernel<D3R_F16>, grid, block, 0, s, W, gamma, beta, bias_in, colsum, bias_out, N, K); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // ConvTranspose bias [Cout] -> fp32 [k*k][cout_pad]
 __global__ __launch_bounds__(256) void pack_convt_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cout_pad, int taps) {
     const int i = blockIdx.x * 256 + threadIdx.x;

@@ -40,10 +40,14 @@ struct Slot {
     int dt = -1;              // layout of a packed matrix (-1: the model's dtype; the transformer blocks' matrices may be fp16 + fp8 rows)
     bool loaded = false, explicit_loaded = false;
     std::string mirror;       // dec_blocks.* -> dec_blocks2.* duplication
+    struct Lin* fold = nullptr;   // PK_MAT: this matrix has the LayerNorm in front of it folded in (ln_fold engines): staged in fp32, packed by finalize_fold
+    bool refold = false;          // PK_VEC: a LayerNorm weight / bias or the bias of a folded nn.Linear -- a new value makes the fold stale
 };
 
-struct Lin { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, n_pad = 0, n_rows = 0, dt = 0; };   // dt: operand layout of this GEMM
 struct LNp { float* g = nullptr; float* b = nullptr; };
+// dt: operand layout of this GEMM. ln != nullptr (ln_fold engines): W is packed as W diag(gamma), b_fold = b + W beta, ln_s[n] = sum_k of the packed row n
+struct Lin { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, n_pad = 0, n_rows = 0, dt = 0;
+             const LNp* ln = nullptr; float* ln_s = nullptr; float* b_fold = nullptr; float* w32 = nullptr; };
 struct EncBlk { LNp n1, n2; Lin qkv, proj, fc1, fc2; };
 struct DecBlk { LNp n1, n2, n3, ny; Lin qkv, proj, cq, ckv, cproj, fc1, fc2; };
 struct ConvW { void* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0, cin_pad = 0, k = 1, n_pad = 0, n_rows = 0, K = 0; };
@@ -66,6 +70,12 @@ struct d3r_model {
     d3r_model_config cfg;
     int dt = 0, ktile = 64;
     int bdt = 0;              // operand layout of the transformer blocks' linears (= dt, or D3R_F16F8 on top of dt = D3R_F16X3)
+    // LayerNorm folded into the GEMMs around it (round 5; split-fp16 engines; kernels.hpp GemmParams::ln_*): norm1 / norm2 of the encoder blocks
+    // and norm1 / norm2 / norm3 / norm_y of the decoder blocks are not launched -- the fp32-residual epilogue in front of them also stores the RAW
+    // typed rows and per-row partial sums, the nn.Linear behind them is packed as W diag(gamma) and applies rstd / mean in its epilogue.
+    // enc_norm / dec_norm (their outputs leave the engine or feed the heads) stay kernels. D3R_LN_FOLD=0|1 at model creation.
+    bool ln_fold = false, fold_dirty = false;
+    std::vector<Lin*> fold_lins;
     std::unordered_map<std::string, Slot> slots;
     std::vector<void*> allocs;
     size_t weight_bytes = 0;
@@ -188,6 +198,20 @@ bool reg_convt(d3r_model* m, const std::string& prefix, Lin& L, int Cin, int Cou
     m->slots[prefix + ".bias"] = b;
     return true;
 }
+// the nn.Linear `L` (weight slots `wkeys`, bias slots `bkeys`) consumes LayerNorm `ln` (slots prefix `lnkey`): fold it (ln_fold engines)
+bool reg_fold(d3r_model* m, Lin& L, const LNp& ln, const std::string& lnkey, std::initializer_list<std::string> wkeys, std::initializer_list<std::string> bkeys) {
+    if (!m->ln_fold) return true;
+    L.ln = &ln;
+    L.ln_s = (float*)m->dalloc((size_t)L.n_rows * sizeof(float));
+    L.b_fold = (float*)m->dalloc((size_t)L.n_rows * sizeof(float));
+    if (!L.ln_s || !L.b_fold) return false;
+    for (auto& k : wkeys) m->slots[k].fold = &L;
+    for (auto& k : bkeys) m->slots[k].refold = true;
+    m->slots[lnkey + ".weight"].refold = true;
+    m->slots[lnkey + ".bias"].refold = true;
+    m->fold_lins.push_back(&L);
+    return true;
+}
 void reg_ignore(d3r_model* m, const std::string& key) { Slot s; s.kind = PK_IGNORE; s.loaded = true; m->slots[key] = s; }
 
 bool build_slots(d3r_model* m) {
@@ -203,6 +227,9 @@ bool build_slots(d3r_model* m) {
         if (!reg_ln(m, p + ".norm1", b.n1, Ce) || !reg_ln(m, p + ".norm2", b.n2, Ce) || !reg_linear(m, p + ".attn.qkv", b.qkv, 3 * Ce, Ce, bd) ||
             !reg_linear(m, p + ".attn.proj", b.proj, Ce, Ce, bd) || !reg_linear(m, p + ".mlp.fc1", b.fc1, 4 * Ce, Ce, bd) ||
             !reg_linear(m, p + ".mlp.fc2", b.fc2, Ce, 4 * Ce, bd))
+            return false;
+        if (!reg_fold(m, b.qkv, b.n1, p + ".norm1", {p + ".attn.qkv.weight"}, {p + ".attn.qkv.bias"}) ||
+            !reg_fold(m, b.fc1, b.n2, p + ".norm2", {p + ".mlp.fc1.weight"}, {p + ".mlp.fc1.bias"}))
             return false;
     }
     if (!reg_ln(m, "enc_norm", m->enc_norm, Ce) || !reg_ln(m, "dec_norm", m->dec_norm, Cd) || !reg_linear(m, "decoder_embed", m->dec_embed, Cd, Ce))
@@ -224,6 +251,11 @@ bool build_slots(d3r_model* m) {
             reg_mat(m, p + ".cross_attn.projv.weight", b.ckv, Cd, Cd);
             reg_vec_at(m, p + ".cross_attn.projk.bias", b.ckv.b, 0, Cd);
             reg_vec_at(m, p + ".cross_attn.projv.bias", b.ckv.b, Cd, Cd);
+            if (!reg_fold(m, b.qkv, b.n1, p + ".norm1", {p + ".attn.qkv.weight"}, {p + ".attn.qkv.bias"}) ||
+                !reg_fold(m, b.cq, b.n2, p + ".norm2", {p + ".cross_attn.projq.weight"}, {p + ".cross_attn.projq.bias"}) ||
+                !reg_fold(m, b.ckv, b.ny, p + ".norm_y", {p + ".cross_attn.projk.weight", p + ".cross_attn.projv.weight"}, {p + ".cross_attn.projk.bias", p + ".cross_attn.projv.bias"}) ||
+                !reg_fold(m, b.fc1, b.n3, p + ".norm3", {p + ".mlp.fc1.weight"}, {p + ".mlp.fc1.bias"}))
+                return false;
         }
     }
     // dec_blocks.* duplicates into dec_blocks2.* until an explicit dec_blocks2 key arrives (model.py:91-98)
@@ -284,10 +316,17 @@ int pack_slot(d3r_model* m, Slot& s, const float* data, int ndim, const int64_t*
         case PK_IGNORE: return D3R_OK;
         case PK_VEC:
             if (numel != (size_t)s.rows) return D3R_ERR_SHAPE;
+            if (s.refold) m->fold_dirty = true;
             return hipMemcpyAsync(s.dst, data, numel * sizeof(float), hipMemcpyDeviceToDevice, nullptr) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
         case PK_MAT:
             if (ndim < 2 || shape[0] != s.rows || numel != (size_t)s.rows * s.cols) return D3R_ERR_SHAPE;
             pp.kind = PACK_MAT; pp.cols = s.cols; pp.row_off = s.row_off;
+            if (s.fold) {       // the LayerNorm in front of this matrix is folded into it: keep the fp32 rows until finalize_fold packs W diag(gamma)
+                Lin& L = *s.fold;
+                if (!L.w32 && hipMalloc((void**)&L.w32, (size_t)L.N * L.K * sizeof(float)) != hipSuccess) { L.w32 = nullptr; return D3R_ERR_ALLOC; }
+                m->fold_dirty = true;
+                return hipMemcpyAsync(L.w32 + (size_t)s.row_off * L.K, data, numel * sizeof(float), hipMemcpyDeviceToDevice, nullptr) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
+            }
             break;
         case PK_CONV:
             if (ndim != 4 || shape[0] != s.rows || shape[1] != s.cin || shape[2] != s.ksize || shape[3] != s.ksize) return D3R_ERR_SHAPE;
@@ -330,20 +369,26 @@ enum { PRF_GEMM = 0, PRF_CONV = 8, PRF_ATTN = 16, PRF_OTHER = 17, PRF_GEMM_64 = 
 static inline int prf_kind(int base, int cfg) { return cfg == GEMM_CFG_384x192 ? PRF_GEMM_384 : cfg == GEMM_CFG_64 ? (base == PRF_CONV ? PRF_CONV_64 : PRF_GEMM_64) : base + cfg; }
 #define D3R_OTHER(call) do { c.mark(PRF_OTHER, 0.0); c.chk(call); } while (0)
 
+// folded LayerNorm (kernels.hpp GemmParams::ln_*): `stats` = the consumer side (rstd, -mean rstd of the input rows; the Lin carries column sums and
+// folded bias), `part` = the producer side (partial sums of the rows this launch stores, next to their raw typed copy out2)
+struct LnStats { const float* rstd = nullptr; const float* nmr = nullptr; };
 void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi, void* out, int ldo, const void* res1 = nullptr,
-                 void* out2 = nullptr, int ldo2 = 0, int n_store = -1, int flags = 0) {
+                 void* out2 = nullptr, int ldo2 = 0, int n_store = -1, int flags = 0, LnStats stats = LnStats(), float* part = nullptr) {
     GemmParams p;
     p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_rows = L.n_rows;
     p.n_store = n_store >= 0 ? n_store : L.N;
     p.epi = epi; p.out = out; p.ldo = ldo; p.res1 = res1; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo2; p.flags = flags;
+    if (stats.rstd) { p.ln_rstd = stats.rstd; p.ln_nmr = stats.nmr; p.ln_colsum = L.ln_s; p.bias = L.b_fold; }
+    p.ln_part = part;
     c.mark(prf_kind((L.dt == D3R_F16F8 || L.dt == D3R_F16X2F8) ? PRF_GEMM_F8 : PRF_GEMM, gemm_pick_config(p, L.dt)), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(L.dt, p, c.st));
 }
 
 void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_c, int nreg, const int* kinds, void* const* dsts, int heads,
-                int ntok, int tok_w, int ldv) {
+                int ntok, int tok_w, int ldv, LnStats stats = LnStats()) {
     GemmParams p;
     p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_rows = L.n_rows; p.n_store = L.N;
+    if (stats.rstd) { p.ln_rstd = stats.rstd; p.ln_nmr = stats.nmr; p.ln_colsum = L.ln_s; p.bias = L.b_fold; }
     p.epi = EPI_HEADS; p.head_c = head_c;
     for (int i = 0; i < nreg; ++i) { p.head_kind[i] = kinds[i]; p.head_dst[i] = dsts[i]; }
     p.heads = heads; p.ntok = ntok; p.tok_w = tok_w; p.ldv = ldv; p.rope_table = c.m->rope_table;
@@ -426,6 +471,11 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     const bool f8blocks = cfg->dtype == D3R_F16F8 || cfg->dtype == D3R_F16X2F8;
     m->cfg = *cfg; m->dt = f8blocks ? D3R_F16X3 : cfg->dtype; m->bdt = f8blocks ? cfg->dtype : m->dt;
     m->ktile = 128 / (int)dt_bytes(m->dt);
+    {   // LayerNorm folded into the neighbouring GEMMs (see d3r_model::ln_fold): split-fp16 engines, every channel count a multiple of 32
+        const char* e = getenv("D3R_LN_FOLD");
+        const bool want = e ? e[0] == '1' : false;
+        m->ln_fold = want && m->dt == D3R_F16X3 && m->bdt == D3R_F16X3 && cfg->enc_embed_dim % 32 == 0 && cfg->dec_embed_dim % 32 == 0 && !getenv("D3R_GEMM_NOWIDE");
+    }
     if (cfg->enc_embed_dim % m->ktile || cfg->dec_embed_dim % m->ktile || (3 * cfg->patch_size * cfg->patch_size) % m->ktile ||
         (cfg->head_type == 1 && (cfg->dec_depth <= 9 || cfg->patch_size != 16))) { delete m; return D3R_ERR_INVALID; }   // run_dpt assumes 16 x th == H
     if (!build_slots(m)) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
@@ -444,6 +494,7 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
 extern "C" int d3r_model_destroy(d3r_model* m) {
     if (!m) return D3R_OK;
     for (void* p : m->allocs) (void)hipFree(p);
+    for (Lin* L : m->fold_lins) if (L->w32) (void)hipFree(L->w32);
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     if (m->ev_main) (void)hipEventDestroy(m->ev_main);
     if (m->ev_side) (void)hipEventDestroy(m->ev_side);
@@ -580,10 +631,10 @@ extern "C" int d3r_model_profile_launch(d3r_model* m, int index, int* kind, int*
 namespace {
 
 void self_attention(Ctx& c, const void* xn, const Lin& qkv, int M, int C, int heads, int nimg, int ntok, int tok_w, int ldv, void* q, void* k,
-                    void* vt, void* ao) {
+                    void* vt, void* ao, LnStats stats = LnStats()) {
     const int kinds[3] = {HEAD_ROPE, HEAD_ROPE, HEAD_VT};
     void* dsts[3] = {q, k, vt};
-    gemm_heads(c, xn, C, qkv, M, C, 3, kinds, dsts, heads, ntok, tok_w, ldv);
+    gemm_heads(c, xn, C, qkv, M, C, 3, kinds, dsts, heads, ntok, tok_w, ldv, stats);
     AttnParams a;
     a.q = q; a.k = k; a.vt = vt; a.out = ao; a.B = nimg; a.H = heads; a.Nq = ntok; a.Nk = ntok; a.ldv = ldv; a.scale = 0.125f;
     a.out_dt = c.m->bdt;      // rows for the proj GEMM
@@ -745,6 +796,22 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
     for (int s = 0; s < 2; ++s)
         for (int j = 0; j < 3; ++j) hook[s][j] = ar.take((size_t)Ms[s] * Cd * eb);
     float* lin_out = cf.head_type == 0 ? (float*)ar.take((size_t)M2d * 4 * ps * ps * 4) : nullptr;
+    // folded LayerNorm (d3r_model::ln_fold): partial sums [rows][C / 32][2], rstd / -mean rstd per row -- one set for the encoder (e_), one per
+    // decoder LAYER OUTPUT and buffer (l_: both sides' rows, read by the own side's norm1 and the other side's norm_y) with the raw typed copy fr
+    // of that output, one per side for the block-internal norm2 / norm3 (s_)
+    const bool fold = m->ln_fold;
+    const int Ge = Ce / 32, Gd = Cd / 32;
+    float *e_part = nullptr, *e_rs = nullptr, *e_nm = nullptr, *l_part[2] = {nullptr, nullptr}, *l_rs[2] = {nullptr, nullptr}, *l_nm[2] = {nullptr, nullptr};
+    float *s_part[2] = {nullptr, nullptr}, *s_rs[2] = {nullptr, nullptr}, *s_nm[2] = {nullptr, nullptr};
+    void* fr[2] = {nullptr, nullptr};
+    if (fold) {
+        e_part = (float*)ar.take((size_t)Me * Ge * 8); e_rs = (float*)ar.take((size_t)Me * 4 + 16); e_nm = (float*)ar.take((size_t)Me * 4 + 16);
+        for (int b = 0; b < 2; ++b) {
+            fr[b] = ar.take((size_t)M2d * Cd * eb);
+            l_part[b] = (float*)ar.take((size_t)M2d * Gd * 8); l_rs[b] = (float*)ar.take((size_t)M2d * 4 + 16); l_nm[b] = (float*)ar.take((size_t)M2d * 4 + 16);
+            s_part[b] = (float*)ar.take((size_t)Mmax * Gd * 8); s_rs[b] = (float*)ar.take((size_t)Mmax * 4 + 16); s_nm[b] = (float*)ar.take((size_t)Mmax * 4 + 16);
+        }
+    }
     const size_t common_end = (ar.off + 255) & ~(size_t)255;
     const int chunk = B < 32 ? B : 32;   // 288 GB of HBM: batch the head as wide as the encoder (low-resolution stages need the rows)
     size_t head_arena = 0;
@@ -786,6 +853,23 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                 } else {
                     D3R_OTHER(launch_patchify(m->dt, pass == 0 ? img1 : img2, hb, n_img, dd.H, dd.W, ps, st));
                 }
+                if (fold) {
+                    // every fp32-residual epilogue also stores the raw typed rows (xn) and their partial sums; the LayerNorm itself is two fmas in
+                    // the epilogue of the nn.Linear behind it (weights packed as W diag(gamma)): 2 x enc_depth LayerNorm launches become
+                    // 2 x enc_depth row-statistics launches of 1 / 64 the traffic
+                    const LnStats es{e_rs, e_nm};
+                    gemm_linear(c, hb, (int)pk, m->patch, Mp, EPI_F32, xp, Ce, nullptr, xn, Ce, -1, 0, LnStats(), e_part);
+                    for (int l = 0; l < cf.enc_depth; ++l) {
+                        const EncBlk& b = m->enc[l];
+                        const bool last = l + 1 == cf.enc_depth;        // enc_norm (a kernel) reads the fp32 rows: no typed copy, no sums
+                        D3R_OTHER(launch_ln_finalize(e_part, Mp, Ce, 1e-6f, e_rs, e_nm, st));
+                        self_attention(c, xn, b.qkv, Mp, Ce, He, n_img, dd.N, dd.tw, dd.ldv, q, k, vt, ao, es);
+                        gemm_linear(c, ao, Ce, b.proj, Mp, EPI_F32, xp, Ce, xp, xn, Ce, -1, 0, LnStats(), e_part);
+                        D3R_OTHER(launch_ln_finalize(e_part, Mp, Ce, 1e-6f, e_rs, e_nm, st));
+                        gemm_linear(c, xn, Ce, b.fc1, Mp, EPI_GELU, hb, 4 * Ce, nullptr, nullptr, 0, -1, 0, es);
+                        gemm_linear(c, hb, 4 * Ce, b.fc2, Mp, EPI_F32, xp, Ce, xp, last ? nullptr : xn, Ce, -1, 0, LnStats(), last ? nullptr : e_part);
+                    }
+                } else {
                 gemm_linear(c, hb, (int)pk, m->patch, Mp, EPI_F32, xp, Ce);
                 for (int l = 0; l < cf.enc_depth; ++l) {
                     const EncBlk& b = m->enc[l];
@@ -796,13 +880,21 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                     gemm_linear(c, xn, Ce, b.fc1, Mp, EPI_GELU, hb, 4 * Ce);
                     gemm_linear(c, hb, 4 * Ce, b.fc2, Mp, EPI_F32, xp, Ce, xp);
                 }
+                }
                 D3R_OTHER(launch_layernorm(m->dt, xp, m->enc_norm.g, m->enc_norm.b, (char*)encn + row0 * Ce * eb, Mp, Ce, 1e-6f, st));
             }
             m->last_encn = encn; m->last_encn_elems = (size_t)Me * Ce;
         }
         if (do_dec) {
         // ---- decoder (model.py:172-191): side s reads the PREVIOUS layer's (f_s, f_other) ---------------------
+        void* frp[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // fold: raw typed copy of layer output [buffer][side] (fr, or a DPT hook buffer at the hook layers)
+        if (fold) {
+            gemm_linear(c, encn, Ce, m->dec_embed, M2d, EPI_F32, f[0], Cd, nullptr, fr[0], Cd, -1, 0, LnStats(), l_part[0]);
+            D3R_OTHER(launch_ln_finalize(l_part[0], M2d, Cd, 1e-6f, l_rs[0], l_nm[0], st));
+            for (int sd = 0; sd < 2; ++sd) frp[0][sd] = (char*)fr[0] + (size_t)Roff[sd] * Cd * eb;
+        } else {
         gemm_linear(c, encn, Ce, m->dec_embed, M2d, EPI_F32, f[0], Cd);
+        }
         if (two) {
             c.chk(hipEventRecord(m->ev_main, S[0]));
             c.chk(hipStreamWaitEvent(S[1], m->ev_main, 0));
@@ -826,6 +918,39 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                 const float* xo = f[cur] + (size_t)Roff[s] * Cd;         // own stream (old)
                 const float* yo = f[cur] + (size_t)Roff[1 - s] * Cd;     // other view (old)
                 float* xw = f[cur ^ 1] + (size_t)Roff[s] * Cd;           // own stream (new)
+                if (fold) {
+                    const LnStats sx{l_rs[cur] + Roff[s], l_nm[cur] + Roff[s]}, sy{l_rs[cur] + Roff[1 - s], l_nm[cur] + Roff[1 - s]}, ss{s_rs[s], s_nm[s]};
+                    self_attention(c, frp[cur][s], b.qkv, Ms[s], Cd, Hd, B, own.N, own.tw, own.ldv, sq, sk, svt, sao, sx);      // norm1 folded
+                    gemm_linear(c, sao, Cd, b.proj, Ms[s], EPI_F32, xw, Cd, xo, sxn, Cd, -1, 0, LnStats(), s_part[s]);
+                    D3R_OTHER(launch_ln_finalize(s_part[s], Ms[s], Cd, 1e-6f, s_rs[s], s_nm[s], c.st));
+                    {
+                        const int kq[1] = {HEAD_ROPE};
+                        void* dq[1] = {sq};
+                        gemm_heads(c, sxn, Cd, b.cq, Ms[s], Cd, 1, kq, dq, Hd, own.N, own.tw, own.ldv, ss);                     // norm2 folded
+                        const int kkv[2] = {HEAD_ROPE, HEAD_VT};
+                        void* dkv[2] = {sk, svt};
+                        gemm_heads(c, frp[cur][1 - s], Cd, b.ckv, Ms[1 - s], Cd, 2, kkv, dkv, Hd, oth.N, oth.tw, oth.ldv, sy);  // norm_y folded: the other side's raw rows and statistics
+                        AttnParams a;
+                        a.q = sq; a.k = sk; a.vt = svt; a.out = sao; a.B = B; a.H = Hd; a.Nq = own.N; a.Nk = oth.N; a.ldv = oth.ldv; a.scale = 0.125f;
+                        a.out_dt = m->bdt;
+                        c.mark(PRF_ATTN, 4.0 * B * Hd * (double)own.N * oth.N * 64, B * Hd, own.N, oth.N);
+                        c.chk(launch_attention(m->dt, a, c.st));
+                    }
+                    gemm_linear(c, sao, Cd, b.cproj, Ms[s], EPI_F32, xw, Cd, xw, sxn, Cd, -1, 0, LnStats(), s_part[s]);
+                    D3R_OTHER(launch_ln_finalize(s_part[s], Ms[s], Cd, 1e-6f, s_rs[s], s_nm[s], c.st));
+                    gemm_linear(c, sxn, Cd, b.fc1, Ms[s], EPI_GELU, shb, 4 * Cd, nullptr, nullptr, 0, -1, 0, ss);                 // norm3 folded
+                    const int layer_no = l + 1;
+                    void* hcopy = (cf.head_type == 1 && (layer_no == hk6 || layer_no == hk9)) ? hook[s][layer_no == hk6 ? 0 : 1] : nullptr;
+                    if (layer_no == cf.dec_depth) {      // dec_norm (a kernel) reads the fp32 rows
+                        gemm_linear(c, shb, 4 * Cd, b.fc2, Ms[s], EPI_F32, xw, Cd, xw, hcopy, Cd);
+                    } else {                             // the raw typed copy of the layer output IS a DPT hook at the hook layers
+                        void* raw = hcopy ? hcopy : (void*)((char*)fr[cur ^ 1] + (size_t)Roff[s] * Cd * eb);
+                        gemm_linear(c, shb, 4 * Cd, b.fc2, Ms[s], EPI_F32, xw, Cd, xw, raw, Cd, -1, 0, LnStats(), l_part[cur ^ 1] + (size_t)Roff[s] * Gd * 2);
+                        D3R_OTHER(launch_ln_finalize(l_part[cur ^ 1] + (size_t)Roff[s] * Gd * 2, Ms[s], Cd, 1e-6f, l_rs[cur ^ 1] + Roff[s], l_nm[cur ^ 1] + Roff[s], c.st));
+                        frp[cur ^ 1][s] = raw;
+                    }
+                    continue;
+                }
                 D3R_OTHER(launch_layernorm(m->bdt, xo, b.n1.g, b.n1.b, sxn, Ms[s], Cd, 1e-6f, c.st));
                 self_attention(c, sxn, b.qkv, Ms[s], Cd, Hd, B, own.N, own.tw, own.ldv, sq, sk, svt, sao);
                 gemm_linear(c, sao, Cd, b.proj, Ms[s], EPI_F32, xw, Cd, xo);
@@ -892,6 +1017,25 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
 
 }  // namespace
 
+// ln_fold engines: (re)pack every nn.Linear behind a folded LayerNorm as W diag(gamma) and form its column sums / folded bias, from the fp32
+// rows staged by pack_slot. Runs once after a load (the first forward finds fold_dirty); the staging copies are released afterwards, so a later
+// load of ONLY a LayerNorm vector or a bias (without the matrices) cannot be folded: D3R_ERR_STATE (include/dust3r_hip.h, d3r_model_load_tensor).
+static int finalize_fold(d3r_model* m) {
+    if (!m->ln_fold || !m->fold_dirty) return D3R_OK;
+    for (Lin* L : m->fold_lins) if (!L->w32) return D3R_ERR_STATE;
+    for (Lin* L : m->fold_lins) {
+        PackParams pp;
+        pp.src = L->w32; pp.numel = (size_t)L->N * L->K; pp.dst = L->w; pp.dst_cols = L->K; pp.kind = PACK_MAT; pp.cols = L->K; pp.row_off = 0;
+        pp.kscale = L->ln->g;
+        if (launch_pack_weight(L->dt, pp, nullptr) != hipSuccess) return D3R_ERR_LAUNCH;
+        if (launch_ln_fold_vectors(L->dt, L->w32, L->ln->g, L->ln->b, L->b, L->ln_s, L->b_fold, L->N, L->K, nullptr) != hipSuccess) return D3R_ERR_LAUNCH;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return D3R_ERR_LAUNCH;
+    for (Lin* L : m->fold_lins) { (void)hipFree(L->w32); L->w32 = nullptr; }
+    m->fold_dirty = false;
+    return D3R_OK;
+}
+
 static int run_phases(d3r_model* m, int phases, const float* img1, const float* img2, int nimg1, int nimg, void* feat, int B, int H1, int W1,
                       int H2, int W2, float* pts1, float* conf1, float* pts2, float* conf2, hipStream_t st) {
     const int ps = m->cfg.patch_size;
@@ -900,6 +1044,7 @@ static int run_phases(d3r_model* m, int phases, const float* img1, const float* 
         if (H % ps || W % ps || H <= 0 || W <= 0 || H / ps > 511 || W / ps > 511) return D3R_ERR_SHAPE;
     }
     if (d3r_model_missing(m) != 0) return D3R_ERR_STATE;
+    { const int frc = finalize_fold(m); if (frc != D3R_OK) return frc; }
     const SideDim d0 = side_dim(H1, W1, ps), d1 = side_dim(H2, W2, ps);
     const size_t need = forward_impl(m, nullptr, 0, phases, img1, img2, nimg1, nimg, feat, B, d0, d1, pts1, conf1, pts2, conf2, st, nullptr);
     if (need > m->ws_bytes) {

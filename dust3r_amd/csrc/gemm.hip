@@ -1437,9 +1437,29 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                 const bool has_tab = heads && p.rope_table != nullptr;
                 const float* rtab = has_tab ? p.rope_table : reinterpret_cast<const float*>(p.wgt);
                 const int r_ntok = has_tab ? p.ntok : 1, r_tokw = has_tab ? p.tok_w : 1, r_M = has_tab ? p.M : 1;
-                float bjv[FJ];     // per-row bias of the operand-swapped (V^T) tiles
+                // Folded LayerNorm (kernels.hpp GemmParams::ln_*): rstd_m (acc - mean_m s_n) + b'_n = fma(acc, R, fma(S, Nm, bias)) with, per element,
+                // R = rstd of its ROW m, Nm = -mean rstd of its row, S = column sum of its COLUMN n. The four operands live in the registers the
+                // bias alone used to take, plus 12:
+                //   not swapped (m = j, n = i):  R = lnC[fj] (scalar), Nm = bjv[fj] (scalar), S = lnX[fl] (float4), bias = bq[fl] (float4)
+                //   swapped, V^T (m = i, n = j): R = lnX[fl] (float4), Nm = bq[fl] (float4), S = lnC[fj] (scalar),  bias = bjv[fj] (scalar)
+                // Without a fold the same two fmas run on (R, Nm, S) = (1, 0, 0) = acc + bias bit for bit; every load then reads the bias vector.
+                const bool has_ln = DTX3 && p.ln_rstd != nullptr;
+                const float* lnr = has_ln ? p.ln_rstd : bsrc;
+                const float* lnn = has_ln ? p.ln_nmr : bsrc;
+                const float* lns = has_ln ? p.ln_colsum : bsrc;
+                const int ln_rmax = has_ln ? p.M - 1 : 0, ln_cmax = has_ln ? p.n_store - 1 : 0;
+                const bool use_bj = swap ? bias_j : has_ln;     // bjv: the per-feature bias of a V^T tile, or the per-row -mean rstd
+                float bjv[FJ], lnC[FJ];
 #pragma unroll
-                for (int fj = 0; fj < FJ; ++fj) bjv[fj] = bsrc[max(min(jb + fj * 16 + jl, p.n_store - 1), 0)];
+                for (int fj = 0; fj < FJ; ++fj) {
+                    const int j = jb + fj * 16 + jl;
+                    const float* pb = swap ? bsrc + max(min(j, p.n_store - 1), 0) : lnn + max(min(j, ln_rmax), 0);
+                    bjv[fj] = *pb;
+                    if constexpr (DTX3) {
+                        const float* pc = swap ? lns + max(min(j, ln_cmax), 0) : lnr + max(min(j, ln_rmax), 0);
+                        lnC[fj] = *pc;
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < FI / 2; ++g) {
                     const int ig = ib + g * 32;                 // first i (column n, or token m when swapped) of this 32-wide group
@@ -1454,26 +1474,48 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                         hdst = reinterpret_cast<char*>(head_dst_of(p, region));
                     }
                     const int xhalf = (ig >> 5) & 1;            // RoPE: columns 0-31 of a head rotate with the y position, 32-63 with x
-                    float4 bq[2];
+                    const bool use_bq = swap ? has_ln : bias_i; // bq: the per-column bias, or (V^T tiles) the -mean rstd of 4 consecutive tokens
+                    float4 bq[2], lnX[2];
 #pragma unroll
                     for (int fl = 0; fl < 2; ++fl) {
-                        const float4 t = *reinterpret_cast<const float4*>(bsrc + max(min(ig + fl * 16 + i4, p.n_store - 4), 0));
-                        bq[fl] = make_float4(bias_i ? t.x : 0.f, bias_i ? t.y : 0.f, bias_i ? t.z : 0.f, bias_i ? t.w : 0.f);
+                        const int i0 = ig + fl * 16 + i4;
+                        const float* pq = swap ? lnn + max(min(i0, ln_rmax - 3), 0) : bsrc + max(min(i0, p.n_store - 4), 0);
+                        const float4 t = *reinterpret_cast<const float4*>(pq);
+                        bq[fl] = make_float4(use_bq ? t.x : 0.f, use_bq ? t.y : 0.f, use_bq ? t.z : 0.f, use_bq ? t.w : 0.f);
+                        if constexpr (DTX3) {
+                            const float* px = swap ? lnr + max(min(i0, ln_rmax - 3), 0) : lns + max(min(i0, ln_cmax - 3), 0);
+                            lnX[fl] = *reinterpret_cast<const float4*>(px);
+                        }
                     }
                     float4 rt[2][2];   // RoPE table rows of this half of the head, double buffered across fragments
                     load_rope_half(rtab, r_ntok, r_tokw, r_M, jb + jl, i4, xhalf, rt[0]);
 #pragma unroll
                     for (int fj = 0; fj < FJ; ++fj) {
-                        const float bj = bias_j ? bjv[fj] : 0.f;
+                        const float bj = use_bj ? bjv[fj] : 0.f;
                         if (fj + 1 < FJ) load_rope_half(rtab, r_ntok, r_tokw, r_M, jb + (fj + 1) * 16 + jl, i4, xhalf, rt[(fj + 1) & 1]);
                         const float4 a0 = rt[fj & 1][0], a1 = rt[fj & 1][1];
                         const float cc[4] = {a0.x, a0.z, a1.x, a1.z}, ss[4] = {a0.y, a0.w, a1.y, a1.w};
                         float vals[2][4];
 #pragma unroll
                         for (int fl = 0; fl < 2; ++fl) {
-                            const float4 bi = swap ? make_float4(bj, bj, bj, bj) : bq[fl];
                             const f32x4_t a = acc[g * 2 + fl][fj];
+                            if constexpr (DTX3) {
+                                const float cj = has_ln ? lnC[fj] : (swap ? 0.f : 1.f);                 // S (swapped) or R
+                                const float4 X = lnX[fl];
+                                const float xd = swap ? 1.f : 0.f;                                      // no fold: R = 1 (swapped), S = 0
+                                const float x0 = has_ln ? X.x : xd, x1 = has_ln ? X.y : xd, x2 = has_ln ? X.z : xd, x3 = has_ln ? X.w : xd;
+                                const float4 q4 = bq[fl];
+                                if (swap) {      // fma(acc, R_i, fma(S_j, Nm_i, bias_j))
+                                    vals[fl][0] = __builtin_fmaf(a[0], x0, __builtin_fmaf(cj, q4.x, bj)); vals[fl][1] = __builtin_fmaf(a[1], x1, __builtin_fmaf(cj, q4.y, bj));
+                                    vals[fl][2] = __builtin_fmaf(a[2], x2, __builtin_fmaf(cj, q4.z, bj)); vals[fl][3] = __builtin_fmaf(a[3], x3, __builtin_fmaf(cj, q4.w, bj));
+                                } else {         // fma(acc, R_j, fma(S_i, Nm_j, bias_i))
+                                    vals[fl][0] = __builtin_fmaf(a[0], cj, __builtin_fmaf(x0, bj, q4.x)); vals[fl][1] = __builtin_fmaf(a[1], cj, __builtin_fmaf(x1, bj, q4.y));
+                                    vals[fl][2] = __builtin_fmaf(a[2], cj, __builtin_fmaf(x2, bj, q4.z)); vals[fl][3] = __builtin_fmaf(a[3], cj, __builtin_fmaf(x3, bj, q4.w));
+                                }
+                            } else {
+                            const float4 bi = swap ? make_float4(bj, bj, bj, bj) : bq[fl];
                             vals[fl][0] = a[0] + bi.x; vals[fl][1] = a[1] + bi.y; vals[fl][2] = a[2] + bi.z; vals[fl][3] = a[3] + bi.w;
+                            }
                         }
                         if (rope) {
 #pragma unroll
@@ -1579,6 +1621,15 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                         store16(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), nt);
                         if (p.out2) store4<O2DT>(p.out2, (size_t)m * p.ldo2 + n, v.x, v.y, v.z, v.w);
                     }
+                    if (p.ln_part) {    // folded LayerNorm: (sum, sum of squares) of the 32 stored values of row m in this column group (8 lanes x 4), one fixed tree
+                        float sm = (v.x + v.y) + (v.z + v.w);
+                        float sq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                        sm += __shfl_xor(sm, 1); sq += __shfl_xor(sq, 1);
+                        sm += __shfl_xor(sm, 2); sq += __shfl_xor(sq, 2);
+                        sm += __shfl_xor(sm, 4); sq += __shfl_xor(sq, 4);
+                        if (rch == 0 && m < p.M && n < p.n_store)
+                            *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * (p.n_store >> 5) + (ig >> 5)) * 2) = make_float2(sm, sq);
+                    }
                 }
                 asm volatile("" ::: "memory");
             }
@@ -1611,6 +1662,16 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                     const f32x4_t u = acc[hb * 2][fj], v = acc[hb * 2 + 1][fj];
                     float uu[4] = {u[0] + bu.x, u[1] + bu.y, u[2] + bu.z, u[3] + bu.w};
                     float vv[4] = {v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w};
+                    if constexpr (DTX3) {
+                        if (p.ln_rstd) {     // folded LayerNorm (kernels.hpp): rstd_m (acc - mean_m s_n) + b'_n
+                            const float rs = p.ln_rstd[m], nm = p.ln_nmr[m];
+                            const float4 su = *reinterpret_cast<const float4*>(p.ln_colsum + nh + i4), sv = *reinterpret_cast<const float4*>(p.ln_colsum + nh + 16 + i4);
+                            uu[0] = __builtin_fmaf(u[0], rs, __builtin_fmaf(su.x, nm, bu.x)); uu[1] = __builtin_fmaf(u[1], rs, __builtin_fmaf(su.y, nm, bu.y));
+                            uu[2] = __builtin_fmaf(u[2], rs, __builtin_fmaf(su.z, nm, bu.z)); uu[3] = __builtin_fmaf(u[3], rs, __builtin_fmaf(su.w, nm, bu.w));
+                            vv[0] = __builtin_fmaf(v[0], rs, __builtin_fmaf(sv.x, nm, bv.x)); vv[1] = __builtin_fmaf(v[1], rs, __builtin_fmaf(sv.y, nm, bv.y));
+                            vv[2] = __builtin_fmaf(v[2], rs, __builtin_fmaf(sv.z, nm, bv.z)); vv[3] = __builtin_fmaf(v[3], rs, __builtin_fmaf(sv.w, nm, bv.w));
+                        }
+                    }
                     if (rope) {
                         const int pos = half ? tx : ty;
                         const float4* cs = reinterpret_cast<const float4*>(p.rope_table + ((size_t)pos * 16 + i4) * 2);
@@ -1640,6 +1701,14 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                 if (m >= p.M) continue;
                 const f32x4_t a = acc[fi][fj];
                 float v0 = a[0] + bias.x, v1 = a[1] + bias.y, v2 = a[2] + bias.z, v3 = a[3] + bias.w;
+                if constexpr (DTX3) {
+                    if (p.ln_rstd) {         // folded LayerNorm (kernels.hpp): rstd_m (acc - mean_m s_n) + b'_n
+                        const float rs = p.ln_rstd[m], nm = p.ln_nmr[m];
+                        const float4 s4 = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+                        v0 = __builtin_fmaf(a[0], rs, __builtin_fmaf(s4.x, nm, bias.x)); v1 = __builtin_fmaf(a[1], rs, __builtin_fmaf(s4.y, nm, bias.y));
+                        v2 = __builtin_fmaf(a[2], rs, __builtin_fmaf(s4.z, nm, bias.z)); v3 = __builtin_fmaf(a[3], rs, __builtin_fmaf(s4.w, nm, bias.w));
+                    }
+                }
                 if constexpr (DTF8) {
                     // fp16 + fp8 launches come with EPI_F32 (+ residual, + split-fp16 typed copy) or GELU / plain activation rows only
                     // (launch_gemm checks); a lean body keeps these fully unrolled loops under the unroller's size cap -- past it the
@@ -1710,22 +1779,35 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         for (int fj = 0; fj < FJ; ++fj) {
             const int dd = (nb & 63) + fj * 16 + jl;
             const float bias = p.bias ? p.bias[nb + fj * 16 + jl] : 0.f;
+            float lns_j = 0.f;
+            if constexpr (DTX3) lns_j = p.ln_rstd ? p.ln_colsum[nb + fj * 16 + jl] : 0.f;
 #pragma unroll
             for (int fi = 0; fi < FI; ++fi) {
                 const int m = mb + fi * 16 + i4;
                 if (m >= p.M) continue;
-                const f32x4_t a = acc[fi][fj];
+                f32x4_t a = acc[fi][fj];
+                float badd = bias;
+                if constexpr (DTX3) {
+                    if (p.ln_rstd) {         // folded LayerNorm (kernels.hpp), the 4 consecutive tokens of this lane: fma(acc, rstd_m, fma(s_n, nmr_m, b'_n)), the wide route's expression
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int mm = min(m + r, p.M - 1);
+                            a[r] = __builtin_fmaf(a[r], p.ln_rstd[mm], __builtin_fmaf(lns_j, p.ln_nmr[mm], bias));
+                        }
+                        badd = 0.f;
+                    }
+                }
                 const int b = m / p.ntok, t = m - b * p.ntok;
                 const size_t rowbase = ((size_t)(b * p.heads + h) * 64 + dd) * p.ldv;
                 if (t + 3 < p.ntok && ((p.ldv | t) & 3) == 0) {
-                    store4<HDT>(dst, rowbase + t, a[0] + bias, a[1] + bias, a[2] + bias, a[3] + bias);
+                    store4<HDT>(dst, rowbase + t, a[0] + badd, a[1] + badd, a[2] + badd, a[3] + badd);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int mm = m + r;
                         if (mm >= p.M) break;
                         const int bb = mm / p.ntok, tt = mm - bb * p.ntok;
-                        store1<HDT>(dst, ((size_t)(bb * p.heads + h) * 64 + dd) * p.ldv + tt, a[r] + bias);
+                        store1<HDT>(dst, ((size_t)(bb * p.heads + h) * 64 + dd) * p.ldv + tt, a[r] + badd);
                     }
                 }
             }
@@ -1981,6 +2063,9 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     if (const char* e = getenv("D3R_GEMM_PANEL")) { const int v = atoi(e); if (v >= 1 && v <= 64) p.panel = v; }
     if (p.epi == EPI_HEADS && p.head_c % 128 != 0 && p.head_c < (1 << 29)) return hipErrorInvalidValue;
     if (p.epi == EPI_HEAD4 && (p.n_store > 128 || p.n_store % 4 != 0 || !p.res1 || !p.res2 || !p.out || !p.out2)) return hipErrorInvalidValue;
+    // folded LayerNorm (kernels.hpp): statistics come out of the wide fp32 epilogue only; the consumer side exists for split-fp16 operands, typed / GELU / head outputs
+    if (p.ln_part && (p.epi != EPI_F32 || (p.flags & GF_NOWIDE) || p.n_store % 32 != 0)) return hipErrorInvalidValue;
+    if (p.ln_rstd && (dt != D3R_F16X3 || !p.ln_nmr || !p.ln_colsum || p.amode != AMODE_LINEAR || !(p.epi == EPI_T || p.epi == EPI_GELU || p.epi == EPI_HEADS) || p.res1 || p.res2 || p.out2)) return hipErrorInvalidValue;
     // fp16 + fp8 rows: nn.Linear operands only, whole 64-element super-groups; outputs: fp32 (+ residual), GELU / plain activation rows, heads
     const bool f8rows = dt == D3R_F16F8 || dt == D3R_F16X2F8;
     if (f8rows && ((size_t)512 * p.lda * 4 >= (1ull << 32) || (size_t)512 * p.K * 5 >= (1ull << 32))) return hipErrorInvalidValue;   // 32-bit offsets inside a tile

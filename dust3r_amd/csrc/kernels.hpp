@@ -50,6 +50,17 @@ struct GemmParams {
     // issued / stores drained, then HW_ID, XCC_ID, blockIdx
     unsigned long long* trace = nullptr;
     PostMode post;               // EPI_HEAD4: depth_mode / conf_mode of the head's postprocess
+    // ---- LayerNorm folded into the GEMMs on both sides of it (round 5, split-fp16 engine; engine.hip `ln_fold`) ----------------------------
+    // LN(x) W^T + b = rstd (x (W diag(gamma))^T - mean s) + b',  s_n = sum_k gamma_k W_nk,  b' = b + W beta.
+    // PRODUCER (an EPI_F32 launch, wide epilogue): next to the fp32 rows it stores (and their typed copy out2 = the RAW x the consumer GEMM
+    //   reads as its activation operand) it writes ln_part[m][n / 32] = (sum, sum of squares) of the 32 stored values of row m in that column
+    //   group, summed in ONE fixed tree whatever the tile shape (quad sums, then xor 1 / 2 / 4 over the 8 quads) -- so the statistics, like every
+    //   output, do not depend on the tile configuration. n_store % 32 == 0.
+    // CONSUMER (weights = W diag(gamma) packed at load time, bias = b'): every epilogue forms rstd_m (acc - mean_m s_n) + b'_n as
+    //   fma(acc, ln_rstd[m], fma(ln_colsum[n], ln_nmr[m], bias[n])) with ln_nmr = -mean rstd; with ln_rstd == nullptr the same expression
+    //   runs on (1, 0, 0): fma(acc, 1, fma(0, 0, b)) = acc + b bit for bit.
+    float* ln_part = nullptr;
+    const float* ln_rstd = nullptr; const float* ln_nmr = nullptr; const float* ln_colsum = nullptr;
     int f8_proxy = 0;            // MEASUREMENT AID (D3R_F8_PROXY=1, results INVALID): fp16 + fp8 K loop with the MFMA mix of a 2.5-unit scheme (4 f16 + 1/2 fp8 MFMA per 64 k)
 };
 void gemm_set_trace(unsigned long long* buf, size_t capacity_blocks);
@@ -91,6 +102,12 @@ hipError_t launch_head_final(int dt, const void* feat, int C, const float* w, co
 hipError_t launch_linear_head_post(const float* feat, float* pts, float* conf, int B, int th, int tw, int ps, int pstride, int cstride,
                                    PostMode post, hipStream_t s);
 hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+// folded LayerNorm (GemmParams::ln_part): per row, the G = C / 32 partial (sum, sum of squares) pairs of the producing GEMM -> rstd[m] and
+// nmr[m] = -mean rstd (fixed summation order; variance = E[x^2] - mean^2 combined in fp64, eps inside the root like nn.LayerNorm)
+hipError_t launch_ln_finalize(const float* part, int rows, int C, float eps, float* rstd, float* nmr, hipStream_t s);
+// load-time fold of a LayerNorm into the nn.Linear that consumes it: for each of the N rows of W (fp32 [N][K]): colsum[n] = sum_k r(gamma_k W_nk)
+// with r() the rounding of the packed operand type (split-fp16: hi + lo), bias_out[n] = bias_in[n] (or 0) + sum_k beta_k W_nk; fp64 sums
+hipError_t launch_ln_fold_vectors(int dt, const float* W, const float* gamma, const float* beta, const float* bias_in, float* colsum, float* bias_out, int N, int K, hipStream_t s);
 
 // load-time weight packing on the device (fp32 PyTorch-layout source -> engine layout in DT)
 enum { PACK_MAT = 0, PACK_CONV = 1, PACK_CONVT = 2 };
@@ -99,6 +116,7 @@ struct PackParams {
     size_t numel = 0;
     int kind = PACK_MAT, cols = 0, row_off = 0, dst_cols = 0, cin = 0, cin_pad = 0, ksize = 1, cout_pad = 0;
     int kslice_major = 0;        // PACK_CONV: K order of the packed rows (conv_k_slice_major())
+    const float* kscale = nullptr;   // PACK_MAT: multiply column k of the source by kscale[k] before the conversion (LayerNorm gamma folded into the weights)
 };
 bool conv_k_slice_major();       // process-wide K order of implicit-GEMM operands (kernel and weight packing agree on it)
 hipError_t launch_pack_weight(int dt, const PackParams& p, hipStream_t s);

@@ -603,3 +603,116 @@ def test_pairs_of_two_image_sizes(gpu, precision, hw1, hw2):
     assert isinstance(out['pred1']['pts3d'], list) and len(out['pred1']['pts3d']) == 2
     assert out['pred2']['pts3d_in_other_view'][0].shape[-3:-1] == hw2 and out['pred2']['pts3d_in_other_view'][1].shape[-3:-1] == hw1
     assert torch.equal(out['pred1']['pts3d'][0].reshape(hw1 + (3,)), e1['pts3d'][0].cpu())
+
+
+# ---- LayerNorm folded into the GEMMs around it (round 5, D3R_LN_FOLD=1 at engine creation) --------------------------------------------------
+def _randomize_norms(model, seed, gain=0.3, shift=0.2):
+    """every LayerNorm weight 1 + gain N(0, 1), every LayerNorm bias shift N(0, 1): the fold moves gamma into the following matrix and beta into
+    its bias, so the test weights must not be the identity affine"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if 'norm' in name and prm.ndim == 1:
+                if name.endswith('weight'):
+                    prm.copy_(1 + gain * torch.randn(prm.shape, generator=g))
+                else:
+                    prm.copy_(shift * torch.randn(prm.shape, generator=g))
+    return model
+
+
+def _fold_engines(oracle, config, gpu, monkeypatch):
+    monkeypatch.setenv('D3R_LN_FOLD', '0')
+    plain = engine_from_oracle(oracle, config, 'fp16x3', gpu)
+    monkeypatch.setenv('D3R_LN_FOLD', '1')
+    folded = engine_from_oracle(oracle, config, 'fp16x3', gpu)
+    return plain, folded
+
+
+@pytest.mark.parametrize('config,B,H,W', [('tiny_dpt', 2, 32, 48), ('tiny_dpt', 1, 64, 64), ('tiny_dpt', 3, 128, 128), ('tiny_dpt', 2, 64, 96), ('tiny_linear', 3, 32, 32),
+                                          ('tiny_linear', 1, 224, 224), ('tiny_dpt', 1, 128, 256)])
+def test_layernorm_fold_matches_oracle_and_the_unfolded_engine(gpu, config, B, H, W, monkeypatch):
+    """norm1 / norm2 (encoder) and norm1 / norm2 / norm3 / norm_y (decoder) folded into the GEMMs around them: LN(x) W^T + b = rstd (x (W diag(gamma))^T -
+    mean s) + b'. The producer's fp32-residual epilogue stores the raw typed rows and per-row partial sums, the consumer's epilogue applies rstd / mean
+    (csrc/kernels.hpp GemmParams::ln_*). Random gamma / beta. Held to the default engine's bar against the CPU oracle, within 5e-5 of the engine
+    that launches the LayerNorm kernels, and -- token counts 6 .. 512, i.e. both the LDS-staged and the direct epilogue routes, q / k / V^T regions --
+    a batch bit-equal to its one-pair calls."""
+    from oracle.dust3r_ref import build_ref_model
+    oracle = _randomize_norms(build_ref_model(config), seed=H * 3 + W)
+    plain, folded = _fold_engines(oracle, config, gpu, monkeypatch)
+    v1, v2 = synthetic_views(B, H, W, seed=H + W)
+    compare(folded, oracle, v1, v2, *TOLS['fp16x3'], tag=f'{config} LN-fold {B}x{H}x{W}')
+    a1, a2 = plain(v1, v2)
+    b1, b2 = folded(v1, v2)
+    for x, y in ((a1['pts3d'], b1['pts3d']), (a2['pts3d_in_other_view'], b2['pts3d_in_other_view'])):
+        mx, mean = pix_rel(y, x.cpu())
+        print(f'[{config} {B}x{H}x{W}] folded vs LayerNorm kernels: max {mx:.3e} mean {mean:.3e}')
+        assert mx < 5e-5 and mean < 5e-6
+    assert float(((b1['conf'] - a1['conf']).abs() / a1['conf']).max()) < 5e-5
+    if B > 1:
+        for k in range(B):
+            s1 = dict(img=v1['img'][k:k + 1], true_shape=v1['true_shape'][k:k + 1], idx=[0], instance=['0'])
+            s2 = dict(img=v2['img'][k:k + 1], true_shape=v2['true_shape'][k:k + 1], idx=[1], instance=['1'])
+            o1, o2 = folded(s1, s2)
+            assert torch.equal(o1['pts3d'][0], b1['pts3d'][k]) and torch.equal(o2['pts3d_in_other_view'][0], b2['pts3d_in_other_view'][k]) and torch.equal(o2['conf'][0], b2['conf'][k])
+
+
+def test_layernorm_fold_is_tile_independent_and_handles_two_image_sizes(gpu, monkeypatch):
+    """The row statistics are summed in one fixed tree per 32-column group whatever tile produced them: with the GEMM tile pinned (128 x 128, 256 x 256,
+    the two-blocks-per-CU 256 x 128, 64 x 64, 384 x 192; infeasible pins fall back per launch) the folded engine's outputs are BIT-identical. Pairs of two
+    image sizes (the other view's statistics feed norm_y with Nq != Nk) against the oracle."""
+    from oracle.dust3r_ref import build_ref_model
+    oracle = _randomize_norms(build_ref_model('tiny_dpt'), seed=11)
+    monkeypatch.setenv('D3R_LN_FOLD', '1')
+    eng = engine_from_oracle(oracle, 'tiny_dpt', 'fp16x3', gpu)
+    v1, v2 = synthetic_views(3, 128, 128, seed=9)
+    outs = []
+    for cfg in ('', '0', '1', '7', '8', '9'):
+        if cfg:
+            monkeypatch.setenv('D3R_GEMM_CFG', cfg)
+        e1, e2 = eng(v1, v2)
+        outs.append((e1['pts3d'].clone(), e2['pts3d_in_other_view'].clone(), e2['conf'].clone()))
+    monkeypatch.delenv('D3R_GEMM_CFG')
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+    g = torch.Generator().manual_seed(3)
+    for hw1, hw2 in (((32, 48), (48, 32)), ((64, 64), (32, 48)), ((64, 128), (128, 128))):
+        w1 = dict(img=torch.rand((2, 3) + hw1, generator=g) * 2 - 1, true_shape=torch.tensor([hw1] * 2, dtype=torch.int32), idx=[0, 2], instance=['0', '2'])
+        w2 = dict(img=torch.rand((2, 3) + hw2, generator=g) * 2 - 1, true_shape=torch.tensor([hw2] * 2, dtype=torch.int32), idx=[1, 3], instance=['1', '3'])
+        compare(eng, oracle, w1, w2, *TOLS['fp16x3'], tag=f'tiny_dpt LN-fold {hw1} + {hw2}')
+
+
+def test_layernorm_fold_full_size_against_oracle(gpu, monkeypatch):
+    """BASELINE model with random LayerNorm affines, one 512x384 pair: the folded engine against the CPU oracle at the north-star bar (per-pixel max
+    <= 1e-3, mean <= 5e-5) and against the engine with LayerNorm kernels; four pairs per call bit-equal to one-pair calls; encode / decode entry points."""
+    from oracle import tune_threads
+    from oracle.dust3r_ref import build_ref_model_fast
+    tune_threads()
+    cfg = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
+    oracle = _randomize_norms(build_ref_model_fast(cfg, seed=4), seed=21)
+    v1, v2 = synthetic_views(1, 384, 512, seed=14)
+    with torch.no_grad():
+        r1, r2 = oracle(v1, v2)
+    plain, folded = _fold_engines(oracle, cfg, gpu, monkeypatch)
+    res = {}
+    for name, eng in (('LayerNorm kernels', plain), ('folded', folded)):
+        e1, e2 = eng(v1, v2)
+        res[name] = torch.cat((e1['pts3d'], e2['pts3d_in_other_view'])).cpu()
+        mx, mean = pix_rel(res[name], torch.cat((r1['pts3d'], r2['pts3d_in_other_view'])))
+        print(f'[512_dpt random LN affines, {name} vs CPU oracle] max {mx:.3e} mean {mean:.3e}')
+        assert mx < 1e-3 and mean < 5e-5
+        assert float(((e1['conf'].cpu() - r1['conf']).abs() / r1['conf']).max()) < 3e-3
+    mx, mean = pix_rel(res['folded'], res['LayerNorm kernels'])
+    print(f'[512_dpt folded vs LayerNorm kernels] max {mx:.3e} mean {mean:.3e}')
+    assert mx < 2e-4 and mean < 1e-5
+    plain._destroy_engine()
+    w1, w2 = synthetic_views(4, 384, 512, seed=15, device=gpu)
+    b1, b2 = folded(w1, w2)
+    for k in (0, 3):
+        s1 = dict(img=w1['img'][k:k + 1], true_shape=w1['true_shape'][k:k + 1], idx=[0], instance=['0'])
+        s2 = dict(img=w2['img'][k:k + 1], true_shape=w2['true_shape'][k:k + 1], idx=[1], instance=['1'])
+        o1, o2 = folded(s1, s2)
+        assert torch.equal(o1['pts3d'][0], b1['pts3d'][k]) and torch.equal(o2['pts3d_in_other_view'][0], b2['pts3d_in_other_view'][k])
+    feat = folded.encode_images(torch.cat((w1['img'], w2['img'])))
+    d1, d2 = folded.decode_pairs(feat, 384, 512)
+    assert torch.equal(d1['pts3d'], b1['pts3d']) and torch.equal(d2['conf'], b2['conf'])
+    folded._destroy_engine()
