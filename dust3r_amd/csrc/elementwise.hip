@@ -10,7 +10,8 @@ namespace d3r {
 // ------------------------------------------------------------------------------ LayerNorm
 // croco blocks use nn.LayerNorm(eps=1e-6) on the fp32 residual stream (oracle/croco_ref/models/
 // croco.py); one wave per row, row kept in registers, two-pass mean / variance like ATen.
-template <int DT>
+// X3IN: the input rows are split-fp16 rows (the residual stream of a folded-LayerNorm engine, kernels.hpp GF_X3RES) instead of fp32
+template <int DT, bool X3IN = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ out, int rows,
                                                         int C, float eps) {
@@ -26,6 +27,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
+            if constexpr (X3IN) v[i] = load4<D3R_F16X3>(x, (size_t)row * C + 4 * (size_t)c);
+            else
             v[i] = xr[c];
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         } else {
@@ -59,6 +62,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+hipError_t launch_layernorm_x3in(const void* x3rows, const float* gamma, const float* beta, void* out, int rows, int C, float eps, hipStream_t s) {
+    if (C % 8 != 0 || C > 2048 || rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((layernorm_kernel<D3R_F16X3, true>), dim3(cdiv(rows, 4)), dim3(256), 0, s, reinterpret_cast<const float*>(x3rows), gamma, beta, out, rows, C, eps);
+    return hipGetLastError();
+}
 hipError_t launch_layernorm(int dt, const float* x, const float* gamma, const float* beta, void* out, int rows, int C,
                             float eps, hipStream_t s) {
     if (C % 4 != 0 || C > 2048 || rows <= 0) return hipErrorInvalidValue;

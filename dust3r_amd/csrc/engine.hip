@@ -857,18 +857,22 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                     // every fp32-residual epilogue also stores the raw typed rows (xn) and their partial sums; the LayerNorm itself is two fmas in
                     // the epilogue of the nn.Linear behind it (weights packed as W diag(gamma)): 2 x enc_depth LayerNorm launches become
                     // 2 x enc_depth row-statistics launches of 1 / 64 the traffic
+                    // The residual stream itself lives in those typed rows (GF_X3RES: xn is read as the residual and rewritten in place, 22
+                    // significand bits -- what every LayerNorm output was rounded to anyway); no fp32 row is stored in the blocks.
                     const LnStats es{e_rs, e_nm};
-                    gemm_linear(c, hb, (int)pk, m->patch, Mp, EPI_F32, xp, Ce, nullptr, xn, Ce, -1, 0, LnStats(), e_part);
+                    gemm_linear(c, hb, (int)pk, m->patch, Mp, EPI_F32, nullptr, Ce, nullptr, xn, Ce, -1, GF_X3RES, LnStats(), e_part);
                     for (int l = 0; l < cf.enc_depth; ++l) {
                         const EncBlk& b = m->enc[l];
-                        const bool last = l + 1 == cf.enc_depth;        // enc_norm (a kernel) reads the fp32 rows: no typed copy, no sums
+                        const bool last = l + 1 == cf.enc_depth;        // enc_norm (a kernel) follows: no sums
                         D3R_OTHER(launch_ln_finalize(e_part, Mp, Ce, 1e-6f, e_rs, e_nm, st));
                         self_attention(c, xn, b.qkv, Mp, Ce, He, n_img, dd.N, dd.tw, dd.ldv, q, k, vt, ao, es);
-                        gemm_linear(c, ao, Ce, b.proj, Mp, EPI_F32, xp, Ce, xp, xn, Ce, -1, 0, LnStats(), e_part);
+                        gemm_linear(c, ao, Ce, b.proj, Mp, EPI_F32, nullptr, Ce, xn, xn, Ce, -1, GF_X3RES, LnStats(), e_part);
                         D3R_OTHER(launch_ln_finalize(e_part, Mp, Ce, 1e-6f, e_rs, e_nm, st));
                         gemm_linear(c, xn, Ce, b.fc1, Mp, EPI_GELU, hb, 4 * Ce, nullptr, nullptr, 0, -1, 0, es);
-                        gemm_linear(c, hb, 4 * Ce, b.fc2, Mp, EPI_F32, xp, Ce, xp, last ? nullptr : xn, Ce, -1, 0, LnStats(), last ? nullptr : e_part);
+                        gemm_linear(c, hb, 4 * Ce, b.fc2, Mp, EPI_F32, nullptr, Ce, xn, xn, Ce, -1, GF_X3RES, LnStats(), last ? nullptr : e_part);
                     }
+                    D3R_OTHER(launch_layernorm_x3in(xn, m->enc_norm.g, m->enc_norm.b, (char*)encn + row0 * Ce * eb, Mp, Ce, 1e-6f, st));
+                    continue;
                 } else {
                 gemm_linear(c, hb, (int)pk, m->patch, Mp, EPI_F32, xp, Ce);
                 for (int l = 0; l < cf.enc_depth; ++l) {
@@ -889,7 +893,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
         // ---- decoder (model.py:172-191): side s reads the PREVIOUS layer's (f_s, f_other) ---------------------
         void* frp[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // fold: raw typed copy of layer output [buffer][side] (fr, or a DPT hook buffer at the hook layers)
         if (fold) {
-            gemm_linear(c, encn, Ce, m->dec_embed, M2d, EPI_F32, f[0], Cd, nullptr, fr[0], Cd, -1, 0, LnStats(), l_part[0]);
+            gemm_linear(c, encn, Ce, m->dec_embed, M2d, EPI_F32, nullptr, Cd, nullptr, fr[0], Cd, -1, GF_X3RES, LnStats(), l_part[0]);
             D3R_OTHER(launch_ln_finalize(l_part[0], M2d, Cd, 1e-6f, l_rs[0], l_nm[0], st));
             for (int sd = 0; sd < 2; ++sd) frp[0][sd] = (char*)fr[0] + (size_t)Roff[sd] * Cd * eb;
         } else {
@@ -921,7 +925,9 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                 if (fold) {
                     const LnStats sx{l_rs[cur] + Roff[s], l_nm[cur] + Roff[s]}, sy{l_rs[cur] + Roff[1 - s], l_nm[cur] + Roff[1 - s]}, ss{s_rs[s], s_nm[s]};
                     self_attention(c, frp[cur][s], b.qkv, Ms[s], Cd, Hd, B, own.N, own.tw, own.ldv, sq, sk, svt, sao, sx);      // norm1 folded
-                    gemm_linear(c, sao, Cd, b.proj, Ms[s], EPI_F32, xw, Cd, xo, sxn, Cd, -1, 0, LnStats(), s_part[s]);
+                    // the residual stream is the typed rows themselves (GF_X3RES): layer input frp[cur][s] -> sxn (after self attention, then in place after
+                    // cross attention) -> the next layer's input fr[cur ^ 1] (or a DPT hook buffer)
+                    gemm_linear(c, sao, Cd, b.proj, Ms[s], EPI_F32, nullptr, Cd, frp[cur][s], sxn, Cd, -1, GF_X3RES, LnStats(), s_part[s]);
                     D3R_OTHER(launch_ln_finalize(s_part[s], Ms[s], Cd, 1e-6f, s_rs[s], s_nm[s], c.st));
                     {
                         const int kq[1] = {HEAD_ROPE};
@@ -936,19 +942,17 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                         c.mark(PRF_ATTN, 4.0 * B * Hd * (double)own.N * oth.N * 64, B * Hd, own.N, oth.N);
                         c.chk(launch_attention(m->dt, a, c.st));
                     }
-                    gemm_linear(c, sao, Cd, b.cproj, Ms[s], EPI_F32, xw, Cd, xw, sxn, Cd, -1, 0, LnStats(), s_part[s]);
+                    gemm_linear(c, sao, Cd, b.cproj, Ms[s], EPI_F32, nullptr, Cd, sxn, sxn, Cd, -1, GF_X3RES, LnStats(), s_part[s]);
                     D3R_OTHER(launch_ln_finalize(s_part[s], Ms[s], Cd, 1e-6f, s_rs[s], s_nm[s], c.st));
                     gemm_linear(c, sxn, Cd, b.fc1, Ms[s], EPI_GELU, shb, 4 * Cd, nullptr, nullptr, 0, -1, 0, ss);                 // norm3 folded
                     const int layer_no = l + 1;
                     void* hcopy = (cf.head_type == 1 && (layer_no == hk6 || layer_no == hk9)) ? hook[s][layer_no == hk6 ? 0 : 1] : nullptr;
-                    if (layer_no == cf.dec_depth) {      // dec_norm (a kernel) reads the fp32 rows
-                        gemm_linear(c, shb, 4 * Cd, b.fc2, Ms[s], EPI_F32, xw, Cd, xw, hcopy, Cd);
-                    } else {                             // the raw typed copy of the layer output IS a DPT hook at the hook layers
-                        void* raw = hcopy ? hcopy : (void*)((char*)fr[cur ^ 1] + (size_t)Roff[s] * Cd * eb);
-                        gemm_linear(c, shb, 4 * Cd, b.fc2, Ms[s], EPI_F32, xw, Cd, xw, raw, Cd, -1, 0, LnStats(), l_part[cur ^ 1] + (size_t)Roff[s] * Gd * 2);
-                        D3R_OTHER(launch_ln_finalize(l_part[cur ^ 1] + (size_t)Roff[s] * Gd * 2, Ms[s], Cd, 1e-6f, l_rs[cur ^ 1] + Roff[s], l_nm[cur ^ 1] + Roff[s], c.st));
-                        frp[cur ^ 1][s] = raw;
-                    }
+                    // the typed layer output IS a DPT hook at the hook layers; after the last layer dec_norm (a kernel) follows: no sums
+                    void* raw = hcopy ? hcopy : (void*)((char*)fr[cur ^ 1] + (size_t)Roff[s] * Cd * eb);
+                    float* lp = layer_no == cf.dec_depth ? nullptr : l_part[cur ^ 1] + (size_t)Roff[s] * Gd * 2;
+                    gemm_linear(c, shb, 4 * Cd, b.fc2, Ms[s], EPI_F32, nullptr, Cd, sxn, raw, Cd, -1, GF_X3RES, LnStats(), lp);
+                    if (lp) D3R_OTHER(launch_ln_finalize(lp, Ms[s], Cd, 1e-6f, l_rs[cur ^ 1] + Roff[s], l_nm[cur ^ 1] + Roff[s], c.st));
+                    frp[cur ^ 1][s] = raw;
                     continue;
                 }
                 D3R_OTHER(launch_layernorm(m->bdt, xo, b.n1.g, b.n1.b, sxn, Ms[s], Cd, 1e-6f, c.st));
@@ -986,6 +990,8 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
         for (int s = 0; s < 2; ++s) {
             c.st = S[s];
             const SideDim& own = D[s];
+            if (fold) D3R_OTHER(launch_layernorm_x3in(frp[cur][s], m->dec_norm.g, m->dec_norm.b, hook[s][2], Ms[s], Cd, 1e-6f, c.st));
+            else
             D3R_OTHER(launch_layernorm(m->dt, f[cur] + (size_t)Roff[s] * Cd, m->dec_norm.g, m->dec_norm.b, hook[s][2], Ms[s], Cd, 1e-6f, c.st));
             if (cf.head_type == 0) {
                 float* lo = lin_out + (size_t)Roff[s] * 4 * ps * ps;

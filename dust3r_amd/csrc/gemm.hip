@@ -1571,68 +1571,91 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
         }
         if (wide32) {
             const bool has_res = p.res1 != nullptr, has_bias = p.bias != nullptr;
-            // without a residual the same addresses of the (fp32, same shape) output are read and discarded: no branch, no PHI
-            const float* rsrc = has_res ? reinterpret_cast<const float*>(p.res1) : reinterpret_cast<const float*>(p.out);
-            const int rld = has_res ? p.ldr : p.ldo;
             const float* bsrc = has_bias ? p.bias : reinterpret_cast<const float*>(p.wgt);
-            // The residual rows a lane adds in the read phase of group g are requested one group AHEAD (double buffered): the per-block
-            // trace (tools/gpu_probe.py gemmtrace) showed this epilogue as four serial HBM round trips, ~19 us per 256 x 256 tile.
-            // In place (res1 == out) is fine: a lane reads exactly the elements it stores later, and group g + 1's columns are
-            // disjoint from the columns group g is storing.
-            float4 rr[2][RP];
-            auto request_rows = [&](int g, float4 (&dst)[RP]) __attribute__((always_inline)) {
-                const int ig = ib + g * 32;
+            // GF_X3RES (split-fp16 launches; the folded-LayerNorm engine, kernels.hpp): the residual stream lives in split-fp16 rows ONLY -- res1 is read
+            // as typed rows (8 + 8 bytes per 4 elements), out2 receives the typed sum, no fp32 row is stored. The two forms are two instances of
+            // one body so that no load feeds a PHI (see the note on conditional reads above).
+            auto body = [&](auto x3c) __attribute__((always_inline)) {
+                constexpr bool X3R = decltype(x3c)::value;
+                using TXR = Traits<D3R_F16X3>;
+                // without a residual the same addresses of the (same shape) output are read and discarded: no branch, no PHI
+                const char* rsrc = X3R ? reinterpret_cast<const char*>(has_res ? p.res1 : (const void*)p.out2)
+                                       : reinterpret_cast<const char*>(has_res ? p.res1 : (const void*)p.out);
+                const int rld = has_res ? p.ldr : (X3R ? p.ldo2 : p.ldo);
+                // The residual rows a lane adds in the read phase of group g are requested one group AHEAD (double buffered): the per-block
+                // trace (tools/gpu_probe.py gemmtrace) showed this epilogue as four serial HBM round trips, ~19 us per 256 x 256 tile.
+                // In place (res1 == out / out2) is fine: a lane reads exactly the elements it stores later, and group g + 1's columns are
+                // disjoint from the columns group g is storing.
+                float4 rr[2][RP];
+                auto request_rows = [&](int g, float4 (&dst)[RP]) __attribute__((always_inline)) {
+                    const int ig = ib + g * 32;
 #pragma unroll
-                for (int pass = 0; pass < RP; ++pass) {
-                    const int m = min(jb + pass * 8 + rrow, p.M - 1), n = max(min(ig + rch * 4, p.n_store - 4), 0);
-                    dst[pass] = *reinterpret_cast<const float4*>(rsrc + (size_t)m * rld + n);
+                    for (int pass = 0; pass < RP; ++pass) {
+                        const int m = min(jb + pass * 8 + rrow, p.M - 1), n = max(min(ig + rch * 4, p.n_store - 4), 0);
+                        if constexpr (X3R) {     // raw (hi x4, lo x4) of the 4 elements: joined when they are added
+                            const char* q = rsrc + TXR::boff((size_t)m * rld + n);
+                            const uint2 h = *reinterpret_cast<const uint2*>(q), l = *reinterpret_cast<const uint2*>(q + 16);
+                            dst[pass] = make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
+                        } else {
+                            dst[pass] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rsrc) + (size_t)m * rld + n);
+                        }
+                    }
+                };
+                request_rows(0, rr[0]);
+#pragma unroll
+                for (int g = 0; g < FI / 2; ++g) {
+                    const int ig = ib + g * 32;
+                    if (g + 1 < FI / 2) request_rows(g + 1, rr[(g + 1) & 1]);
+                    float4 bi2[2];
+#pragma unroll
+                    for (int fl = 0; fl < 2; ++fl) {
+                        const float4 t = *reinterpret_cast<const float4*>(bsrc + max(min(ig + fl * 16 + i4, p.n_store - 4), 0));
+                        bi2[fl] = make_float4(has_bias ? t.x : 0.f, has_bias ? t.y : 0.f, has_bias ? t.z : 0.f, has_bias ? t.w : 0.f);
+                    }
+#pragma unroll
+                    for (int fl = 0; fl < 2; ++fl) {
+                        const float4 bi = bi2[fl];
+#pragma unroll
+                        for (int fj = 0; fj < FJ; ++fj) {
+                            const f32x4_t a = acc[g * 2 + fl][fj];
+                            *reinterpret_cast<float4*>(wreg + (fj * 16 + jl) * WROW + (fl * 16 + i4) * 4) = make_float4(a[0] + bi.x, a[1] + bi.y, a[2] + bi.z, a[3] + bi.w);
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int pass = 0; pass < RP; ++pass) {
+                        const int row = pass * 8 + rrow;
+                        float4 v = *reinterpret_cast<const float4*>(wreg + row * WROW + rch * 16);
+                        const int m = jb + row, n = ig + rch * 4;
+                        float4 rv = rr[g & 1][pass];
+                        if constexpr (X3R) {
+                            const uint32_t hx = __float_as_uint(rv.x), hy = __float_as_uint(rv.y), lx = __float_as_uint(rv.z), ly = __float_as_uint(rv.w);
+                            rv = make_float4(TXR::join_lo(hx, lx), TXR::join_hi(hx, lx), TXR::join_lo(hy, ly), TXR::join_hi(hy, ly));
+                        }
+                        v.x += has_res ? rv.x : 0.f; v.y += has_res ? rv.y : 0.f;
+                        v.z += has_res ? rv.z : 0.f; v.w += has_res ? rv.w : 0.f;
+                        if (m < p.M && n < p.n_store) {
+                            if constexpr (!X3R)
+                                store16(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), nt);
+                            if (X3R || p.out2) store4<O2DT>(p.out2, (size_t)m * p.ldo2 + n, v.x, v.y, v.z, v.w);
+                        }
+                        if (p.ln_part) {    // folded LayerNorm: (sum, sum of squares) of the 32 stored values of row m in this column group (8 lanes x 4), one fixed tree
+                            float sm = (v.x + v.y) + (v.z + v.w);
+                            float sq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                            sm += __shfl_xor(sm, 1); sq += __shfl_xor(sq, 1);
+                            sm += __shfl_xor(sm, 2); sq += __shfl_xor(sq, 2);
+                            sm += __shfl_xor(sm, 4); sq += __shfl_xor(sq, 4);
+                            if (rch == 0 && m < p.M && n < p.n_store)
+                                *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * (p.n_store >> 5) + (ig >> 5)) * 2) = make_float2(sm, sq);
+                        }
+                    }
+                    asm volatile("" ::: "memory");
                 }
             };
-            request_rows(0, rr[0]);
-#pragma unroll
-            for (int g = 0; g < FI / 2; ++g) {
-                const int ig = ib + g * 32;
-                if (g + 1 < FI / 2) request_rows(g + 1, rr[(g + 1) & 1]);
-                float4 bi2[2];
-#pragma unroll
-                for (int fl = 0; fl < 2; ++fl) {
-                    const float4 t = *reinterpret_cast<const float4*>(bsrc + max(min(ig + fl * 16 + i4, p.n_store - 4), 0));
-                    bi2[fl] = make_float4(has_bias ? t.x : 0.f, has_bias ? t.y : 0.f, has_bias ? t.z : 0.f, has_bias ? t.w : 0.f);
-                }
-#pragma unroll
-                for (int fl = 0; fl < 2; ++fl) {
-                    const float4 bi = bi2[fl];
-#pragma unroll
-                    for (int fj = 0; fj < FJ; ++fj) {
-                        const f32x4_t a = acc[g * 2 + fl][fj];
-                        *reinterpret_cast<float4*>(wreg + (fj * 16 + jl) * WROW + (fl * 16 + i4) * 4) = make_float4(a[0] + bi.x, a[1] + bi.y, a[2] + bi.z, a[3] + bi.w);
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int pass = 0; pass < RP; ++pass) {
-                    const int row = pass * 8 + rrow;
-                    float4 v = *reinterpret_cast<const float4*>(wreg + row * WROW + rch * 16);
-                    const int m = jb + row, n = ig + rch * 4;
-                    const float4 rv = rr[g & 1][pass];
-                    v.x += has_res ? rv.x : 0.f; v.y += has_res ? rv.y : 0.f;
-                    v.z += has_res ? rv.z : 0.f; v.w += has_res ? rv.w : 0.f;
-                    if (m < p.M && n < p.n_store) {
-                        store16(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), nt);
-                        if (p.out2) store4<O2DT>(p.out2, (size_t)m * p.ldo2 + n, v.x, v.y, v.z, v.w);
-                    }
-                    if (p.ln_part) {    // folded LayerNorm: (sum, sum of squares) of the 32 stored values of row m in this column group (8 lanes x 4), one fixed tree
-                        float sm = (v.x + v.y) + (v.z + v.w);
-                        float sq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-                        sm += __shfl_xor(sm, 1); sq += __shfl_xor(sq, 1);
-                        sm += __shfl_xor(sm, 2); sq += __shfl_xor(sq, 2);
-                        sm += __shfl_xor(sm, 4); sq += __shfl_xor(sq, 4);
-                        if (rch == 0 && m < p.M && n < p.n_store)
-                            *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * (p.n_store >> 5) + (ig >> 5)) * 2) = make_float2(sm, sq);
-                    }
-                }
-                asm volatile("" ::: "memory");
+            if constexpr (DTX3) {
+                if (p.flags & GF_X3RES) { body(std::true_type{}); return; }
             }
+            body(std::false_type{});
             return;
         }
     }
@@ -2065,6 +2088,7 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     if (p.epi == EPI_HEAD4 && (p.n_store > 128 || p.n_store % 4 != 0 || !p.res1 || !p.res2 || !p.out || !p.out2)) return hipErrorInvalidValue;
     // folded LayerNorm (kernels.hpp): statistics come out of the wide fp32 epilogue only; the consumer side exists for split-fp16 operands, typed / GELU / head outputs
     if (p.ln_part && (p.epi != EPI_F32 || (p.flags & GF_NOWIDE) || p.n_store % 32 != 0)) return hipErrorInvalidValue;
+    if ((p.flags & GF_X3RES) && (dt != D3R_F16X3 || p.epi != EPI_F32 || (p.flags & GF_NOWIDE) || !p.out2 || (p.ldo2 & 7) || (p.res1 && (p.ldr & 7)))) return hipErrorInvalidValue;
     if (p.ln_rstd && (dt != D3R_F16X3 || !p.ln_nmr || !p.ln_colsum || p.amode != AMODE_LINEAR || !(p.epi == EPI_T || p.epi == EPI_GELU || p.epi == EPI_HEADS) || p.res1 || p.res2 || p.out2)) return hipErrorInvalidValue;
     // fp16 + fp8 rows: nn.Linear operands only, whole 64-element super-groups; outputs: fp32 (+ residual), GELU / plain activation rows, heads
     const bool f8rows = dt == D3R_F16F8 || dt == D3R_F16X2F8;
