@@ -472,9 +472,11 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     m->cfg = *cfg; m->dt = f8blocks ? D3R_F16X3 : cfg->dtype; m->bdt = f8blocks ? cfg->dtype : m->dt;
     m->ktile = 128 / (int)dt_bytes(m->dt);
     {   // LayerNorm folded into the neighbouring GEMMs (see d3r_model::ln_fold): split-fp16 engines, every channel count a multiple of 32
+        // default ON since round 5 (same-box A/B of two engines in one process, tools/fold_probe.py, profiles/r05_d: 168.8 -> 164.9 ms per 32-pair forward,
+        // "other" kernels 11.9 -> 5.3 ms, nn.Linear launches +1.8 ms); D3R_LN_FOLD=0: LayerNorm kernels and an fp32 residual stream (rounds 1-4)
         const char* e = getenv("D3R_LN_FOLD");
-        const bool want = e ? e[0] == '1' : false;
-        m->ln_fold = want && m->dt == D3R_F16X3 && m->bdt == D3R_F16X3 && cfg->enc_embed_dim % 32 == 0 && cfg->dec_embed_dim % 32 == 0 && !getenv("D3R_GEMM_NOWIDE");
+        const bool want = e ? e[0] != '0' : true;
+        m->ln_fold = want && m->dt == D3R_F16X3 && m->bdt == D3R_F16X3 && cfg->enc_embed_dim % 32 == 0 && cfg->dec_embed_dim % 32 == 0;
     }
     if (cfg->enc_embed_dim % m->ktile || cfg->dec_embed_dim % m->ktile || (3 * cfg->patch_size * cfg->patch_size) % m->ktile ||
         (cfg->head_type == 1 && (cfg->dec_depth <= 9 || cfg->patch_size != 16))) { delete m; return D3R_ERR_INVALID; }   // run_dpt assumes 16 x th == H

@@ -1642,9 +1642,13 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                         if (p.ln_part) {    // folded LayerNorm: (sum, sum of squares) of the 32 stored values of row m in this column group (8 lanes x 4), one fixed tree
                             float sm = (v.x + v.y) + (v.z + v.w);
                             float sq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-                            sm += __shfl_xor(sm, 1); sq += __shfl_xor(sq, 1);
-                            sm += __shfl_xor(sm, 2); sq += __shfl_xor(sq, 2);
-                            sm += __shfl_xor(sm, 4); sq += __shfl_xor(sq, 4);
+                            // the 8 lanes of a row (rch = lane & 7): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror -- VALU-side DPP moves, not the LDS crossbar
+                            sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), 0xB1, 0xF, 0xF, false));
+                            sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0xB1, 0xF, 0xF, false));
+                            sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), 0x4E, 0xF, 0xF, false));
+                            sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x4E, 0xF, 0xF, false));
+                            sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), 0x141, 0xF, 0xF, false));
+                            sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x141, 0xF, 0xF, false));
                             if (rch == 0 && m < p.M && n < p.n_store)
                                 *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * (p.n_store >> 5) + (ig >> 5)) * 2) = make_float2(sm, sq);
                         }
@@ -2073,7 +2077,8 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     if (g_trace_buf && (size_t)cdiv(p.M, 128) * cdiv(p.n_store, 128) <= g_trace_cap) p.trace = g_trace_buf;   // capacity for the smallest tile
     if (const char* e = getenv("D3R_GEMM_NOSTORE")) if (e[0] == '1') p.flags |= GF_NOSTORE;
-    if (const char* e = getenv("D3R_GEMM_NOWIDE")) if (e[0] == '1') p.flags |= GF_NOWIDE;
+    // (the folded-LayerNorm producer launches keep their wide epilogue: it is where the row sums and the typed residual stream are written)
+    if (const char* e = getenv("D3R_GEMM_NOWIDE")) if (e[0] == '1' && !p.ln_part && !(p.flags & GF_X3RES)) p.flags |= GF_NOWIDE;
     // measurement aid (results INVALID): the fp16 + fp8 K loop issues the MFMA mix of a 2.5-unit scheme -- per 64 k four f16 MFMAs (hi.hi and
     // hi.w_lo on the f16 pipe) and half an e4m3 MFMA (a_lo.w_hi, K = 128 spans two groups) = 80 MFMA cycles instead of 64 (fp16f8) / 96 (fp16x3)
     if (const char* e = getenv("D3R_F8_PROXY")) if (e[0] == '1') p.f8_proxy = 1;

@@ -128,7 +128,13 @@ int d3r_model_destroy(d3r_model* m);
 /* Load one tensor of the reference checkpoint's state dict by its key, e.g.
  * "enc_blocks.3.attn.qkv.weight". data: HOST fp32, contiguous, PyTorch layout. Keys the engine does not use
  * (mask_token, aliased scratch.layerN_rn, ...) return D3R_OK and are ignored; unknown keys -> D3R_ERR_UNKNOWN_KEY.
- * dec_blocks.* also fills dec_blocks2.* until a dec_blocks2 key arrives (dust3r/model.py:91-98). */
+ * dec_blocks.* also fills dec_blocks2.* until a dec_blocks2 key arrives (dust3r/model.py:91-98).
+ * Split-fp16 engines (D3R_DTYPE_F16X3, the default; environment D3R_LN_FOLD=0 turns it off at creation) fold the blocks' LayerNorms
+ * (croco Block.norm1 / norm2, DecoderBlock.norm1 / norm2 / norm3 / norm_y) into the nn.Linear behind each of them: the matrix is packed
+ * as W diag(gamma) with the bias b + W beta, by the first forward / encode / decode call after a load, from fp32 copies of those matrices
+ * that are released once packed. Consequence: after that call, a new value for one of these LayerNorm vectors, or for the bias of
+ * attn.qkv / cross_attn.projq / projk / projv / mlp.fc1, must come together with the matrices it is folded into -- otherwise the next
+ * forward returns D3R_ERR_STATE. Loading a whole state dict (what the Python mirror does) always satisfies this. */
 int d3r_model_load_tensor(d3r_model* m, const char* key, const float* data_host, int ndim, const int64_t* shape);
 /* same, but `data_dev` is a DEVICE fp32 tensor (e.g. a checkpoint already uploaded by the caller). Both variants convert
  * to the engine dtype / layout on the GPU; the call is ordered on the default stream and returns without synchronising. */

@@ -34,6 +34,7 @@ def main():
         return (time.perf_counter() - t) / n * 1e3
 
     acc = {'0': [], '1': []}
+    tables = {}
     for r in range(reps):
         for f in ('0', '1'):
             m = eng[f]
@@ -42,6 +43,7 @@ def main():
             blk = bench.profile_mode(m, v1, v2, 'fp16x3', quiet=True)
             m.set_two_streams(True)
             k = blk['kernels']
+            tables.setdefault(f, []).append({(t['kernel'], t['M'], t['N'], t['K']): (t['launches'], t['ms']) for t in blk['launch_table']})
             one = measure(m, s1, s2, n=20)
             row = (ms, k['attention']['ms'], k['other']['ms'], k['other']['launches'], k['all_gemm_linear']['ms'], k['all_gemm_conv']['ms'], one)
             acc[f].append(row)
@@ -56,8 +58,13 @@ def main():
     b = torch.cat((o1[0]['pts3d'], o1[1]['pts3d_in_other_view']))
     rel = ((a - b).norm(dim=-1) / a.norm(dim=-1).clamp_min(1e-8)).flatten()
     print(f'folded vs LayerNorm kernels, {B} pairs: per-pixel rel diff max {float(rel.max()):.3e} p99.99 {float(rel.kthvalue(int(0.9999 * rel.numel())).values):.3e} mean {float(rel.mean()):.3e}')
-    for r in blk['launch_table'][:16]:
-        print('   ', r)
+    keys = sorted(set(tables['0'][0]) | set(tables['1'][0]), key=lambda kk: -tables['0'][0].get(kk, (0, 0.0))[1])
+    print('per shape, ms per step (mean over repetitions): LayerNorm kernels -> folded')
+    for kk in keys:
+        a0 = [t[kk][1] for t in tables['0'] if kk in t]
+        a1 = [t[kk][1] for t in tables['1'] if kk in t]
+        if a0 and a1:
+            print(f'    {kk[0]:12s} M={kk[1]:8d} N={kk[2]:5d} K={kk[3]:5d} x{tables["0"][0][kk][0]:3d}: {sum(a0) / len(a0):7.3f} -> {sum(a1) / len(a1):7.3f} ms')
 
 
 if __name__ == '__main__':
