@@ -182,7 +182,7 @@ def profile_mode(model, v1, v2, precision, quiet=False):
     # both cross terms on the fp8 pipe at twice the 16-bit rate (2 x 2 M N K flops at 5 PFLOP/s = one more 16-bit unit)
     mfma_per_product = {'fp16x3': 3, 'fp16f8': 2, 'fp16x2f8': 2.5}.get(dom_dt, 1)
     cfg_name = GEMM_CFG_NAMES.get(dom, dom)
-    if dom_dt in ('fp16f8', 'fp16x2f8') and dom in (1, 2, 3):      # rocprofv3 symbol: gemm_kernel<4, GemmCfg<...,128,2,4>> (DMA pieces interleaved with the MFMA rows)
+    if dom_dt in ('fp16f8', 'fp16x2f8') and dom in (1, 2, 3):      # rocprofv3 symbol: gemm_kernel<4 | 5, GemmCfg<...,128,2,4>> (DMA pieces interleaved with the MFMA rows; 4 = fp16f8, 5 = fp16x2f8)
         cfg_name = cfg_name.replace(',128,2>', ',128,2,4>')
     traffic, tsrc = pmc_traffic_gb(dom, dom_dt)
     out = {'roofline': {
@@ -551,6 +551,7 @@ def main():
     ap.add_argument('--no-aligner', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-latency', action='store_true', help='skip the latency block (1 / 2 / 4 / 8 pairs per call)')
     ap.add_argument('--no-fast', '--no-accurate', dest='no_fast', action='store_true', help='skip the fast_mode block (fp16f8 / bf16 / fp16 throughput + their measured error)')
     ap.add_argument('--single-stream', action='store_true', help='keep decoder side 2 / head 2 on the main stream (serialised kernels: use under rocprofv3 so that per-kernel durations are not inflated by overlap)')
     args = ap.parse_args()
@@ -687,6 +688,27 @@ def main():
         blk = profile_mode(model, v1, v2, args.precision)
         if blk:
             result.update(blk)
+
+    # ---- small batches: the reference's own call shape (dust3r/demo.py:156 batch_size=1, visloc.py:88 one pair per query) ----------------
+    if rank == 0 and world == 1 and not args.no_latency:
+        try:
+            lat = {}
+            for nb, reps in ((1, 20), (2, 12), (4, 8), (8, 5)):
+                sub = lambda v: {k: (x[:nb] if isinstance(x, torch.Tensor) else x[:nb]) for k, x in v.items()}   # noqa: E731
+                a, b = sub(v1), sub(v2)
+                for _ in range(3):
+                    model(a, b)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    model(a, b)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t1) / reps * 1e3
+                lat[f'pairs_{nb}'] = {'ms_per_call': ms, 'pairs_per_s': nb / ms * 1e3}
+            result['latency'] = dict(lat, what='engine forward, inputs and outputs resident in HBM, back-to-back calls of 1 / 2 / 4 / 8 pairs of 512x384 (same weights and precision as the headline)')
+            log('[bench] latency: ' + ', '.join(f"{k} {v['ms_per_call']:.2f} ms" for k, v in lat.items()))
+        except Exception as e:
+            result['latency'] = {'error': repr(e)}
 
     # ---- opt-in fast modes: NOT parity-grade, reported with their measured error and their own roofline block --------------
     # Error = per-pixel relative pointmap difference against the headline (parity-grade) engine on the same weights and the

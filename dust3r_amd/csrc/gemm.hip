@@ -26,6 +26,7 @@
 // MFMA operand roles: D[i][j] with 4 consecutive i per lane. Normally i = n (weights) so each
 // lane owns 4 consecutive output columns of one row -> 8/16-byte stores; for V^T tiles of the
 // attention projections the roles are swapped (i = m) so 4 consecutive TOKENS land together.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -1896,7 +1897,33 @@ template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hi
 // once there are at least ~3 full rounds of 256 resident blocks (M = 49152: 760-1070 vs 640-830 TF/s), the 128x128 tile
 // (2 blocks per CU: one block's prologue / epilogue hides behind the other's K loop) wins below that; N <= 128 problems
 // (DPT head convolutions) take the 512x128 / 256x128 tiles so that no half-empty 256-wide tile is computed.
+static int pick_config_raw(const GemmParams& p, int dt);
+// compute units of the current device, cached per device id (the whole-rounds rules below are about THIS chip's CU count, not a constant)
+static int device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int slot = dev & 63;
+    int v = cache[slot].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        int q = 0;
+        v = (hipDeviceGetAttribute(&q, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && q > 0) ? q : 256;
+        cache[slot].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+// the tile configuration a launch of (p, dt) RUNS on -- what the engine's profile records and d3r_gemm_tile_config reports: the heuristic's
+// choice, then the remaps launch_t applies for operand types that do not have every shape
 int gemm_pick_config(const GemmParams& p, int dt) {
+    int cfg = pick_config_raw(p, dt);
+    const bool split = dt == D3R_F16X3 || dt == D3R_F16F8 || dt == D3R_F16X2F8;
+    if (cfg == GEMM_CFG_256x128W4 && split) cfg = GEMM_CFG_256x128;
+    if ((cfg == GEMM_CFG_256x128R || cfg == GEMM_CFG_64 || cfg == GEMM_CFG_384x192) && dt != D3R_F16X3) cfg = cfg == GEMM_CFG_256x128R ? GEMM_CFG_256x128 : GEMM_CFG_128;
+    if ((cfg == GEMM_CFG_256S4 || cfg == GEMM_CFG_256PP) && split) cfg = GEMM_CFG_256;
+    if (dt == D3R_F16X2F8 && cfg != GEMM_CFG_256) cfg = GEMM_CFG_128;      // the 2.5-unit K loop exists on the two square tiles
+    return cfg;
+}
+static int pick_config_raw(const GemmParams& p, int dt) {
     const int n_rows = p.n_rows > 0 ? p.n_rows : p.n_pad;
     const bool wide_vt = (dt == D3R_BF16 || dt == D3R_F16) && (p.ntok & 63) == 0 && !(p.flags & GF_NOWIDE);
     const bool heads = p.epi == EPI_HEADS && !wide_vt;   // "heads" = needs a square tile (operand-role swap for V^T)
@@ -1931,7 +1958,8 @@ int gemm_pick_config(const GemmParams& p, int dt) {
         const char* e384 = getenv("D3R_GEMM_T384");
         const long t384 = (long)cdiv(p.M, 384) * cdiv(p.n_store, 192);
         const bool short_res = p.epi == EPI_F32 && p.K <= 1024;
-        if (!(e384 && e384[0] == '0') && !(short_res && e384 && e384[0] == '1') && t384 >= 230 && (t384 % 256 == 0 || t384 % 256 >= 230)) return GEMM_CFG_384x192;
+        const int cus = device_cus();       // whole rounds of THIS device's compute units (256 on MI355X; a partitioned device has fewer)
+        if (!(e384 && e384[0] == '0') && !(short_res && e384 && e384[0] == '1') && t384 >= cus * 9 / 10 && (t384 % cus == 0 || t384 % cus >= cus * 9 / 10)) return GEMM_CFG_384x192;
     }
     // split-fp16, launches without attention heads (their V^T regions need a square tile): the two-blocks-per-CU 256 x 128 shape with the
     // weights of a K step in registers. Measured on MI355X (profiles/r03_c/gemmtrace_cfg7.log, bench_r*.log): it wins where the epilogue
@@ -2081,7 +2109,11 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     if (const char* e = getenv("D3R_GEMM_NOWIDE")) if (e[0] == '1' && !p.ln_part && !(p.flags & GF_X3RES)) p.flags |= GF_NOWIDE;
     // measurement aid (results INVALID): the fp16 + fp8 K loop issues the MFMA mix of a 2.5-unit scheme -- per 64 k four f16 MFMAs (hi.hi and
     // hi.w_lo on the f16 pipe) and half an e4m3 MFMA (a_lo.w_hi, K = 128 spans two groups) = 80 MFMA cycles instead of 64 (fp16f8) / 96 (fp16x3)
-    if (const char* e = getenv("D3R_F8_PROXY")) if (e[0] == '1') p.f8_proxy = 1;
+    if (const char* e = getenv("D3R_F8_PROXY")) if (e[0] == '1') {
+        p.f8_proxy = 1;
+        static std::atomic<bool> told{false};
+        if (!told.exchange(true)) fprintf(stderr, "[dust3r_amd] D3R_F8_PROXY=1: MEASUREMENT AID -- the fp16 + fp8 K loops issue a different MFMA mix and every result of an fp16f8 engine is INVALID\n");
+    }
     // wide epilogues store with the non-temporal policy (measured +3..10 % on isolated GEMMs, +1 % on the forward); D3R_GEMM_NT=0: plain stores
     { const char* e = getenv("D3R_GEMM_NT"); if (!e || e[0] != '0') p.flags |= GF_NTSTORE; }
     const int kt = 128 / (int)dt_bytes(dt);

@@ -129,12 +129,15 @@ class AsymmetricCroCo3DStereo(nn.Module):
         assert head_type in ('linear', 'dpt'), f'unexpected {head_type=}'
         # heads/postprocess.py:23-58: depth 'exp' | 'linear' | 'square' (the reference asserts the depth bounds away, :29-30),
         # conf 'exp' (any vmin < vmax) | 'sigmoid' (finite bounds); anything else is the reference's ValueError(f'bad {mode=}')
+        if conf_mode is None:      # the reference accepts None (heads then emit no confidence, heads/postprocess.py:20-21); the engine's heads always emit one
+            raise NotImplementedError('conf_mode=None (a model without a confidence output) is not supported by the dust3r_amd engine')
         depth_mode, conf_mode = tuple(depth_mode), tuple(conf_mode)
         assert depth_mode[1] == -inf and depth_mode[2] == inf, 'depth_mode bounds must be (-inf, inf) (dust3r/heads/postprocess.py:29-30)'
         if depth_mode[0] not in ('exp', 'linear', 'square'):
             raise ValueError(f'bad mode={depth_mode[0]!r}')
         if conf_mode[0] not in ('exp', 'sigmoid'):
             raise ValueError(f'bad mode={conf_mode[0]!r}')
+        # deliberate deviation: the reference does not check the bounds (vmin >= vmax there silently yields a constant or negative-width confidence)
         assert conf_mode[1] < conf_mode[2] and (conf_mode[0] == 'exp' or abs(conf_mode[1]) < inf and abs(conf_mode[2]) < inf), f'bad bounds in {conf_mode=}'
         assert pos_embed.startswith('RoPE'), 'DUSt3R checkpoints use RoPE positional embedding'
         assert mlp_ratio == 4 and norm_im2_in_dec, 'unsupported CroCo variant'

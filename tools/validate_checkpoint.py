@@ -72,6 +72,9 @@ def main():
     print(f'oracle   <- {a.checkpoint}: constructor {kw}')
     print(f'           missing keys {list(res.missing_keys)[:8]}{" ..." if len(res.missing_keys) > 8 else ""} ({len(res.missing_keys)}), '
           f'unexpected {list(res.unexpected_keys)[:8]}{" ..." if len(res.unexpected_keys) > 8 else ""} ({len(res.unexpected_keys)})')
+    keys_ok = len(res.missing_keys) == 0 and len(res.unexpected_keys) == 0      # a key-for-key match of the restated module tree is part of the verdict
+    if not keys_ok:
+        print('           [FAIL] the restated module tree does not match the checkpoint key for key')
     engine = load_model(a.checkpoint, dev, verbose=False, precision=a.precision.split(',')[0])
     print(f'engine   <- loaded, {engine.device_bytes() / 2**30:.2f} GiB in HBM, head {engine.head_type}, depth_mode {engine.depth_mode}, conf_mode {engine.conf_mode}')
     if a.images:
@@ -88,16 +91,16 @@ def main():
     ref = torch.cat((r1['pts3d'], r2['pts3d_in_other_view']))
     nrm = ref.norm(dim=-1)
     print(f'oracle pointmaps: |pts| mean {float(nrm.mean()):.3f}, min / mean {float(nrm.min() / nrm.mean()):.2e}; conf range [{float(r1["conf"].min()):.2f}, {float(r1["conf"].max()):.2f}]')
-    ok = True
+    ok = keys_ok
     for prec in a.precision.split(','):
         engine.set_precision(prec)
         e1, e2 = engine(v1, v2)
         s = stats(torch.cat((e1['pts3d'], e2['pts3d_in_other_view'])), ref)
         cref = torch.cat((r1['conf'], r2['conf']))
         cerr = float(((torch.cat((e1['conf'], e2['conf'])).cpu() - cref).abs() / cref.abs().clamp_min(1e-6)).max())
-        verdict = 'PASS' if s['max'] <= 1e-3 else 'FAIL'
-        ok = ok and s['max'] <= 1e-3
-        print(f'engine {prec:7s} vs oracle: pointmap rel err max {s["max"]:.3e}  p99.99 {s["p9999"]:.3e}  p99 {s["p99"]:.3e}  mean {s["mean"]:.3e};  conf rel err max {cerr:.3e}   [{verdict} at 1e-3]')
+        verdict = 'PASS' if s['max'] <= 1e-3 and cerr <= 3e-3 else 'FAIL'          # confidences: the bound the test-suite holds them to
+        ok = ok and s['max'] <= 1e-3 and cerr <= 3e-3
+        print(f'engine {prec:7s} vs oracle: pointmap rel err max {s["max"]:.3e}  p99.99 {s["p9999"]:.3e}  p99 {s["p99"]:.3e}  mean {s["mean"]:.3e};  conf rel err max {cerr:.3e}   [{verdict} at 1e-3 / conf 3e-3]')
     if a.align:       # needs weights that produce a scene (a real checkpoint): the MST / focal initialisation of a random network's output ends in NaN
       try:
         from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
