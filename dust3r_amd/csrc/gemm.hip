@@ -1576,16 +1576,93 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
             // GF_X3RES (split-fp16 launches; the folded-LayerNorm engine, kernels.hpp): the residual stream lives in split-fp16 rows ONLY -- res1 is read
             // as typed rows (8 + 8 bytes per 4 elements), out2 receives the typed sum, no fp32 row is stored. The two forms are two instances of
             // one body so that no load feeds a PHI (see the note on conditional reads above).
-            auto body = [&](auto x3c) __attribute__((always_inline)) {
-                constexpr bool X3R = decltype(x3c)::value;
-                using TXR = Traits<D3R_F16X3>;
-                // without a residual the same addresses of the (same shape) output are read and discarded: no branch, no PHI
-                const char* rsrc = X3R ? reinterpret_cast<const char*>(has_res ? p.res1 : (const void*)p.out2)
-                                       : reinterpret_cast<const char*>(has_res ? p.res1 : (const void*)p.out);
-                const int rld = has_res ? p.ldr : (X3R ? p.ldo2 : p.ldo);
+            if constexpr (DTX3) {
+                if (p.flags & GF_X3RES) {
+                    using TXR = Traits<D3R_F16X3>;
+                    // without a residual the same addresses of the (same shape) output are read and discarded: no branch, no PHI
+                    const char* rsrc = reinterpret_cast<const char*>(has_res ? p.res1 : (const void*)p.out2);
+                    const int rld = has_res ? p.ldr : p.ldo2;
+                    // Lanes 2k / 2k + 1 of the read phase hold the two halves of one 8-element group [hi x8 (16 B)][lo x8 (16 B)]: the even lane reads /
+                    // writes the group's 16 hi bytes, the odd lane its 16 lo bytes -- ONE 16-byte access per lane and direction (8-byte accesses are
+                    // issue-bound, MI355X_MICROARCH.md store tail) -- and the halves are swapped with a DPP move. n_store % 8 == 0.
+                    // ONE residual buffer: the row of group g + 1 is requested into the register its group-g value has just left (a whole group
+                    // ahead of its use, like the double buffer of the fp32 form, at half the registers: this kernel has none to spare).
+                    const bool odd = rch & 1;
+                    const bool x3nt = p.x3res_nt != 0;       // probe D3R_GEMM_X3NT: the typed stream stored with the non-temporal policy (it is re-read by the next two launches)
+                    auto swap_pair = [](uint32_t x) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); };   // quad_perm [1,0,3,2]: lane ^ 1
+                    auto request_row = [&](int g, int pass) __attribute__((always_inline)) -> uint4 {
+                        const int m = min(jb + pass * 8 + rrow, p.M - 1);
+                        const int n8 = max(min((ib + g * 32 + rch * 4) & ~7, p.n_store - 8), 0);
+                        return *reinterpret_cast<const uint4*>(rsrc + TXR::boff((size_t)m * rld + n8) + (odd ? 16 : 0));
+                    };
+                    uint4 rr1[RP];
+#pragma unroll
+                    for (int pass = 0; pass < RP; ++pass) rr1[pass] = request_row(0, pass);
+#pragma unroll
+                    for (int g = 0; g < FI / 2; ++g) {
+                        const int ig = ib + g * 32;
+                        float4 bi2[2];
+#pragma unroll
+                        for (int fl = 0; fl < 2; ++fl) {
+                            const float4 t = *reinterpret_cast<const float4*>(bsrc + max(min(ig + fl * 16 + i4, p.n_store - 4), 0));
+                            bi2[fl] = make_float4(has_bias ? t.x : 0.f, has_bias ? t.y : 0.f, has_bias ? t.z : 0.f, has_bias ? t.w : 0.f);
+                        }
+#pragma unroll
+                        for (int fl = 0; fl < 2; ++fl) {
+                            const float4 bi = bi2[fl];
+#pragma unroll
+                            for (int fj = 0; fj < FJ; ++fj) {
+                                const f32x4_t a = acc[g * 2 + fl][fj];
+                                *reinterpret_cast<float4*>(wreg + (fj * 16 + jl) * WROW + (fl * 16 + i4) * 4) = make_float4(a[0] + bi.x, a[1] + bi.y, a[2] + bi.z, a[3] + bi.w);
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int pass = 0; pass < RP; ++pass) {
+                            const int row = pass * 8 + rrow;
+                            float4 v = *reinterpret_cast<const float4*>(wreg + row * WROW + rch * 16);
+                            const int m = jb + row, n = ig + rch * 4;
+                            const uint4 raw = rr1[pass];
+                            if (g + 1 < FI / 2) rr1[pass] = request_row(g + 1, pass);
+                            // even lane holds hi0..7 (keeps hi0..3, hands over hi4..7), odd lane lo0..7 (keeps lo4..7, hands over lo0..3)
+                            const uint32_t t0 = swap_pair(odd ? raw.x : raw.z), t1 = swap_pair(odd ? raw.y : raw.w);
+                            const uint32_t hx = odd ? t0 : raw.x, hy = odd ? t1 : raw.y, lx = odd ? raw.z : t0, ly = odd ? raw.w : t1;
+                            v.x += has_res ? TXR::join_lo(hx, lx) : 0.f; v.y += has_res ? TXR::join_hi(hx, lx) : 0.f;
+                            v.z += has_res ? TXR::join_lo(hy, ly) : 0.f; v.w += has_res ? TXR::join_hi(hy, ly) : 0.f;
+                            uint2 h, l;
+                            TXR::split2(v.x, v.y, h.x, l.x);
+                            TXR::split2(v.z, v.w, h.y, l.y);
+                            const uint32_t u0 = swap_pair(odd ? h.x : l.x), u1 = swap_pair(odd ? h.y : l.y);
+                            if (m < p.M && n < p.n_store) {      // the typed sum: 16 hi bytes from the even lane, 16 lo bytes from the odd lane
+                                char* o2 = reinterpret_cast<char*>(p.out2) + TXR::boff((size_t)m * p.ldo2 + (n & ~7)) + (odd ? 16 : 0);
+                                store16(o2, odd ? make_uint4(u0, u1, l.x, l.y) : make_uint4(h.x, h.y, u0, u1), nt && x3nt);
+                            }
+                            if (p.ln_part) {    // folded LayerNorm: (sum, sum of squares) of the 32 values of row m in this column group (8 lanes x 4), one fixed tree
+                                float sm = (v.x + v.y) + (v.z + v.w);
+                                float sq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                                // the 8 lanes of a row (rch = lane & 7): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror -- VALU-side DPP moves, not the LDS crossbar
+                                sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), 0xB1, 0xF, 0xF, false));
+                                sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0xB1, 0xF, 0xF, false));
+                                sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), 0x4E, 0xF, 0xF, false));
+                                sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x4E, 0xF, 0xF, false));
+                                sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), 0x141, 0xF, 0xF, false));
+                                sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x141, 0xF, 0xF, false));
+                                if (rch == 0 && m < p.M && n < p.n_store)
+                                    *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * (p.n_store >> 5) + (ig >> 5)) * 2) = make_float2(sm, sq);
+                            }
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                    return;
+                }
+            }
+            {
+                // without a residual the same addresses of the (fp32, same shape) output are read and discarded: no branch, no PHI
+                const float* rsrc = has_res ? reinterpret_cast<const float*>(p.res1) : reinterpret_cast<const float*>(p.out);
+                const int rld = has_res ? p.ldr : p.ldo;
                 // The residual rows a lane adds in the read phase of group g are requested one group AHEAD (double buffered): the per-block
                 // trace (tools/gpu_probe.py gemmtrace) showed this epilogue as four serial HBM round trips, ~19 us per 256 x 256 tile.
-                // In place (res1 == out / out2) is fine: a lane reads exactly the elements it stores later, and group g + 1's columns are
+                // In place (res1 == out) is fine: a lane reads exactly the elements it stores later, and group g + 1's columns are
                 // disjoint from the columns group g is storing.
                 float4 rr[2][RP];
                 auto request_rows = [&](int g, float4 (&dst)[RP]) __attribute__((always_inline)) {
@@ -1593,13 +1670,7 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
 #pragma unroll
                     for (int pass = 0; pass < RP; ++pass) {
                         const int m = min(jb + pass * 8 + rrow, p.M - 1), n = max(min(ig + rch * 4, p.n_store - 4), 0);
-                        if constexpr (X3R) {     // raw (hi x4, lo x4) of the 4 elements: joined when they are added
-                            const char* q = rsrc + TXR::boff((size_t)m * rld + n);
-                            const uint2 h = *reinterpret_cast<const uint2*>(q), l = *reinterpret_cast<const uint2*>(q + 16);
-                            dst[pass] = make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
-                        } else {
-                            dst[pass] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rsrc) + (size_t)m * rld + n);
-                        }
+                        dst[pass] = *reinterpret_cast<const float4*>(rsrc + (size_t)m * rld + n);
                     }
                 };
                 request_rows(0, rr[0]);
@@ -1628,39 +1699,17 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                         const int row = pass * 8 + rrow;
                         float4 v = *reinterpret_cast<const float4*>(wreg + row * WROW + rch * 16);
                         const int m = jb + row, n = ig + rch * 4;
-                        float4 rv = rr[g & 1][pass];
-                        if constexpr (X3R) {
-                            const uint32_t hx = __float_as_uint(rv.x), hy = __float_as_uint(rv.y), lx = __float_as_uint(rv.z), ly = __float_as_uint(rv.w);
-                            rv = make_float4(TXR::join_lo(hx, lx), TXR::join_hi(hx, lx), TXR::join_lo(hy, ly), TXR::join_hi(hy, ly));
-                        }
+                        const float4 rv = rr[g & 1][pass];
                         v.x += has_res ? rv.x : 0.f; v.y += has_res ? rv.y : 0.f;
                         v.z += has_res ? rv.z : 0.f; v.w += has_res ? rv.w : 0.f;
                         if (m < p.M && n < p.n_store) {
-                            if constexpr (!X3R)
-                                store16(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), nt);
-                            if (X3R || p.out2) store4<O2DT>(p.out2, (size_t)m * p.ldo2 + n, v.x, v.y, v.z, v.w);
-                        }
-                        if (p.ln_part) {    // folded LayerNorm: (sum, sum of squares) of the 32 stored values of row m in this column group (8 lanes x 4), one fixed tree
-                            float sm = (v.x + v.y) + (v.z + v.w);
-                            float sq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-                            // the 8 lanes of a row (rch = lane & 7): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror -- VALU-side DPP moves, not the LDS crossbar
-                            sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), 0xB1, 0xF, 0xF, false));
-                            sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0xB1, 0xF, 0xF, false));
-                            sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), 0x4E, 0xF, 0xF, false));
-                            sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x4E, 0xF, 0xF, false));
-                            sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), 0x141, 0xF, 0xF, false));
-                            sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x141, 0xF, 0xF, false));
-                            if (rch == 0 && m < p.M && n < p.n_store)
-                                *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * (p.n_store >> 5) + (ig >> 5)) * 2) = make_float2(sm, sq);
+                            store16(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), nt);
+                            if (p.out2) store4<O2DT>(p.out2, (size_t)m * p.ldo2 + n, v.x, v.y, v.z, v.w);
                         }
                     }
                     asm volatile("" ::: "memory");
                 }
-            };
-            if constexpr (DTX3) {
-                if (p.flags & GF_X3RES) { body(std::true_type{}); return; }
             }
-            body(std::false_type{});
             return;
         }
     }
@@ -2120,12 +2169,13 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     if (p.M <= 0 || p.n_pad % 128 != 0 || p.n_store > p.n_pad || p.K % kt != 0 || p.K <= 0) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV && (p.Cin % kt != 0 || p.zero_page == nullptr)) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV) p.kslice_major = conv_k_slice_major() ? 1 : 0;
+    if (const char* e = getenv("D3R_GEMM_X3NT")) p.x3res_nt = e[0] == '1' ? 1 : 0;
     if (const char* e = getenv("D3R_GEMM_PANEL")) { const int v = atoi(e); if (v >= 1 && v <= 64) p.panel = v; }
     if (p.epi == EPI_HEADS && p.head_c % 128 != 0 && p.head_c < (1 << 29)) return hipErrorInvalidValue;
     if (p.epi == EPI_HEAD4 && (p.n_store > 128 || p.n_store % 4 != 0 || !p.res1 || !p.res2 || !p.out || !p.out2)) return hipErrorInvalidValue;
     // folded LayerNorm (kernels.hpp): statistics come out of the wide fp32 epilogue only; the consumer side exists for split-fp16 operands, typed / GELU / head outputs
-    if (p.ln_part && (p.epi != EPI_F32 || (p.flags & GF_NOWIDE) || p.n_store % 32 != 0)) return hipErrorInvalidValue;
-    if ((p.flags & GF_X3RES) && (dt != D3R_F16X3 || p.epi != EPI_F32 || (p.flags & GF_NOWIDE) || !p.out2 || (p.ldo2 & 7) || (p.res1 && (p.ldr & 7)))) return hipErrorInvalidValue;
+    if (p.ln_part && (p.epi != EPI_F32 || !(p.flags & GF_X3RES) || p.n_store % 32 != 0)) return hipErrorInvalidValue;   // the row sums come out of the typed-stream epilogue
+    if ((p.flags & GF_X3RES) && (dt != D3R_F16X3 || p.epi != EPI_F32 || (p.flags & GF_NOWIDE) || !p.out2 || (p.ldo2 & 7) || (p.n_store & 7) || (p.res1 && (p.ldr & 7)))) return hipErrorInvalidValue;
     if (p.ln_rstd && (dt != D3R_F16X3 || !p.ln_nmr || !p.ln_colsum || p.amode != AMODE_LINEAR || !(p.epi == EPI_T || p.epi == EPI_GELU || p.epi == EPI_HEADS) || p.res1 || p.res2 || p.out2)) return hipErrorInvalidValue;
     // fp16 + fp8 rows: nn.Linear operands only, whole 64-element super-groups; outputs: fp32 (+ residual), GELU / plain activation rows, heads
     const bool f8rows = dt == D3R_F16F8 || dt == D3R_F16X2F8;
