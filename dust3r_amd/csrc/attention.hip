@@ -762,7 +762,11 @@ template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream
             }
         }
     }
-    if (const char* e = getenv("D3R_ATTN_NW")) if (e[0] == '8') return launch_x3_v2p<ODT, 0, 8>(p, s);   // probe: 256 queries per workgroup
+    if (const char* e = getenv("D3R_ATTN_NW")) {
+        if (e[0] == '8' && e[1] == 0) return launch_x3_v2p<ODT, 0, 8>(p, s);   // probe: 256 queries per workgroup (register staging, packed softmax: round 3's instance)
+        // probe '8d' / '8e': 256 queries per workgroup with DMA staging and the scalar softmax slices, everywhere / for launches of >= 2048 workgroups of 128 queries only
+        if (e[0] == '8' && (e[1] == 'd' || (e[1] == 'e' && (long)p.B * p.H * ((p.Nq + 127) / 128) >= 4096))) return launch_x3_v2p<ODT, 0, 8, true, true>(p, s);
+    }
     // K / V^T tiles by global_load_lds DMA into swizzled 256-byte rows (default since round 4; D3R_ATTN_DMA=0: staged through registers into padded
     // rows; read per launch). Measured (profiles/r04_b/attndma.log, ab_attn_dma.txt): 64 x 16 heads 512 -> 492 us, 32 x 12 heads equal, forward
     // 193.15 -> 193.5 pairs/s; bit-identical outputs (tests/test_kernels_gpu.py::test_attention_split_fp16_dma_staging_is_bit_identical).

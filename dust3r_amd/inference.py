@@ -161,22 +161,35 @@ def _shared_images(pairs):
     return [t for _, t in sorted(uniq.values(), key=lambda x: x[0])], index[0], index[1]
 
 
-def _collate_views(pairs, shared=None, device_stack=None):
+def _collate_views(pairs, shared=None, device_stack=None, ready=None):
     """view1 / view2 dicts of the whole pair list in the reference's collated format (inference.py:68-72: tensors concatenated on the
     host, lists chained). When the pair list shares images, the two big `img` tensors (2 x len(pairs) images) are gathered ON THE GPU
     from the stack of distinct images (already uploaded for the forward) and come back in one D2H each: a host-side concatenation of
-    600 pairs x 2 views ran 1.6 s per view on the GPU box (profiles/r02_*/host_probe.log), the device gather + copy ~0.1 s."""
+    600 pairs x 2 views ran 1.6 s per view on the GPU box (profiles/r02_*/host_probe.log), the device gather + copy ~0.1 s.
+    `ready` (round 5): a CUDA event behind the upload of `device_stack`. The function is then safe to run on a host thread WHILE the forward
+    loop runs (the two view tensors are 2.8 GB for 600 pairs at 512x384 -- a quarter second of page faults and PCIe that used to follow the
+    last batch): its gathers and D2H copies go through a side stream of their own that waits for that event only."""
     if shared is None or device_stack is None:
         return collate_with_cat(list(pairs))
     light = [tuple({k: v for k, v in view.items() if k != 'img'} for view in p) for p in pairs]
     view1, view2 = collate_with_cat(light)
     dev = device_stack.device
+    side = torch.cuda.Stream(device=dev) if ready is not None else None
 
     def gather(index, chunk=128):      # in chunks: 2 x len(pairs) whole images never sit in HBM at once (2.8 GB for 600 pairs at 512x384)
-        out = torch.empty((len(index),) + tuple(device_stack.shape[1:]), dtype=device_stack.dtype)
-        idx = torch.tensor(index, device=dev)
-        for i in range(0, len(index), chunk):
-            out[i:i + chunk].copy_(device_stack.index_select(0, idx[i:i + chunk]))
+        out = torch.zeros((len(index),) + tuple(device_stack.shape[1:]), dtype=device_stack.dtype)     # zeros: the pages are touched before the copies need them
+        if side is None:
+            idx = torch.tensor(index, device=dev)
+            for i in range(0, len(index), chunk):
+                out[i:i + chunk].copy_(device_stack.index_select(0, idx[i:i + chunk]))
+            return out
+        with torch.cuda.device(dev), torch.cuda.stream(side):
+            side.wait_event(ready)
+            idx = torch.tensor(index, device=dev)
+            for i in range(0, len(index), chunk):
+                piece = device_stack.index_select(0, idx[i:i + chunk])
+                out[i:i + chunk].copy_(piece)      # blocks this thread only; ordered on the side stream
+            side.synchronize()
         return out
     view1['img'], view2['img'] = gather(shared[1]), gather(shared[2])
     return view1, view2
@@ -230,6 +243,13 @@ def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, outp
         feats.append(model.encode_images(dev_imgs[-1]))
     feats = torch.cat(feats, dim=0)
     i1h, i2h = [pos[int(a['idx'])] for a, _ in pairs], [pos[int(b['idx'])] for _, b in pairs]
+    # the collated view images (what inference() returns next to the predictions) go to the host on a thread of their own while the pairs decode
+    stack = torch.cat(dev_imgs, dim=0)
+    views = None
+    if stack.is_cuda:
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(stack.device))
+        views = _Background(_collate_views, pairs, (None, i1h, i2h), stack, ready)
     sink = _PredictionSink(len(pairs), H, W, output_device, feats.device, outputs=outputs.join())
     i1, i2 = torch.tensor(i1h, device=feats.device), torch.tensor(i2h, device=feats.device)
     for i in tqdm.trange(0, len(pairs), batch_size, disable=not verbose, desc='decode'):
@@ -237,7 +257,7 @@ def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, outp
         p1, p2 = model.decode_pairs(feats.index_select(0, torch.cat((i1[i:j], i2[i:j]))), H, W)
         sink.put(i, j, p1, p2)
     pred1, pred2 = sink.finish()
-    view1, view2 = _collate_views(pairs, shared=(None, i1h, i2h), device_stack=torch.cat(dev_imgs, dim=0))
+    view1, view2 = views.join() if views is not None else _collate_views(pairs, shared=(None, i1h, i2h), device_stack=stack)
     return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)
 
 
@@ -281,9 +301,13 @@ def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None
     on_gpu = torch.device(device).type == 'cuda'
     shared = _shared_images(pairs) if on_gpu else None
     sink = _PredictionSink(len(pairs), H, W, output_device, device)
+    views = None
     if shared is not None:       # the distinct images go up once; every batch is gathered on the device
         stack = torch.cat(shared[0], dim=0).to(device, non_blocking=True)
         i1, i2 = torch.tensor(shared[1], device=stack.device), torch.tensor(shared[2], device=stack.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(stack.device))
+        views = _Background(_collate_views, pairs, shared, stack, ready)      # the collated view images leave for the host while the batches run
     for i in tqdm.trange(0, len(pairs), batch_size, disable=not verbose):
         j = min(i + batch_size, len(pairs))
         if shared is not None:
@@ -294,5 +318,5 @@ def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None
         res = loss_of_one_batch(batch, model, None, device)
         sink.put(i, j, res['pred1'], res['pred2'])
     pred1, pred2 = sink.finish()
-    view1, view2 = _collate_views(pairs, shared, stack if shared is not None else None)
+    view1, view2 = views.join() if views is not None else _collate_views(pairs, shared, stack if shared is not None else None)
     return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)
