@@ -258,14 +258,17 @@ def bench_aligner(device, niter=300, n_views=20):
     scene.load_state_dict(init)
     E, n, A = scene.n_edges, scene.n_imgs, H * W
     global_alignment_loop(scene, niter=5)                      # warm-up (also builds the engine)
-    scene.load_state_dict(init)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    loss = global_alignment_loop(scene, niter=niter, schedule='cosine', lr=0.01)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1)
+    runs = []
+    for _ in range(3):          # the whole 300-iteration run three times from the same state (75 ms each): MEDIAN reported, every run listed
+        scene.load_state_dict(init)       # (900 dependent launches: one run of the round-5 visit H read 128 ms on a box whose other runs read 74)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        loss = global_alignment_loop(scene, niter=niter, schedule='cosine', lr=0.01)
+        e1.record()
+        torch.cuda.synchronize()
+        runs.append(e0.elapsed_time(e1))
+    ms = sorted(runs)[1]
     bytes_iter = E * A * 32 + n * A * 4 * 6                    # preds + weights once, depth param/Adam r/w
     gbs = bytes_iter * niter / (ms * 1e-3) / 1e9
     traffic, tsrc = None, None
@@ -275,7 +278,7 @@ def bench_aligner(device, niter=300, n_views=20):
             traffic, tsrc = d['aligner_main_kernel']['hbm_gb_per_launch'], path
             break
     res = dict(metric='global_aligner_iters_per_sec', value=niter / (ms * 1e-3), unit='iters/s', n_views=n, n_edges=E, niter=niter,
-               ms_total=ms, final_loss=loss,
+               ms_total=ms, ms_runs=runs, final_loss=loss,
                roofline=dict(bound='hbm', kernel='d3r::aligner_main_kernel (+ reduce + small kernels: whole iteration timed)', achieved=gbs,
                              peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, bytes_per_iter=bytes_iter, traffic=traffic, traffic_source=tsrc))
     return res, (out, init)

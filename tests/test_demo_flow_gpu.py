@@ -141,4 +141,4 @@ def test_validate_checkpoint_tool_on_a_synthetic_checkpoint(gpu, tmp_path):
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert 'missing keys [] (0), unexpected [] (0)' in r.stdout
-    assert r.stdout.count('[PASS at 1e-3]') == 2
+    assert r.stdout.count('[PASS at 1e-3 / conf 3e-3]') == 2
