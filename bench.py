@@ -248,12 +248,13 @@ def parity_vs_cpu_oracle(model, oracle, v1, v2, ref):
             'pointmap_rel_err': st, 'conf_rel_err_max': cf, 'tolerance': 1e-3, 'pass': st['max'] < 1e-3 and cf < 3e-3}
 
 
-def bench_aligner(device, niter=300, n_views=20):
-    """configs[3]: PointCloudOptimizer, 20 synthetic views -> 190 edges, 300 iterations, cosine schedule, one GPU."""
+def bench_aligner(device, niter=300, n_views=20, symmetrize=False):
+    """configs[3]: PointCloudOptimizer, 20 synthetic views -> 190 edges (symmetrize=True: the demo's symmetrised graph, dust3r/demo.py:155, 380 edges),
+    300 iterations, cosine schedule, one GPU."""
     from dust3r_amd.cloud_opt import global_aligner
     from dust3r_amd.cloud_opt.base_opt import global_alignment_loop
     from dust3r_amd.synthetic import synthetic_scene
-    out, init, gt = synthetic_scene(n_views, H, W, seed=0, symmetrize=False, device=device)
+    out, init, gt = synthetic_scene(n_views, H, W, seed=0, symmetrize=symmetrize, device=device, device_rng=symmetrize)
     scene = global_aligner(out, device, verbose=False)
     scene.load_state_dict(init)
     E, n, A = scene.n_edges, scene.n_imgs, H * W
@@ -769,6 +770,13 @@ def main():
             try:
                 result['aligner'], scene_io = bench_aligner(device)
                 log(f"[bench] aligner {result['aligner']['value']:.1f} iters/s, {result['aligner']['roofline']['achieved']:.0f} GB/s algorithmic")
+                try:        # the same 20 views with the demo's symmetrised pair graph (380 edges, 2.48 GB per iteration): reported beside the BASELINE scene
+                    a380, _ = bench_aligner(device, symmetrize=True)
+                    result['aligner']['symmetrized_380_edges'] = {k: a380[k] for k in ('value', 'unit', 'n_edges', 'ms_total', 'ms_runs', 'final_loss', 'roofline')}
+                    log(f"[bench] aligner, 380 edges: {a380['value']:.1f} iters/s, {a380['roofline']['achieved']:.0f} GB/s algorithmic")
+                    del a380, _
+                except Exception as e:
+                    result['aligner']['symmetrized_380_edges'] = {'error': repr(e)}
             except Exception as e:  # keep the forward line even if the second leg fails
                 result['aligner'] = {'error': repr(e)}
         if not args.no_cpu_baseline:
