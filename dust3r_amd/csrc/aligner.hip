@@ -92,12 +92,15 @@ D3R_DEV float4 stream_ld4(const float* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 #define D3R_STREAM_LD4(ptr) stream_ld4(ptr)
-template <bool L2, int PF>   // PF = prefetch distance of the pred / weight stream in edges (1 or 2)
-__global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
+// NWV = waves per workgroup (4: 1024-pixel chunks; 8: 2048-pixel chunks = 8 KiB contiguous per plane and edge side, half the partial records;
+// probe D3R_ALIGNER_NWV=8 at handle creation -- the partial sums are then grouped differently: same result to fp32 rounding, not bit for bit)
+template <bool L2, int PF, int NWV = 4>   // PF = prefetch distance of the pred / weight stream in edges (1 or 2)
+__global__ __launch_bounds__(NWV * 64) void aligner_main_kernel(AlignerView a) {
+    constexpr int NTH = NWV * 64, CHUNK_T = NTH * PPT;
     const int nchunk = a.nslot;
     const int img = blockIdx.x / nchunk, chunk = blockIdx.x - img * nchunk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int p0 = chunk * CHUNK + threadIdx.x * PPT;
+    const int p0 = chunk * CHUNK_T + threadIdx.x * PPT;
     const int area = a.img_area[img], W = a.img_w[img];
     const bool active = p0 < a.maxA;  // maxA % 4 == 0: the 4 pixels are in or out together
 
@@ -136,12 +139,12 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
     constexpr int EBATCH = 64;
     __shared__ int sh_es[EBATCH];
     __shared__ __attribute__((aligned(16))) float sh_M[EBATCH][12];
-    __shared__ __attribute__((aligned(16))) float sh_part[4][EBATCH][PW];   // per-wave sums, combined once per batch
+    __shared__ __attribute__((aligned(16))) float sh_part[NWV][EBATCH][PW];   // per-wave sums, combined once per batch
     const int pl = active ? p0 : 0;   // inactive lanes (beyond maxA in the last chunk) stream pixel 0 and discard it
     for (int base = a0; base < a1; base += EBATCH) {
         const int nb = min(EBATCH, a1 - base);
         __syncthreads();
-        for (int i = threadIdx.x; i < nb * 12; i += 256) {
+        for (int i = threadIdx.x; i < nb * 12; i += NTH) {
             const int j = i / 12, k = i - j * 12;
             const int es = a.adj_es[base + j];
             if (k == 0) sh_es[j] = es;
@@ -221,9 +224,10 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
         }
         // the four waves' sums of every edge of the batch -> one record per (edge side, workgroup), fixed order
         __syncthreads();
-        for (int i = threadIdx.x; i < nb * PW; i += 256) {
+        for (int i = threadIdx.x; i < nb * PW; i += NTH) {
             const int j = i / PW, v = i - j * PW;
-            const float t = (sh_part[0][j][v] + sh_part[1][j][v]) + (sh_part[2][j][v] + sh_part[3][j][v]);
+            float t = (sh_part[0][j][v] + sh_part[1][j][v]) + (sh_part[2][j][v] + sh_part[3][j][v]);
+            if constexpr (NWV == 8) t += (sh_part[4][j][v] + sh_part[5][j][v]) + (sh_part[6][j][v] + sh_part[7][j][v]);
             a.part_edge[((size_t)sh_es[j] * a.nslot + slot) * PW + v] = t;
         }
     }
@@ -275,7 +279,9 @@ __global__ __launch_bounds__(256) void aligner_main_kernel(AlignerView a) {
     __syncthreads();
     if (threadIdx.x < PW) {
         const int v = threadIdx.x;
-        a.part_img[((size_t)img * a.nslot + slot) * PW + v] = (sh_part[0][0][v] + sh_part[1][0][v]) + (sh_part[2][0][v] + sh_part[3][0][v]);
+        float t = (sh_part[0][0][v] + sh_part[1][0][v]) + (sh_part[2][0][v] + sh_part[3][0][v]);
+        if constexpr (NWV == 8) t += (sh_part[4][0][v] + sh_part[5][0][v]) + (sh_part[6][0][v] + sh_part[7][0][v]);
+        a.part_img[((size_t)img * a.nslot + slot) * PW + v] = t;
     }
 }
 
@@ -689,6 +695,7 @@ using namespace d3r;
 
 struct d3r_aligner {
     int n = 0, E = 0, maxA = 0, nslot = 0;
+    int nwv = 4;              // waves per workgroup of the main kernel (D3R_ALIGNER_NWV=8 at creation: 2048-pixel chunks)
     std::vector<int> h_w, h_h, h_area;
     int *d_w = nullptr, *d_h = nullptr, *d_area = nullptr, *d_adj_off = nullptr, *d_adj_es = nullptr;
     const float *pred[2] = {nullptr, nullptr}, *wgt[2] = {nullptr, nullptr};
@@ -732,7 +739,8 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     d3r_aligner* a = new (std::nothrow) d3r_aligner();
     if (!a) return D3R_ERR_ALLOC;
     a->n = n_imgs; a->E = n_edges; a->maxA = max_area;
-    a->nslot = cdiv(max_area, CHUNK);
+    { const char* e = getenv("D3R_ALIGNER_NWV"); a->nwv = (e && e[0] == '8') ? 8 : 4; }
+    a->nslot = cdiv(max_area, a->nwv * 64 * PPT);
     a->h_w.assign(img_w, img_w + n_imgs);
     a->h_h.assign(img_h, img_h + n_imgs);
     a->h_area.resize(n_imgs);
@@ -861,7 +869,10 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
     // D3R_ALIGNER_PF=2: two edges of the stream in flight per wave (probe; 16 more VGPRs, 3 instead of 4 waves per SIMD)
     static const int pf = [] { const char* e = getenv("D3R_ALIGNER_PF"); return (e && e[0] == '2') ? 2 : 1; }();
     const dim3 grid(a->n * a->nslot);
-    if (a->l2) {
+    if (a->nwv == 8) {
+        if (a->l2) hipLaunchKernelGGL((aligner_main_kernel<true, 1, 8>), grid, dim3(512), 0, st, v);
+        else hipLaunchKernelGGL((aligner_main_kernel<false, 1, 8>), grid, dim3(512), 0, st, v);
+    } else if (a->l2) {
         if (pf == 2) hipLaunchKernelGGL((aligner_main_kernel<true, 2>), grid, dim3(256), 0, st, v);
         else hipLaunchKernelGGL((aligner_main_kernel<true, 1>), grid, dim3(256), 0, st, v);
     } else {

@@ -53,6 +53,19 @@ def test_dpp_and_shuffle_reductions_agree(gpu):
         assert rel(g1[k], g2[k]) < 1e-5, k
 
 
+def test_workgroups_of_eight_waves_agree(gpu, monkeypatch):
+    """D3R_ALIGNER_NWV=8 (read at handle creation): the main kernel on 512-thread workgroups / 2048-pixel chunks (round 5 probe: 0.644 vs 0.655 of the HBM
+    peak on the BASELINE scene, not the default). Partial sums are grouped differently: same loss and gradients to fp32 rounding; several chunks per image."""
+    scene4, out, init, gt = make_scene(gpu, 4, 64, 96, seed=3)
+    monkeypatch.setenv('D3R_ALIGNER_NWV', '8')
+    scene8, *_ = make_scene(gpu, 4, 64, 96, seed=3)
+    l4, g4 = scene4.loss_and_grads()
+    l8, g8 = scene8.loss_and_grads()
+    assert abs(float(l4) / float(l8) - 1) < 1e-6
+    for k in g4:
+        assert rel(g4[k], g8[k]) < 1e-5, k
+
+
 def test_short_trajectory_matches_oracle(gpu):
     """First 20 Adam iterations: per-iteration losses and parameters track the fp32 oracle (torch Adam) closely."""
     from oracle.aligner_ref import AlignerRef
