@@ -32,6 +32,8 @@ struct AlignerView {
     const int* adj_es;      // [2E] entries e*2+side, grouped by projecting image
     const float* pred[2];   // PLANAR copies owned by the handle: [E][3][maxA] (x, y, z planes: unit-stride float4 loads)
     const float* wgt[2];    // [E][maxA]
+    const float* inter;     // LAY == 1: [2][E][maxAp / 256][4][256] -- per (side, edge, 256-pixel wave chunk) the x, y, z and weight runs back to back (4 KiB)
+    int maxAp;              // maxA rounded up to 256
     float* depth;           // [n][maxA] log-depth
     float* depth_m;
     float* depth_v;
@@ -94,7 +96,12 @@ D3R_DEV float4 stream_ld4(const float* p) {
 #define D3R_STREAM_LD4(ptr) stream_ld4(ptr)
 // NWV = waves per workgroup (4: 1024-pixel chunks; 8: 2048-pixel chunks = 8 KiB contiguous per plane and edge side, half the partial records;
 // probe D3R_ALIGNER_NWV=8 at handle creation -- the partial sums are then grouped differently: same result to fp32 rounding, not bit for bit)
-template <bool L2, int PF, int NWV = 4>   // PF = prefetch distance of the pred / weight stream in edges (1 or 2)
+// PROBE (measurement aid, results INVALID; D3R_ALIGNER_PROBE=1|2 at handle creation, tools/aligner_probe.py): 1 = the pred / weight stream is loaded and summed,
+// the per-edge residual math and wave reductions are skipped -- the speed at which this access pattern is delivered; 2 = math kept, wave reductions skipped
+// LAY (round 5): 0 = four separate streams per edge side (x, y, z planes of the handle's planar copy + the caller's weight rows), a wave reads four 1 KiB
+// runs megabytes apart; 1 = the handle's block-interleaved copy [side][edge][256-pixel chunk][x | y | z | w][256]: a wave reads ONE contiguous 4 KiB run,
+// a workgroup 16 KiB per edge side (D3R_ALIGNER_LAYOUT at handle creation; same loads, same arithmetic, bit-identical results)
+template <bool L2, int PF, int NWV = 4, int PROBE = 0, int LAY = 0>   // PF = prefetch distance of the pred / weight stream in edges (1 or 2)
 __global__ __launch_bounds__(NWV * 64) void aligner_main_kernel(AlignerView a) {
     constexpr int NTH = NWV * 64, CHUNK_T = NTH * PPT;
     const int nchunk = a.nslot;
@@ -152,22 +159,24 @@ __global__ __launch_bounds__(NWV * 64) void aligner_main_kernel(AlignerView a) {
         }
         __syncthreads();
         float4 nq0, nq1, nq2, nww, mq0, mq1, mq2, mww;   // edge j + 1 (and, PF == 2, edge j + 2) in flight
-        {
-            const int es = sh_es[0];
-            const float* pp = a.pred[es & 1] + (size_t)(es >> 1) * 3 * a.maxA + pl;
-            nq0 = D3R_STREAM_LD4(pp);
-            nq1 = D3R_STREAM_LD4(pp + a.maxA);
-            nq2 = D3R_STREAM_LD4(pp + 2 * (size_t)a.maxA);
-            nww = D3R_STREAM_LD4(a.wgt[es & 1] + (size_t)(es >> 1) * a.maxA + pl);
-        }
-        if (PF == 2) {
-            const int es = sh_es[nb > 1 ? 1 : 0];
-            const float* pp = a.pred[es & 1] + (size_t)(es >> 1) * 3 * a.maxA + pl;
-            mq0 = D3R_STREAM_LD4(pp);
-            mq1 = D3R_STREAM_LD4(pp + a.maxA);
-            mq2 = D3R_STREAM_LD4(pp + 2 * (size_t)a.maxA);
-            mww = D3R_STREAM_LD4(a.wgt[es & 1] + (size_t)(es >> 1) * a.maxA + pl);
-        }
+        const size_t ploff = (size_t)(pl >> 8) * 1024 + (pl & 255);     // LAY == 1: this lane's offset inside an edge side's interleaved block
+        auto stream_edge = [&](int es, float4& d0, float4& d1, float4& d2, float4& dw) __attribute__((always_inline)) {
+            if constexpr (LAY == 1) {
+                const float* pp = a.inter + ((size_t)(es & 1) * a.E + (size_t)(es >> 1)) * 4 * (size_t)a.maxAp + ploff;
+                d0 = D3R_STREAM_LD4(pp);
+                d1 = D3R_STREAM_LD4(pp + 256);
+                d2 = D3R_STREAM_LD4(pp + 512);
+                dw = D3R_STREAM_LD4(pp + 768);
+            } else {
+                const float* pp = a.pred[es & 1] + (size_t)(es >> 1) * 3 * a.maxA + pl;
+                d0 = D3R_STREAM_LD4(pp);
+                d1 = D3R_STREAM_LD4(pp + a.maxA);
+                d2 = D3R_STREAM_LD4(pp + 2 * (size_t)a.maxA);
+                dw = D3R_STREAM_LD4(a.wgt[es & 1] + (size_t)(es >> 1) * a.maxA + pl);
+            }
+        };
+        stream_edge(sh_es[0], nq0, nq1, nq2, nww);
+        if (PF == 2) stream_edge(sh_es[nb > 1 ? 1 : 0], mq0, mq1, mq2, mww);
         for (int j = 0; j < nb; ++j) {
             const int es = sh_es[j];
             const int side = es & 1;
@@ -175,16 +184,12 @@ __global__ __launch_bounds__(NWV * 64) void aligner_main_kernel(AlignerView a) {
             {   // unconditional (index clamped): a branch here would make the compiler wait for the loads at its join
                 const int jn = j + PF < nb ? j + PF : nb - 1;
                 const int es2 = sh_es[jn];
-                const float* pp = a.pred[es2 & 1] + (size_t)(es2 >> 1) * 3 * a.maxA + pl;
                 if (PF == 2) { nq0 = mq0; nq1 = mq1; nq2 = mq2; nww = mww; }
                 float4& d0 = PF == 2 ? mq0 : nq0;
                 float4& d1 = PF == 2 ? mq1 : nq1;
                 float4& d2 = PF == 2 ? mq2 : nq2;
                 float4& dw = PF == 2 ? mww : nww;
-                d0 = D3R_STREAM_LD4(pp);
-                d1 = D3R_STREAM_LD4(pp + a.maxA);
-                d2 = D3R_STREAM_LD4(pp + 2 * (size_t)a.maxA);
-                dw = D3R_STREAM_LD4(a.wgt[es2 & 1] + (size_t)(es2 >> 1) * a.maxA + pl);
+                stream_edge(es2, d0, d1, d2, dw);
             }
             float M[12];
             {
@@ -200,10 +205,20 @@ __global__ __launch_bounds__(NWV * 64) void aligner_main_kernel(AlignerView a) {
                 const float pr[PPT][3] = {{q0.x, q1.x, q2.x}, {q0.y, q1.y, q2.y}, {q0.z, q1.z, q2.z}, {q0.w, q1.w, q2.w}};   // q0 = x, q1 = y, q2 = z planes
                 const float ia = active ? a.inv_area[side] : 0.f;   // zero weight: inactive lanes contribute nothing
                 const float wv[PPT] = {ww.x * ia, ww.y * ia, ww.z * ia, ww.w * ia};
+                if constexpr (PROBE == 1) {
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) { loss += pr[k][0] + pr[k][1] + pr[k][2] + wv[k] + M[k]; g[k][0] += pr[k][0]; }
+                } else {
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) residual_accumulate(X[k], M, pr[k], wv[k], L2, loss, g[k], gm);
+                }
             }
             float red[13];
+            if constexpr (PROBE != 0) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) red[k] = gm[k];
+                red[12] = loss;
+            } else
             if (a.use_dpp) {
 #pragma unroll
                 for (int k = 0; k < 12; ++k) red[k] = gm[k];
@@ -292,6 +307,24 @@ __global__ __launch_bounds__(256) void aligner_planarize_kernel(const float* __r
         const float x = in[i * 3], y = in[i * 3 + 1], z = in[i * 3 + 2];
         float* o = out + e * 3 * (size_t)maxA + p;
         o[0] = x; o[maxA] = y; o[2 * (size_t)maxA] = z;
+    }
+}
+
+// one-time re-layout at create (LAY == 1): pred [E][maxA][3] + weights [E][maxA] of one side -> [E][maxAp / 256][x | y | z | w][256]
+__global__ __launch_bounds__(256) void aligner_interleave_kernel(const float* __restrict__ pred, const float* __restrict__ wgt, float* __restrict__ out, int E, int maxA,
+                                                                 int maxAp) {
+    const size_t total = (size_t)E * maxAp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t e = i / maxAp;
+        const int p = (int)(i - e * maxAp);
+        float x = 0.f, y = 0.f, z = 0.f, w = 0.f;
+        if (p < maxA) {
+            const float* s = pred + (e * maxA + p) * 3;
+            x = s[0]; y = s[1]; z = s[2];
+            w = wgt[e * maxA + p];
+        }
+        float* o = out + e * 4 * (size_t)maxAp + (size_t)(p >> 8) * 1024 + (p & 255);
+        o[0] = x; o[256] = y; o[512] = z; o[768] = w;
     }
 }
 
@@ -696,6 +729,10 @@ using namespace d3r;
 struct d3r_aligner {
     int n = 0, E = 0, maxA = 0, nslot = 0;
     int nwv = 4;              // waves per workgroup of the main kernel (D3R_ALIGNER_NWV=8 at creation: 2048-pixel chunks)
+    int probe = 0;            // D3R_ALIGNER_PROBE at creation (measurement aid, results INVALID)
+    int layout = 0;           // D3R_ALIGNER_LAYOUT at creation: 1 = block-interleaved stream copy (aligner_main_kernel LAY)
+    float* inter = nullptr;   // [2][E][maxAp / 256][4][256]
+    int maxAp = 0;
     std::vector<int> h_w, h_h, h_area;
     int *d_w = nullptr, *d_h = nullptr, *d_area = nullptr, *d_adj_off = nullptr, *d_adj_es = nullptr;
     const float *pred[2] = {nullptr, nullptr}, *wgt[2] = {nullptr, nullptr};
@@ -740,6 +777,11 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     if (!a) return D3R_ERR_ALLOC;
     a->n = n_imgs; a->E = n_edges; a->maxA = max_area;
     { const char* e = getenv("D3R_ALIGNER_NWV"); a->nwv = (e && e[0] == '8') ? 8 : 4; }
+    { const char* e = getenv("D3R_ALIGNER_PROBE"); a->probe = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
+    // default since round 5: the block-interleaved copy (same-process A/B, tools/aligner_probe.py, profiles/r05_k: 3998 -> 4085 it/s at 190 edges, 2142 -> 2161 at 380,
+    // bit-identical losses); D3R_ALIGNER_LAYOUT=0: the planar copy + the caller's weight rows (rounds 1-4)
+    { const char* e = getenv("D3R_ALIGNER_LAYOUT"); a->layout = (!(e && e[0] == '0') && a->nwv == 4 && !a->probe) ? 1 : 0; }
+    a->maxAp = (max_area + 255) / 256 * 256;
     a->nslot = cdiv(max_area, a->nwv * 64 * PPT);
     a->h_w.assign(img_w, img_w + n_imgs);
     a->h_h.assign(img_h, img_h + n_imgs);
@@ -805,15 +847,24 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     (void)hipMemcpy(a->d_area, a->h_area.data(), n_imgs * sizeof(int), hipMemcpyHostToDevice);
     (void)hipMemcpy(a->d_adj_off, off.data(), (n_imgs + 1) * sizeof(int), hipMemcpyHostToDevice);
     (void)hipMemcpy(a->d_adj_es, es.data(), 2 * (size_t)n_edges * sizeof(int), hipMemcpyHostToDevice);
-    {
+    if (a->layout != 1) {
         const size_t npix = (size_t)n_edges * max_area;
         if (hipMalloc((void**)&a->planar, 2 * npix * 3 * sizeof(float)) != hipSuccess) { (void)hipFree(a->state); (void)hipFree(a->d_w); delete a; return D3R_ERR_ALLOC; }
         const int grid = (int)((npix + 255) / 256 < 65536 ? (npix + 255) / 256 : 65536);
-        if (poison) (void)hipMemsetAsync(a->planar, 0xFF, 2 * npix * 3 * sizeof(float), st);
+        if (poison) (void)hipMemsetAsync(a->planar, 0xFF, 2 * npix * 3 * sizeof(float), st);   // (layout 1: every float of the interleaved copy is written by its kernel, padding included)
         hipLaunchKernelGGL(aligner_planarize_kernel, dim3(grid), dim3(256), 0, st, pred_i, a->planar, npix, max_area);
         hipLaunchKernelGGL(aligner_planarize_kernel, dim3(grid), dim3(256), 0, st, pred_j, a->planar + npix * 3, npix, max_area);
         if (hipGetLastError() != hipSuccess) { (void)hipFree(a->planar); (void)hipFree(a->state); (void)hipFree(a->d_w); delete a; return D3R_ERR_LAUNCH; }
         a->pred[0] = a->planar; a->pred[1] = a->planar + npix * 3;
+    }
+    if (a->layout == 1) {
+        const size_t per_side = (size_t)n_edges * 4 * a->maxAp;
+        if (hipMalloc((void**)&a->inter, 2 * per_side * sizeof(float)) != hipSuccess) { (void)hipFree(a->planar); (void)hipFree(a->state); (void)hipFree(a->d_w); delete a; return D3R_ERR_ALLOC; }
+        const size_t total = (size_t)n_edges * a->maxAp;
+        const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+        hipLaunchKernelGGL(aligner_interleave_kernel, dim3(grid), dim3(256), 0, st, pred_i, w_i, a->inter, n_edges, max_area, a->maxAp);
+        hipLaunchKernelGGL(aligner_interleave_kernel, dim3(grid), dim3(256), 0, st, pred_j, w_j, a->inter + per_side, n_edges, max_area, a->maxAp);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(a->inter); (void)hipFree(a->planar); (void)hipFree(a->state); (void)hipFree(a->d_w); delete a; return D3R_ERR_LAUNCH; }
     }
     a->create_stream = st;
     if (hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(a->ev_ready, st);
@@ -826,6 +877,7 @@ extern "C" int d3r_aligner_destroy(d3r_aligner* a) {
     if (!a) return D3R_OK;
     if (a->ev_ready) (void)hipEventDestroy(a->ev_ready);
     (void)hipFree(a->planar);
+    if (a->inter) (void)hipFree(a->inter);
     (void)hipFree(a->state);
     (void)hipFree(a->d_w);
     delete a;
@@ -861,7 +913,7 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
     }
     AlignerView v;
     v.n = a->n; v.E = a->E; v.maxA = a->maxA; v.nslot = a->nslot; v.img_w = a->d_w; v.img_area = a->d_area;
-    v.adj_off = a->d_adj_off; v.adj_es = a->d_adj_es; v.pred[0] = a->pred[0]; v.pred[1] = a->pred[1];
+    v.adj_off = a->d_adj_off; v.adj_es = a->d_adj_es; v.pred[0] = a->pred[0]; v.pred[1] = a->pred[1]; v.inter = a->inter; v.maxAp = a->maxAp;
     v.wgt[0] = a->wgt[0]; v.wgt[1] = a->wgt[1]; v.depth = a->im_depth; v.depth_m = a->depth_m; v.depth_v = a->depth_v;
     v.depth_grad = g_depth; v.d_edge = a->d_edge; v.d_img = a->d_img; v.part_edge = a->part_edge; v.part_img = a->part_img;
     v.inv_area[0] = a->inv_area[0]; v.inv_area[1] = a->inv_area[1]; v.l2 = a->l2; v.update = update ? 1 : 0;
@@ -869,7 +921,13 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
     // D3R_ALIGNER_PF=2: two edges of the stream in flight per wave (probe; 16 more VGPRs, 3 instead of 4 waves per SIMD)
     static const int pf = [] { const char* e = getenv("D3R_ALIGNER_PF"); return (e && e[0] == '2') ? 2 : 1; }();
     const dim3 grid(a->n * a->nslot);
-    if (a->nwv == 8) {
+    if (a->probe && !a->l2) {
+        if (a->probe == 1) hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 1>), grid, dim3(256), 0, st, v);
+        else hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 2>), grid, dim3(256), 0, st, v);
+    } else if (a->layout == 1) {
+        if (a->l2) hipLaunchKernelGGL((aligner_main_kernel<true, 1, 4, 0, 1>), grid, dim3(256), 0, st, v);
+        else hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 0, 1>), grid, dim3(256), 0, st, v);
+    } else if (a->nwv == 8) {
         if (a->l2) hipLaunchKernelGGL((aligner_main_kernel<true, 1, 8>), grid, dim3(512), 0, st, v);
         else hipLaunchKernelGGL((aligner_main_kernel<false, 1, 8>), grid, dim3(512), 0, st, v);
     } else if (a->l2) {

@@ -218,9 +218,10 @@ int d3r_model_debug_read(d3r_model* m, int what, float* out_f32, size_t max_elem
  *   pw_poses [E][8] = quat XYZW, signed-log translation, log scale;  pw_adaptors [E][2] (frozen);
  *   im_poses [n][7];  im_depthmaps [n][max_area] log-depth;  im_focals [n] = focal_break*log(f);  im_pp [n][2] (frozen)
  * They live in caller-owned device memory and are updated IN PLACE; the handle borrows them and the weight
- * tensors until destroy. pred_* [E][max_area][3] (read ONCE at create: the handle keeps its own planar
- * [E][3][max_area] copy so that the hot loop streams unit-stride float4s), w_* [E][max_area] = conf_trf(conf)
- * (zero in padding), fp32. ei/ej/img_h/img_w are HOST arrays. Alignment: pw_poses, im_depthmaps, pred_*, w_* 16 bytes, pw_adaptors 8
+ * tensors until destroy. pred_* [E][max_area][3] and w_* [E][max_area] = conf_trf(conf) (zero in padding), fp32, are read ONCE at create:
+ * the handle keeps its own block-interleaved copy [side][E][max_area / 256][x | y | z | w][256], so that a wave of the hot loop streams one
+ * contiguous 4 KiB run per edge side (environment D3R_ALIGNER_LAYOUT=0 at creation: a planar [E][3][max_area] copy of pred_* and the caller's
+ * w_* rows, which are then borrowed until destroy like the parameters). ei/ej/img_h/img_w are HOST arrays. Alignment: pw_poses, im_depthmaps, pred_*, w_* 16 bytes, pw_adaptors 8
  * (D3R_ERR_INVALID otherwise; any torch allocation satisfies it). create enqueues its one-off work (clearing the Adam state, the planar
  * copy of pred_*) on `stream` and does not synchronise the device: pred_* must be complete on that stream, and may be freed once it has
  * drained; run / loss_grad on the same stream need no further ordering, and on ANOTHER stream they first wait for an event the create
