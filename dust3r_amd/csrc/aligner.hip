@@ -922,7 +922,8 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
     static const int pf = [] { const char* e = getenv("D3R_ALIGNER_PF"); return (e && e[0] == '2') ? 2 : 1; }();
     const dim3 grid(a->n * a->nslot);
     if (a->probe && !a->l2) {
-        if (a->probe == 1) hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 1>), grid, dim3(256), 0, st, v);
+        if (a->probe == 1 && pf == 2) hipLaunchKernelGGL((aligner_main_kernel<false, 2, 4, 1>), grid, dim3(256), 0, st, v);
+        else if (a->probe == 1) hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 1>), grid, dim3(256), 0, st, v);
         else hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 2>), grid, dim3(256), 0, st, v);
     } else if (a->layout == 1) {
         if (a->l2) hipLaunchKernelGGL((aligner_main_kernel<true, 1, 4, 0, 1>), grid, dim3(256), 0, st, v);
