@@ -556,6 +556,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-latency', action='store_true', help='skip the latency block (1 / 2 / 4 / 8 pairs per call)')
+    ap.add_argument('--no-aligner-380', action='store_true', help='skip the second aligner scene (the demo\'s symmetrised graph, 380 edges): under rocprofv3 its launches would be averaged into the same kernel symbol as the BASELINE scene\'s')
     ap.add_argument('--no-fast', '--no-accurate', dest='no_fast', action='store_true', help='skip the fast_mode block (fp16f8 / bf16 / fp16 throughput + their measured error)')
     ap.add_argument('--single-stream', action='store_true', help='keep decoder side 2 / head 2 on the main stream (serialised kernels: use under rocprofv3 so that per-kernel durations are not inflated by overlap)')
     args = ap.parse_args()
@@ -771,6 +772,8 @@ def main():
                 result['aligner'], scene_io = bench_aligner(device)
                 log(f"[bench] aligner {result['aligner']['value']:.1f} iters/s, {result['aligner']['roofline']['achieved']:.0f} GB/s algorithmic")
                 try:        # the same 20 views with the demo's symmetrised pair graph (380 edges, 2.48 GB per iteration): reported beside the BASELINE scene
+                    if args.no_aligner_380:
+                        raise RuntimeError('skipped (--no-aligner-380)')
                     a380, _ = bench_aligner(device, symmetrize=True)
                     result['aligner']['symmetrized_380_edges'] = {k: a380[k] for k in ('value', 'unit', 'n_edges', 'ms_total', 'ms_runs', 'final_loss', 'roofline')}
                     log(f"[bench] aligner, 380 edges: {a380['value']:.1f} iters/s, {a380['roofline']['achieved']:.0f} GB/s algorithmic")

@@ -24,12 +24,12 @@ for w in $WHAT; do
         D3R_PROBE_DT=fp16f8 timeout 300 python tools/gpu_probe.py gemmtrace > $OUT/gemmtrace_f8.log 2>&1; tail -12 $OUT/gemmtrace_f8.log ;;
     benchq) timeout 600 python bench.py --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.log; grep -E "bench\]" $OUT/bench_quick.log | tail -60 ;;
     bench) timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.log; tail -12 $OUT/bench.log; cat $OUT/bench.json ;;
-    prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast --no-parity --no-latency --single-stream > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.log); find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
-    pmc) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_fetch -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fast --no-parity --no-latency --single-stream > /dev/null 2> $OLDPWD/$OUT/pmc_fetch.log);
-         (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_write -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fast --no-parity --no-latency --single-stream > /dev/null 2> $OLDPWD/$OUT/pmc_write.log); ls $OUT/pmc_fetch $OUT/pmc_write ;;
+    prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast --no-parity --no-latency --no-aligner-380 --single-stream > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.log); find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
+    pmc) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_fetch -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fast --no-parity --no-latency --no-aligner-380 --single-stream > /dev/null 2> $OLDPWD/$OUT/pmc_fetch.log);
+         (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_write -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fast --no-parity --no-latency --no-aligner-380 --single-stream > /dev/null 2> $OLDPWD/$OUT/pmc_write.log); ls $OUT/pmc_fetch $OUT/pmc_write ;;
     pmcsq) # issue / MFMA-busy / wait breakdown per kernel (SQ has 8 slots per pass, GRBM is separate); two passes, kernel-trace only
-         (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OLDPWD/$OUT/pmc_sq1 -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fast --no-parity --no-latency --single-stream > /dev/null 2> $OLDPWD/$OUT/pmc_sq1.log);
-         (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OLDPWD/$OUT/pmc_sq2 -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fast --no-parity --no-latency --single-stream > /dev/null 2> $OLDPWD/$OUT/pmc_sq2.log); tail -3 $OUT/pmc_sq1.log $OUT/pmc_sq2.log; ls $OUT/pmc_sq1 $OUT/pmc_sq2 ;;
+         (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OLDPWD/$OUT/pmc_sq1 -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fast --no-parity --no-latency --no-aligner-380 --single-stream > /dev/null 2> $OLDPWD/$OUT/pmc_sq1.log);
+         (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OLDPWD/$OUT/pmc_sq2 -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fast --no-parity --no-latency --no-aligner-380 --single-stream > /dev/null 2> $OLDPWD/$OUT/pmc_sq2.log); tail -3 $OUT/pmc_sq1.log $OUT/pmc_sq2.log; ls $OUT/pmc_sq1 $OUT/pmc_sq2 ;;
   esac
 done
 # summarise the per-dispatch PMC csvs (sum / mean per kernel) and keep the merged-back payload small
