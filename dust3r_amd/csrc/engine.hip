@@ -74,6 +74,7 @@ struct d3r_model {
     // and norm1 / norm2 / norm3 / norm_y of the decoder blocks are not launched -- the fp32-residual epilogue in front of them also stores the RAW
     // typed rows and per-row partial sums, the nn.Linear behind them is packed as W diag(gamma) and applies rstd / mean in its epilogue.
     // enc_norm / dec_norm (their outputs leave the engine or feed the heads) stay kernels. D3R_LN_FOLD=0|1 at model creation.
+    int enc_split_max = 0;    // encoder of calls with <= this many images (two views): the two views as two concurrent chains on the two streams (D3R_ENC_SPLIT)
     bool ln_fold = false, fold_dirty = false;
     std::vector<Lin*> fold_lins;
     std::unordered_map<std::string, Slot> slots;
@@ -488,6 +489,7 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
     if (const char* e = getenv("D3R_GRAPH_MAX_PAIRS")) m->graph_max_pairs = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("D3R_ENC_SPLIT")) m->enc_split_max = atoi(e) > 0 ? atoi(e) : 0;
     (void)hipDeviceSynchronize();
     *out = m;
     return D3R_OK;
@@ -841,54 +843,84 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
             // ---- encoder: all images of the call in one pass when the views share a size (model.py:142-151 concatenates the
             // two views), else view 1's images then view 2's (model.py:148-150) -----------------------------------------------
             const size_t pk = 3 * (size_t)ps * ps;
-            const int npass = same ? 1 : 2;
-            for (int pass = 0; pass < npass; ++pass) {
-                const SideDim& dd = D[pass];
-                const int n_img = same ? nimg : (pass == 0 ? nimg1 : nimg - nimg1);
-                if (n_img <= 0) continue;
-                const int Mp = n_img * dd.N;
-                const size_t row0 = (same || pass == 0) ? 0 : (size_t)nimg1 * d0.N;
-                float* xp = x + row0 * Ce;
-                if (same) {
-                    if (nimg1 > 0) D3R_OTHER(launch_patchify(m->dt, img1, hb, nimg1, dd.H, dd.W, ps, st));
-                    if (nimg > nimg1) D3R_OTHER(launch_patchify(m->dt, img2, (char*)hb + (size_t)nimg1 * dd.N * pk * eb, nimg - nimg1, dd.H, dd.W, ps, st));
-                } else {
-                    D3R_OTHER(launch_patchify(m->dt, pass == 0 ? img1 : img2, hb, n_img, dd.H, dd.W, ps, st));
-                }
-                if (fold) {
-                    // every fp32-residual epilogue also stores the raw typed rows (xn) and their partial sums; the LayerNorm itself is two fmas in
-                    // the epilogue of the nn.Linear behind it (weights packed as W diag(gamma)): 2 x enc_depth LayerNorm launches become
-                    // 2 x enc_depth row-statistics launches of 1 / 64 the traffic
-                    // The residual stream itself lives in those typed rows (GF_X3RES: xn is read as the residual and rewritten in place, 22
-                    // significand bits -- what every LayerNorm output was rounded to anyway); no fp32 row is stored in the blocks.
-                    const LnStats es{e_rs, e_nm};
-                    gemm_linear(c, hb, (int)pk, m->patch, Mp, EPI_F32, nullptr, Ce, nullptr, xn, Ce, -1, GF_X3RES, LnStats(), e_part);
-                    for (int l = 0; l < cf.enc_depth; ++l) {
-                        const EncBlk& b = m->enc[l];
-                        const bool last = l + 1 == cf.enc_depth;        // enc_norm (a kernel) follows: no sums
-                        D3R_OTHER(launch_ln_finalize(e_part, Mp, Ce, 1e-6f, e_rs, e_nm, st));
-                        self_attention(c, xn, b.qkv, Mp, Ce, He, n_img, dd.N, dd.tw, dd.ldv, q, k, vt, ao, es);
-                        gemm_linear(c, ao, Ce, b.proj, Mp, EPI_F32, nullptr, Ce, xn, xn, Ce, -1, GF_X3RES, LnStats(), e_part);
-                        D3R_OTHER(launch_ln_finalize(e_part, Mp, Ce, 1e-6f, e_rs, e_nm, st));
-                        gemm_linear(c, xn, Ce, b.fc1, Mp, EPI_GELU, hb, 4 * Ce, nullptr, nullptr, 0, -1, 0, es);
-                        gemm_linear(c, hb, 4 * Ce, b.fc2, Mp, EPI_F32, nullptr, Ce, xn, xn, Ce, -1, GF_X3RES, LnStats(), last ? nullptr : e_part);
-                    }
-                    D3R_OTHER(launch_layernorm_x3in(xn, m->enc_norm.g, m->enc_norm.b, (char*)encn + row0 * Ce * eb, Mp, Ce, 1e-6f, st));
-                    continue;
-                } else {
-                gemm_linear(c, hb, (int)pk, m->patch, Mp, EPI_F32, xp, Ce);
-                for (int l = 0; l < cf.enc_depth; ++l) {
-                    const EncBlk& b = m->enc[l];
-                    D3R_OTHER(launch_layernorm(m->bdt, xp, b.n1.g, b.n1.b, xn, Mp, Ce, 1e-6f, st));
-                    self_attention(c, xn, b.qkv, Mp, Ce, He, n_img, dd.N, dd.tw, dd.ldv, q, k, vt, ao);
-                    gemm_linear(c, ao, Ce, b.proj, Mp, EPI_F32, xp, Ce, xp);
-                    D3R_OTHER(launch_layernorm(m->bdt, xp, b.n2.g, b.n2.b, xn, Mp, Ce, 1e-6f, st));
-                    gemm_linear(c, xn, Ce, b.fc1, Mp, EPI_GELU, hb, 4 * Ce);
-                    gemm_linear(c, hb, 4 * Ce, b.fc2, Mp, EPI_F32, xp, Ce, xp);
-                }
-                }
-                D3R_OTHER(launch_layernorm(m->dt, xp, m->enc_norm.g, m->enc_norm.b, (char*)encn + row0 * Ce * eb, Mp, Ce, 1e-6f, st));
+            // Encoder work is a list of GROUPS of images of one size: one group (both views) when the views share a size, else one per view. Round 5: small calls
+            // (<= enc_split_max images, two views, two streams on) run the two views as two groups CONCURRENTLY, view 2 on the model's second stream with its
+            // own rows of every scratch buffer -- one pair per call is a dependent chain of kernels that each fill a fraction of the chip, and two
+            // independent chains fill it better (what the decoder's two sides already do). Same kernels on the same rows: bit-identical.
+            struct EncGroup { const float* im[2]; int n[2]; const SideDim* dd; size_t row0; int img0; hipStream_t s; bool off; };
+            EncGroup groups[2];
+            int ngroups = 0;
+            const bool split = two && nimg1 > 0 && nimg > nimg1 && nimg <= m->enc_split_max;
+            if (same && !split) {
+                groups[ngroups++] = EncGroup{{img1, img2}, {nimg1, nimg - nimg1}, &D[0], 0, 0, st, false};
+            } else {
+                if (nimg1 > 0) groups[ngroups++] = EncGroup{{img1, nullptr}, {nimg1, 0}, &D[0], 0, 0, st, split};
+                if (nimg > nimg1) groups[ngroups++] = EncGroup{{img2, nullptr}, {nimg - nimg1, 0}, &D[same ? 0 : 1], (size_t)nimg1 * d0.N, nimg1, split ? S[1] : st, split};
             }
+            if (split) {      // view 2's stream starts behind everything the caller's stream holds (the images, the v^T clear)
+                c.chk(hipEventRecord(m->ev_main, S[0]));
+                c.chk(hipStreamWaitEvent(S[1], m->ev_main, 0));
+            }
+            // phase -1: patches + patch embedding; 0 .. depth - 1: block l; depth: enc_norm
+            auto enc_phase = [&](const EncGroup& g, int phase) {
+                const SideDim& dd = *g.dd;
+                const int n_img = g.n[0] + g.n[1];
+                const int Mp = n_img * dd.N;
+                c.st = g.s;
+                // a group that runs next to another one works in its own rows of the scratch buffers (sequential groups reuse them from row 0, as before)
+                const size_t ro = g.off ? g.row0 : 0;
+                float* xp = x + g.row0 * Ce;
+                void* gxn = (char*)xn + ro * Ce * eb;
+                void* gq = (char*)q + ro * Ce * eb;
+                void* gk = (char*)k + ro * Ce * eb;
+                void* gvt = (char*)vt + (size_t)(g.off ? g.img0 : 0) * He * 64 * dd.ldv * eb;
+                void* gao = (char*)ao + ro * Ce * eb;
+                void* ghb = (char*)hb + ro * 4 * Ce * eb;        // hidden rows; the patches of the group start at the same place
+                float* gpart = fold ? e_part + ro * Ge * 2 : nullptr;
+                float* grs = fold ? e_rs + ro : nullptr;
+                float* gnm = fold ? e_nm + ro : nullptr;
+                const LnStats es{grs, gnm};
+                if (phase < 0) {
+                    if (g.n[0] > 0) D3R_OTHER(launch_patchify(m->dt, g.im[0], ghb, g.n[0], dd.H, dd.W, ps, c.st));
+                    if (g.n[1] > 0) D3R_OTHER(launch_patchify(m->dt, g.im[1], (char*)ghb + (size_t)g.n[0] * dd.N * pk * eb, g.n[1], dd.H, dd.W, ps, c.st));
+                    // fold: every residual epilogue stores the typed rows (the residual stream itself, GF_X3RES) and their partial sums; the LayerNorm is two fmas in
+                    // the epilogue of the nn.Linear behind it (weights packed as W diag(gamma)) -- DESIGN 4.0
+                    if (fold) gemm_linear(c, ghb, (int)pk, m->patch, Mp, EPI_F32, nullptr, Ce, nullptr, gxn, Ce, -1, GF_X3RES, LnStats(), gpart);
+                    else gemm_linear(c, ghb, (int)pk, m->patch, Mp, EPI_F32, xp, Ce);
+                } else if (phase < cf.enc_depth) {
+                    const EncBlk& b = m->enc[phase];
+                    if (fold) {
+                        const bool last = phase + 1 == cf.enc_depth;        // enc_norm (a kernel) follows: no sums
+                        D3R_OTHER(launch_ln_finalize(gpart, Mp, Ce, 1e-6f, grs, gnm, c.st));
+                        self_attention(c, gxn, b.qkv, Mp, Ce, He, n_img, dd.N, dd.tw, dd.ldv, gq, gk, gvt, gao, es);
+                        gemm_linear(c, gao, Ce, b.proj, Mp, EPI_F32, nullptr, Ce, gxn, gxn, Ce, -1, GF_X3RES, LnStats(), gpart);
+                        D3R_OTHER(launch_ln_finalize(gpart, Mp, Ce, 1e-6f, grs, gnm, c.st));
+                        gemm_linear(c, gxn, Ce, b.fc1, Mp, EPI_GELU, ghb, 4 * Ce, nullptr, nullptr, 0, -1, 0, es);
+                        gemm_linear(c, ghb, 4 * Ce, b.fc2, Mp, EPI_F32, nullptr, Ce, gxn, gxn, Ce, -1, GF_X3RES, LnStats(), last ? nullptr : gpart);
+                    } else {
+                        D3R_OTHER(launch_layernorm(m->bdt, xp, b.n1.g, b.n1.b, gxn, Mp, Ce, 1e-6f, c.st));
+                        self_attention(c, gxn, b.qkv, Mp, Ce, He, n_img, dd.N, dd.tw, dd.ldv, gq, gk, gvt, gao);
+                        gemm_linear(c, gao, Ce, b.proj, Mp, EPI_F32, xp, Ce, xp);
+                        D3R_OTHER(launch_layernorm(m->bdt, xp, b.n2.g, b.n2.b, gxn, Mp, Ce, 1e-6f, c.st));
+                        gemm_linear(c, gxn, Ce, b.fc1, Mp, EPI_GELU, ghb, 4 * Ce);
+                        gemm_linear(c, ghb, 4 * Ce, b.fc2, Mp, EPI_F32, xp, Ce, xp);
+                    }
+                } else {
+                    void* dst = (char*)encn + g.row0 * Ce * eb;
+                    if (fold) D3R_OTHER(launch_layernorm_x3in(gxn, m->enc_norm.g, m->enc_norm.b, dst, Mp, Ce, 1e-6f, c.st));
+                    else D3R_OTHER(launch_layernorm(m->dt, xp, m->enc_norm.g, m->enc_norm.b, dst, Mp, Ce, 1e-6f, c.st));
+                }
+            };
+            if (split) {       // layer by layer, so that both streams have work queued from the start
+                for (int phase = -1; phase <= cf.enc_depth; ++phase)
+                    for (int gi = 0; gi < ngroups; ++gi) enc_phase(groups[gi], phase);
+                c.chk(hipEventRecord(m->ev_side, S[1]));           // the caller's stream continues behind view 2's encoder
+                c.chk(hipStreamWaitEvent(S[0], m->ev_side, 0));
+            } else {
+                for (int gi = 0; gi < ngroups; ++gi)
+                    for (int phase = -1; phase <= cf.enc_depth; ++phase) enc_phase(groups[gi], phase);
+            }
+            c.st = st;
             m->last_encn = encn; m->last_encn_elems = (size_t)Me * Ce;
         }
         if (do_dec) {

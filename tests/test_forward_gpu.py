@@ -722,3 +722,29 @@ def test_layernorm_fold_full_size_against_oracle(gpu, monkeypatch):
     d1, d2 = folded.decode_pairs(feat, 384, 512)
     assert torch.equal(d1['pts3d'], b1['pts3d']) and torch.equal(d2['conf'], b2['conf'])
     folded._destroy_engine()
+
+
+def test_encoder_views_on_two_streams_is_bit_identical(gpu, monkeypatch):
+    """D3R_ENC_SPLIT=n at engine creation (round 5 probe, default off: measured 10.05 vs 10.10 ms for one 512x384 pair, slower from four pairs on): calls of at most n
+    images run the encoder of view 1 and of view 2 as two concurrent chains on the engine's two streams, each in its own rows of every scratch buffer. Same kernels on the
+    same rows: bit-identical to the one-chain schedule, for pairs of one and of two image sizes, folded LayerNorm on and off."""
+    from oracle.dust3r_ref import build_ref_model
+    oracle = build_ref_model('tiny_dpt')
+    g = torch.Generator().manual_seed(5)
+    cases = []
+    for hw1, hw2 in (((64, 96), (64, 96)), ((32, 48), (48, 32)), ((128, 128), (128, 128))):
+        cases.append((dict(img=torch.rand((2, 3) + hw1, generator=g) * 2 - 1, true_shape=torch.tensor([hw1] * 2, dtype=torch.int32), idx=[0, 2], instance=['0', '2']),
+                      dict(img=torch.rand((2, 3) + hw2, generator=g) * 2 - 1, true_shape=torch.tensor([hw2] * 2, dtype=torch.int32), idx=[1, 3], instance=['1', '3'])))
+    for fold in ('1', '0'):
+        monkeypatch.setenv('D3R_LN_FOLD', fold)
+        outs = {}
+        for split in ('0', '64'):
+            monkeypatch.setenv('D3R_ENC_SPLIT', split)
+            eng = engine_from_oracle(oracle, 'tiny_dpt', 'fp16x3', gpu)
+            outs[split] = []
+            for v1, v2 in cases:
+                e1, e2 = eng(v1, v2)
+                outs[split].append((e1['pts3d'].clone(), e1['conf'].clone(), e2['pts3d_in_other_view'].clone(), e2['conf'].clone()))
+            eng._destroy_engine()
+        for a, b in zip(outs['0'], outs['64']):
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
