@@ -4,7 +4,9 @@ trained ViTs (sharp attention, outlier channels x40 / x150: tests/test_forward_g
 ||pts_hip - pts_ref||_2 / max(||pts_ref||_2, eps) per pixel with eps = 1e-8 (no floor), both views of one pair; reported: max, 99.99th
 and 99th percentile, mean, and the smallest |pts| relative to the mean (how close the random network's pointmap comes to the origin,
 where the ratio is ill-conditioned for any arithmetic).
-Usage (GPU box): python tools/oracle_survey.py [n_seeds]      (about 5 s per weight set: one CPU oracle forward + three engine modes)"""
+Usage (GPU box): python tools/oracle_survey.py [n_seeds] [ln]      (about 5 s per weight set: one CPU oracle forward + three engine modes)
+`ln` (round 5): every LayerNorm weight 1 + 0.3 N(0, 1) and bias 0.2 N(0, 1) instead of the identity affine of build_ref_model_fast, so that the fold of the blocks' LayerNorms
+into the GEMMs around them (D3R_LN_FOLD=0 in the environment = the LayerNorm kernels) is measured on non-trivial gamma / beta."""
 import sys
 import time
 
@@ -17,10 +19,22 @@ from oracle import tune_threads  # noqa: E402
 from oracle.dust3r_ref import build_ref_model_fast  # noqa: E402
 
 MODEL = 'DUSt3R_ViTLarge_BaseDecoder_512_dpt'
-n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 6
+RANDOM_LN = 'ln' in sys.argv
+
+
+def random_ln(model, seed):
+    if not RANDOM_LN:
+        return model
+    g = torch.Generator().manual_seed(1000 + seed)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if 'norm' in name and prm.ndim == 1:
+                prm.copy_(1 + 0.3 * torch.randn(prm.shape, generator=g) if name.endswith('weight') else 0.2 * torch.randn(prm.shape, generator=g))
+    return model
 dev = torch.device('cuda:0')
 tune_threads()
-MODES = ('fp32', 'fp16x3', 'fp16f8')
+MODES = ('fp32', 'fp16x3')
 
 
 def outlier_weights(oracle, big):
@@ -61,12 +75,13 @@ def survey(tag, oracle, view_seed, worst):
     torch.cuda.empty_cache()
 
 
-print(f'{MODEL}, one 512x384 pair per weight set, engine vs the CPU oracle; eps = 1e-8')
+import os  # noqa: E402
+print(f'{MODEL}, one 512x384 pair per weight set, engine vs the CPU oracle; eps = 1e-8; random LayerNorm affines: {RANDOM_LN}; D3R_LN_FOLD={os.environ.get("D3R_LN_FOLD", "(default: on)")}')
 worst_plain, worst_out = {}, {}
 for seed in range(n_seeds):
-    survey(f'random weights, seed {seed}', build_ref_model_fast(MODEL, seed=seed), 100 + seed, worst_plain)
+    survey(f'random weights, seed {seed}', random_ln(build_ref_model_fast(MODEL, seed=seed), seed), 100 + seed, worst_plain)
 for big in (40.0, 150.0):
-    oracle = build_ref_model_fast(MODEL, seed=0)
+    oracle = random_ln(build_ref_model_fast(MODEL, seed=0), 0)
     outlier_weights(oracle, big)
     survey(f'sharp attn + outliers x{big:g}', oracle, 3, worst_out)
 for name, w in (('random weights', worst_plain), ('sharp attention + outlier channels', worst_out)):
