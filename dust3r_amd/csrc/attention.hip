@@ -309,7 +309,11 @@ D3R_DEV float xor32_sum(float v) {
 // (it holds the SIMD's issue port twice as long, and the matrix pipe's next instruction waits behind it) -- 64 of them per tile and wave here.
 // Same values bit for bit (the packed forms are two independent IEEE operations). attention.hip is compiled with -fno-slp-vectorize so that
 // hipcc does not re-pack the scalar pairs (dust3r_amd/build.py).
-template <int ODT, int PROBE = 0, int NW = 4, bool DMA = false, bool SC = false>
+// LZ (round 5): LAZY running maximum. The maximum a query's exponents are taken against moves only when the tile's maximum exceeds it by more than 6 octaves
+// (p = exp2(s c - m c) then stays <= 64: far inside fp16's range for the hi / lo split, fp32 for the row sum), so that on most tiles NO query of the wave moves it,
+// alpha = 1 everywhere, and the 32 multiplications per lane that rescale the O accumulators are skipped behind one wave-uniform branch (with an eager maximum at
+// least one of a wave's 32 queries moves it on nearly every tile of a 768-key row). The result is the same softmax(QK^T)V up to fp32 rounding of differently scaled partial sums.
+template <int ODT, int PROBE = 0, int NW = 4, bool DMA = false, bool SC = false, bool LZ = false>
 __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TR = Traits<D3R_F16X3>;
@@ -408,6 +412,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
 
     const int ntiles = (p.Nk + 63) / 64;
     const float c = p.scale * 1.44269504088896340736f;  // fold log2(e): p = exp2(s c - m c)
+    const float lz_thr = 6.0f / c;                        // LZ: six octaves, in score units
     const int koff = DMA ? l31 * KROW : l31 * KROW + hh * 32;   // this lane's K row (/ group inside a 32-key block: padded image)
     const int voff = DMA ? l31 * VROW : l31 * VROW + hh * 8;    // this lane's V^T row (/ 4-key slot: padded image)
     // swizzled images: byte offsets inside the 256-byte row. K: chunk 4 ks + 2 hh + lo; V^T: logical slot 2 g (+ 1: second 8-key group, + 8: lo plane)
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
                 }
         }
         float mt = -1e30f, m_new = 0.f, alpha = 1.f, mcn = 0.f;
+        bool resc = true;                             // LZ: does any query of this wave move its maximum on this tile (wave-uniform)
         v2f_t ps2 = {0.f, 0.f}, aa = {0.f, 0.f};      // row sum; the pair of exponents in flight between two slices
         float ps0 = 0.f, ps1 = 0.f, aa0 = 0.f, aa1 = 0.f;   // SC: the same as four scalars (the pins below carry whichever set is live)
         u32x4_t pH[2], pL[2];                         // P operands of PV group g in set g & 1 (hi and lo halves)
@@ -516,7 +522,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
         const v2f_t xv_ = {x_, y_};                                                                        \
         const h2v_t hh_ = __builtin_convertvector(xv_, h2v_t);                                             \
         v2f_t dv_;                                                                                         \
-        if constexpr (SC) { const float d0_ = (x_) - (float)hh_[0], d1_ = (y_) - (float)hh_[1]; dv_ = (v2f_t){d0_, d1_}; }   /* two v_sub_f32 */ \
+        if constexpr (SC) {   /* x - float(hi) as ONE v_fma_mix_f32 per element: the f16 -> f32 conversion rides in the instruction (hipcc emits v_cvt_f32_f16 + v_sub_f32 for the C form) */ \
+            float d0_, d1_;                                                                                \
+            const unsigned hu_ = __builtin_bit_cast(unsigned, hh_);                                        \
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0_) : "v"(hu_), "v"(x_));        \
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1_) : "v"(hu_), "v"(y_)); \
+            dv_ = (v2f_t){d0_, d1_};                                                                       \
+        }                                                                                                  \
         else dv_ = xv_ - __builtin_convertvector(hh_, v2f_t);                                              \
         const h2v_t ll_ = __builtin_convertvector(dv_, h2v_t);                                             \
         hv_[idx_] = __builtin_bit_cast(unsigned, hh_); lv_[idx_] = __builtin_bit_cast(unsigned, ll_);      \
@@ -534,7 +546,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
                 mt = fmaxf(fmaxf(mt, sv[r0 + 6]), sv[r0 + 7]);
             } else if (v == 4) {               // lanes l and l ^ 32 share a query
                 mt = xor32_max(mt);
+                if constexpr (LZ) {
+                    m_new = mt > m_run + lz_thr ? mt : m_run;
+                    resc = __builtin_amdgcn_ballot_w64(m_new != m_run) != 0ull;
+                } else {
                 m_new = fmaxf(m_run, mt);
+                }
                 alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
                 mcn = -m_new * c;
                 if constexpr (SC) {
@@ -570,7 +587,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
                     aa = __builtin_elementwise_fma(sv, c2, m2);
                     }
                 }
-                if (i == 16) {                 // rescale O: first d-block (the PV MFMAs of this tile come after phase A)
+                if (i == 16 && resc) {         // rescale O: first d-block (the PV MFMAs of this tile come after phase A)
                     if constexpr (SC) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) o[0][r] *= alpha;
@@ -585,6 +602,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
                     }
                 }
             } else if (v == 22) {              // second d-block
+                if (!resc) {
+                } else
                 if constexpr (SC) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[1][r] *= alpha;
@@ -731,18 +750,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(AttnParams p) 
     }
 }
 
-template <int ODT, int PROBE, int NW = 4, bool DMA = false, bool SC = false> static hipError_t launch_x3_v2p(const AttnParams& p, hipStream_t s) {
+template <int ODT, int PROBE, int NW = 4, bool DMA = false, bool SC = false, bool LZ = false> static hipError_t launch_x3_v2p(const AttnParams& p, hipStream_t s) {
     constexpr int LDS = DMA ? 4 * 64 * 256 : 2 * 64 * (256 + 16) + 2 * 64 * (256 + 8);
     static std::atomic<unsigned long long> attr_done{0};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     const unsigned long long dev_bit = 1ull << (dev_id & 63);
     if (!(attr_done.load(std::memory_order_relaxed) & dev_bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_x3_kernel<ODT, PROBE, NW, DMA, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_x3_kernel<ODT, PROBE, NW, DMA, SC, LZ>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done.fetch_or(dev_bit, std::memory_order_relaxed);
     }
     const int grid = p.B * p.H * ((p.Nq + NW * 32 - 1) / (NW * 32));
-    hipLaunchKernelGGL((attention_x3_kernel<ODT, PROBE, NW, DMA, SC>), dim3(grid), dim3(NW * 64), LDS, s, p);
+    hipLaunchKernelGGL((attention_x3_kernel<ODT, PROBE, NW, DMA, SC, LZ>), dim3(grid), dim3(NW * 64), LDS, s, p);
     return hipGetLastError();
 }
 template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream_t s) {
@@ -775,6 +794,8 @@ template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream
     // Measured in one process on one box (tools/ab_probe.py, profiles/r05_b/ab_probe.log, three alternating repetitions of the 32-pair forward):
     // attention 21.20 -> 20.72 ms per step, forward 171.29 -> 170.83 ms.
     const char* e_sc = getenv("D3R_ATTN_SC");
+    const char* e_lz = getenv("D3R_ATTN_LAZY");          // 1: lazy running maximum (round 5 probe; read per launch)
+    if ((e_dma ? e_dma[0] != '0' : true) && !(e_sc && e_sc[0] == '0') && e_lz && e_lz[0] == '1') return launch_x3_v2p<ODT, 0, 4, true, true, true>(p, s);
     if ((e_dma ? e_dma[0] != '0' : true) && !(e_sc && e_sc[0] == '0')) return launch_x3_v2p<ODT, 0, 4, true, true>(p, s);
     if (e_dma ? e_dma[0] != '0' : true) return launch_x3_v2p<ODT, 0, 4, true>(p, s);
     return launch_x3_v2p<ODT, 0>(p, s);
