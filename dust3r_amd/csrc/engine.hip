@@ -74,6 +74,9 @@ struct d3r_model {
     // and norm1 / norm2 / norm3 / norm_y of the decoder blocks are not launched -- the fp32-residual epilogue in front of them also stores the RAW
     // typed rows and per-row partial sums, the nn.Linear behind them is packed as W diag(gamma) and applies rstd / mean in its epilogue.
     // enc_norm / dec_norm (their outputs leave the engine or feed the heads) stay kernels. D3R_LN_FOLD=0|1 at model creation.
+    int ln_inline_rows = 0;   // probe D3R_LN_INLINE_ROWS=n: folded LayerNorms of at most n rows get their statistics in the consumer's prologue (GemmParams::ln_part_in) instead
+                              // of an ln_finalize launch. Bit-identical; measured SLOWER (one pair 10.57 vs 10.17 ms, four 27.2 vs 25.5: profiles/r05_v) -- the fp64 butterflies
+                              // in front of every tile cost more than the launch they replace. Default 0 = always launch.
     int enc_split_max = 0;    // encoder of calls with <= this many images (two views): the two views as two concurrent chains on the two streams (D3R_ENC_SPLIT)
     bool ln_fold = false, fold_dirty = false;
     std::vector<Lin*> fold_lins;
@@ -372,14 +375,14 @@ static inline int prf_kind(int base, int cfg) { return cfg == GEMM_CFG_384x192 ?
 
 // folded LayerNorm (kernels.hpp GemmParams::ln_*): `stats` = the consumer side (rstd, -mean rstd of the input rows; the Lin carries column sums and
 // folded bias), `part` = the producer side (partial sums of the rows this launch stores, next to their raw typed copy out2)
-struct LnStats { const float* rstd = nullptr; const float* nmr = nullptr; };
+struct LnStats { const float* rstd = nullptr; const float* nmr = nullptr; const float* part_in = nullptr; };   // part_in: small problem, the consumer forms rstd / nmr itself (no ln_finalize launch)
 void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi, void* out, int ldo, const void* res1 = nullptr,
                  void* out2 = nullptr, int ldo2 = 0, int n_store = -1, int flags = 0, LnStats stats = LnStats(), float* part = nullptr) {
     GemmParams p;
     p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_rows = L.n_rows;
     p.n_store = n_store >= 0 ? n_store : L.N;
     p.epi = epi; p.out = out; p.ldo = ldo; p.res1 = res1; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo2; p.flags = flags;
-    if (stats.rstd) { p.ln_rstd = stats.rstd; p.ln_nmr = stats.nmr; p.ln_colsum = L.ln_s; p.bias = L.b_fold; }
+    if (stats.rstd) { p.ln_rstd = stats.rstd; p.ln_nmr = stats.nmr; p.ln_colsum = L.ln_s; p.bias = L.b_fold; p.ln_part_in = stats.part_in; p.ln_inv_c = 1.0f / (float)L.K; }
     p.ln_part = part;
     c.mark(prf_kind((L.dt == D3R_F16F8 || L.dt == D3R_F16X2F8) ? PRF_GEMM_F8 : PRF_GEMM, gemm_pick_config(p, L.dt)), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(L.dt, p, c.st));
@@ -389,7 +392,7 @@ void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_
                 int ntok, int tok_w, int ldv, LnStats stats = LnStats()) {
     GemmParams p;
     p.act = act; p.lda = lda; p.wgt = L.w; p.bias = L.b; p.M = M; p.K = L.K; p.n_pad = L.n_pad; p.n_rows = L.n_rows; p.n_store = L.N;
-    if (stats.rstd) { p.ln_rstd = stats.rstd; p.ln_nmr = stats.nmr; p.ln_colsum = L.ln_s; p.bias = L.b_fold; }
+    if (stats.rstd) { p.ln_rstd = stats.rstd; p.ln_nmr = stats.nmr; p.ln_colsum = L.ln_s; p.bias = L.b_fold; p.ln_part_in = stats.part_in; p.ln_inv_c = 1.0f / (float)L.K; }
     p.epi = EPI_HEADS; p.head_c = head_c;
     for (int i = 0; i < nreg; ++i) { p.head_kind[i] = kinds[i]; p.head_dst[i] = dsts[i]; }
     p.heads = heads; p.ntok = ntok; p.tok_w = tok_w; p.ldv = ldv; p.rope_table = c.m->rope_table;
@@ -490,6 +493,7 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
         hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
     if (const char* e = getenv("D3R_GRAPH_MAX_PAIRS")) m->graph_max_pairs = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("D3R_ENC_SPLIT")) m->enc_split_max = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("D3R_LN_INLINE_ROWS")) m->ln_inline_rows = atoi(e) > 0 ? atoi(e) : 0;
     (void)hipDeviceSynchronize();
     *out = m;
     return D3R_OK;
@@ -805,6 +809,8 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
     // of that output, one per side for the block-internal norm2 / norm3 (s_)
     const bool fold = m->ln_fold;
     const int Ge = Ce / 32, Gd = Cd / 32;
+    // rows up to which a folded LayerNorm's statistics are formed in the consumer GEMM's prologue instead of by a launch (D3R_LN_INLINE_ROWS; 0 = always launch)
+    const int inline_rows = m->ln_inline_rows;
     float *e_part = nullptr, *e_rs = nullptr, *e_nm = nullptr, *l_part[2] = {nullptr, nullptr}, *l_rs[2] = {nullptr, nullptr}, *l_nm[2] = {nullptr, nullptr};
     float *s_part[2] = {nullptr, nullptr}, *s_rs[2] = {nullptr, nullptr}, *s_nm[2] = {nullptr, nullptr};
     void* fr[2] = {nullptr, nullptr};
@@ -879,7 +885,8 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                 float* gpart = fold ? e_part + ro * Ge * 2 : nullptr;
                 float* grs = fold ? e_rs + ro : nullptr;
                 float* gnm = fold ? e_nm + ro : nullptr;
-                const LnStats es{grs, gnm};
+                const bool inl = fold && Mp <= inline_rows;
+                const LnStats es{grs, gnm, inl ? gpart : nullptr};
                 if (phase < 0) {
                     if (g.n[0] > 0) D3R_OTHER(launch_patchify(m->dt, g.im[0], ghb, g.n[0], dd.H, dd.W, ps, c.st));
                     if (g.n[1] > 0) D3R_OTHER(launch_patchify(m->dt, g.im[1], (char*)ghb + (size_t)g.n[0] * dd.N * pk * eb, g.n[1], dd.H, dd.W, ps, c.st));
@@ -891,10 +898,10 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                     const EncBlk& b = m->enc[phase];
                     if (fold) {
                         const bool last = phase + 1 == cf.enc_depth;        // enc_norm (a kernel) follows: no sums
-                        D3R_OTHER(launch_ln_finalize(gpart, Mp, Ce, 1e-6f, grs, gnm, c.st));
+                        if (!inl) D3R_OTHER(launch_ln_finalize(gpart, Mp, Ce, 1e-6f, grs, gnm, c.st));
                         self_attention(c, gxn, b.qkv, Mp, Ce, He, n_img, dd.N, dd.tw, dd.ldv, gq, gk, gvt, gao, es);
                         gemm_linear(c, gao, Ce, b.proj, Mp, EPI_F32, nullptr, Ce, gxn, gxn, Ce, -1, GF_X3RES, LnStats(), gpart);
-                        D3R_OTHER(launch_ln_finalize(gpart, Mp, Ce, 1e-6f, grs, gnm, c.st));
+                        if (!inl) D3R_OTHER(launch_ln_finalize(gpart, Mp, Ce, 1e-6f, grs, gnm, c.st));
                         gemm_linear(c, gxn, Ce, b.fc1, Mp, EPI_GELU, ghb, 4 * Ce, nullptr, nullptr, 0, -1, 0, es);
                         gemm_linear(c, ghb, 4 * Ce, b.fc2, Mp, EPI_F32, nullptr, Ce, gxn, gxn, Ce, -1, GF_X3RES, LnStats(), last ? nullptr : gpart);
                     } else {
@@ -928,7 +935,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
         void* frp[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // fold: raw typed copy of layer output [buffer][side] (fr, or a DPT hook buffer at the hook layers)
         if (fold) {
             gemm_linear(c, encn, Ce, m->dec_embed, M2d, EPI_F32, nullptr, Cd, nullptr, fr[0], Cd, -1, GF_X3RES, LnStats(), l_part[0]);
-            D3R_OTHER(launch_ln_finalize(l_part[0], M2d, Cd, 1e-6f, l_rs[0], l_nm[0], st));
+            if (!(Ms[0] <= inline_rows && Ms[1] <= inline_rows)) D3R_OTHER(launch_ln_finalize(l_part[0], M2d, Cd, 1e-6f, l_rs[0], l_nm[0], st));
             for (int sd = 0; sd < 2; ++sd) frp[0][sd] = (char*)fr[0] + (size_t)Roff[sd] * Cd * eb;
         } else {
         gemm_linear(c, encn, Ce, m->dec_embed, M2d, EPI_F32, f[0], Cd);
@@ -957,12 +964,16 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                 const float* yo = f[cur] + (size_t)Roff[1 - s] * Cd;     // other view (old)
                 float* xw = f[cur ^ 1] + (size_t)Roff[s] * Cd;           // own stream (new)
                 if (fold) {
-                    const LnStats sx{l_rs[cur] + Roff[s], l_nm[cur] + Roff[s]}, sy{l_rs[cur] + Roff[1 - s], l_nm[cur] + Roff[1 - s]}, ss{s_rs[s], s_nm[s]};
+                    // small problems: the consumers form rstd / nmr of their input rows themselves (the set of side t has Ms[t] rows whoever consumes it)
+                    const bool inl_own = Ms[s] <= inline_rows, inl_oth = Ms[1 - s] <= inline_rows;
+                    const LnStats sx{l_rs[cur] + Roff[s], l_nm[cur] + Roff[s], inl_own ? l_part[cur] + (size_t)Roff[s] * Gd * 2 : nullptr},
+                                  sy{l_rs[cur] + Roff[1 - s], l_nm[cur] + Roff[1 - s], inl_oth ? l_part[cur] + (size_t)Roff[1 - s] * Gd * 2 : nullptr},
+                                  ss{s_rs[s], s_nm[s], inl_own ? s_part[s] : nullptr};
                     self_attention(c, frp[cur][s], b.qkv, Ms[s], Cd, Hd, B, own.N, own.tw, own.ldv, sq, sk, svt, sao, sx);      // norm1 folded
                     // the residual stream is the typed rows themselves (GF_X3RES): layer input frp[cur][s] -> sxn (after self attention, then in place after
                     // cross attention) -> the next layer's input fr[cur ^ 1] (or a DPT hook buffer)
                     gemm_linear(c, sao, Cd, b.proj, Ms[s], EPI_F32, nullptr, Cd, frp[cur][s], sxn, Cd, -1, GF_X3RES, LnStats(), s_part[s]);
-                    D3R_OTHER(launch_ln_finalize(s_part[s], Ms[s], Cd, 1e-6f, s_rs[s], s_nm[s], c.st));
+                    if (!inl_own) D3R_OTHER(launch_ln_finalize(s_part[s], Ms[s], Cd, 1e-6f, s_rs[s], s_nm[s], c.st));
                     {
                         const int kq[1] = {HEAD_ROPE};
                         void* dq[1] = {sq};
@@ -977,7 +988,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                         c.chk(launch_attention(m->dt, a, c.st));
                     }
                     gemm_linear(c, sao, Cd, b.cproj, Ms[s], EPI_F32, nullptr, Cd, sxn, sxn, Cd, -1, GF_X3RES, LnStats(), s_part[s]);
-                    D3R_OTHER(launch_ln_finalize(s_part[s], Ms[s], Cd, 1e-6f, s_rs[s], s_nm[s], c.st));
+                    if (!inl_own) D3R_OTHER(launch_ln_finalize(s_part[s], Ms[s], Cd, 1e-6f, s_rs[s], s_nm[s], c.st));
                     gemm_linear(c, sxn, Cd, b.fc1, Ms[s], EPI_GELU, shb, 4 * Cd, nullptr, nullptr, 0, -1, 0, ss);                 // norm3 folded
                     const int layer_no = l + 1;
                     void* hcopy = (cf.head_type == 1 && (layer_no == hk6 || layer_no == hk9)) ? hook[s][layer_no == hk6 ? 0 : 1] : nullptr;
@@ -985,7 +996,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                     void* raw = hcopy ? hcopy : (void*)((char*)fr[cur ^ 1] + (size_t)Roff[s] * Cd * eb);
                     float* lp = layer_no == cf.dec_depth ? nullptr : l_part[cur ^ 1] + (size_t)Roff[s] * Gd * 2;
                     gemm_linear(c, shb, 4 * Cd, b.fc2, Ms[s], EPI_F32, nullptr, Cd, sxn, raw, Cd, -1, GF_X3RES, LnStats(), lp);
-                    if (lp) D3R_OTHER(launch_ln_finalize(lp, Ms[s], Cd, 1e-6f, l_rs[cur ^ 1] + Roff[s], l_nm[cur ^ 1] + Roff[s], c.st));
+                    if (lp && !inl_own) D3R_OTHER(launch_ln_finalize(lp, Ms[s], Cd, 1e-6f, l_rs[cur ^ 1] + Roff[s], l_nm[cur ^ 1] + Roff[s], c.st));
                     frp[cur ^ 1][s] = raw;
                     continue;
                 }

@@ -199,6 +199,34 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     // swapped for that block (square tiles only) so that a lane owns 4 consecutive tokens.
     const bool vt_wide = (DT == D3R_BF16 || DT == D3R_F16) && p.epi == EPI_HEADS && (p.ntok & 63) == 0 && !(p.flags & GF_NOWIDE);
     const bool swap = !vt_wide && (BM == BN) && (p.epi == EPI_HEADS) && (head_kind_of(p, n0 / p.head_c) == HEAD_VT);
+    // Folded LayerNorm, SMALL problems (GemmParams::ln_part_in, the one- to four-pair forwards): the rstd / -mean rstd of this tile's BM rows are formed HERE from the
+    // producer's partial sums instead of by a launch of ln_finalize_kernel between the two GEMMs (9 us in a dependent chain of ~25 us kernels). The arithmetic IS that
+    // kernel's -- 32 lanes per row, pairs g and g + 32 added in fp64, xor butterfly 1 .. 16 -- so a row's statistics are bit-identical whichever route formed them
+    // (the batch-vs-one-pair tests compare the two). Every column tile of a row panel writes the same values to the same addresses and reads back what it wrote itself;
+    // the stores are complete before the epilogue through the K loop's barriers (each waits vmcnt(0)).
+    if constexpr (DT == D3R_F16X3) {
+        if (p.ln_part_in) {
+            const int G = p.K >> 5;
+            const double inv_c = (double)p.ln_inv_c;      // 1 / C as the host rounds it: the value ln_finalize_kernel is launched with
+            for (int t = tid; t < BM * 32; t += CF::NT) {
+                const int g = t & 31, m = m0 + (t >> 5);
+                const float2* pr = reinterpret_cast<const float2*>(p.ln_part_in) + (size_t)min(m, p.M - 1) * G;
+                double sm = 0.0, sq = 0.0;
+                if (g < G) { const float2 v = pr[g]; sm = (double)v.x; sq = (double)v.y; }
+                if (g + 32 < G) { const float2 v = pr[g + 32]; sm += (double)v.x; sq += (double)v.y; }
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+                if (g == 0 && m < p.M) {
+                    const double mean = sm * inv_c;
+                    double var = sq * inv_c - mean * mean;
+                    var = var > 0.0 ? var : 0.0;
+                    const float rs = (float)(1.0 / sqrt(var + (double)p.ln_eps));
+                    const_cast<float*>(p.ln_rstd)[m] = rs;
+                    const_cast<float*>(p.ln_nmr)[m] = (float)(-mean) * rs;
+                }
+            }
+        }
+    }
 
     // ---- staging addresses (per lane: one 16-byte chunk of APASS activation rows and WPASS weight rows) ---
     const int lrow = wave * CF::RPI + lane / CF::CPR;                // row inside a PASS_ROWS slab
@@ -2176,6 +2204,7 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     // folded LayerNorm (kernels.hpp): statistics come out of the wide fp32 epilogue only; the consumer side exists for split-fp16 operands, typed / GELU / head outputs
     if (p.ln_part && (p.epi != EPI_F32 || !(p.flags & GF_X3RES) || p.n_store % 32 != 0)) return hipErrorInvalidValue;   // the row sums come out of the typed-stream epilogue
     if ((p.flags & GF_X3RES) && (dt != D3R_F16X3 || p.epi != EPI_F32 || (p.flags & GF_NOWIDE) || !p.out2 || (p.ldo2 & 7) || (p.n_store & 7) || (p.res1 && (p.ldr & 7)))) return hipErrorInvalidValue;
+    if (p.ln_part_in && (!p.ln_rstd || p.K % 32 != 0 || p.K > 2048)) return hipErrorInvalidValue;
     if (p.ln_rstd && (dt != D3R_F16X3 || !p.ln_nmr || !p.ln_colsum || p.amode != AMODE_LINEAR || !(p.epi == EPI_T || p.epi == EPI_GELU || p.epi == EPI_HEADS) || p.res1 || p.res2 || p.out2)) return hipErrorInvalidValue;
     // fp16 + fp8 rows: nn.Linear operands only, whole 64-element super-groups; outputs: fp32 (+ residual), GELU / plain activation rows, heads
     const bool f8rows = dt == D3R_F16F8 || dt == D3R_F16X2F8;

@@ -61,6 +61,9 @@ struct GemmParams {
     //   runs on (1, 0, 0): fma(acc, 1, fma(0, 0, b)) = acc + b bit for bit.
     float* ln_part = nullptr;
     const float* ln_rstd = nullptr; const float* ln_nmr = nullptr; const float* ln_colsum = nullptr;
+    // CONSUMER of a small problem: the partial sums [M][K / 32][2] of its input rows; the kernel's prologue then forms ln_rstd / ln_nmr of its tile's rows itself (and WRITES
+    // them to those two arrays) with the arithmetic of ln_finalize_kernel, which is not launched
+    const float* ln_part_in = nullptr; float ln_eps = 1e-6f, ln_inv_c = 0.f;
     int x3res_nt = 0;            // GF_X3RES: typed-stream stores with the non-temporal policy (probe D3R_GEMM_X3NT=1; default plain: the rows are re-read at once)
     int f8_proxy = 0;            // MEASUREMENT AID (D3R_F8_PROXY=1, results INVALID): fp16 + fp8 K loop with the MFMA mix of a 2.5-unit scheme (4 f16 + 1/2 fp8 MFMA per 64 k)
 };

@@ -748,3 +748,27 @@ def test_encoder_views_on_two_streams_is_bit_identical(gpu, monkeypatch):
             eng._destroy_engine()
         for a, b in zip(outs['0'], outs['64']):
             assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_layernorm_statistics_in_the_consumer_prologue_are_bit_identical(gpu, monkeypatch):
+    """D3R_LN_INLINE_ROWS=n at engine creation (round 5 probe, default off: measured slower): folded LayerNorms of at most n rows get rstd / -mean rstd from the consumer GEMM's prologue
+    instead of an ln_finalize launch. The prologue repeats that kernel's arithmetic (32 lanes per row, fp64 butterfly), so outputs are bit-identical -- which is what keeps a batch bit-equal
+    to its one-pair calls if the two ever take different routes."""
+    from oracle.dust3r_ref import build_ref_model
+    oracle = _randomize_norms(build_ref_model('tiny_dpt'), seed=5)
+    monkeypatch.setenv('D3R_LN_FOLD', '1')
+    outs = {}
+    g = torch.Generator().manual_seed(8)
+    cases = [synthetic_views(3, 128, 128, seed=2), synthetic_views(2, 32, 48, seed=3),
+             (dict(img=torch.rand((2, 3, 64, 128), generator=g) * 2 - 1, true_shape=torch.tensor([(64, 128)] * 2, dtype=torch.int32), idx=[0, 2], instance=['0', '2']),
+              dict(img=torch.rand((2, 3, 128, 64), generator=g) * 2 - 1, true_shape=torch.tensor([(128, 64)] * 2, dtype=torch.int32), idx=[1, 3], instance=['1', '3']))]
+    for rows in ('0', '1000000'):
+        monkeypatch.setenv('D3R_LN_INLINE_ROWS', rows)
+        eng = engine_from_oracle(oracle, 'tiny_dpt', 'fp16x3', gpu)
+        outs[rows] = []
+        for v1, v2 in cases:
+            e1, e2 = eng(v1, v2)
+            outs[rows].append((e1['pts3d'].clone(), e2['pts3d_in_other_view'].clone(), e2['conf'].clone()))
+        eng._destroy_engine()
+    for a, b in zip(outs['0'], outs['1000000']):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
