@@ -98,6 +98,12 @@ struct d3r_model {
     hipStream_t side = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     bool two_streams = true;
+    // Cross-attention K | V of a decoder block read the OTHER side's previous-layer output, not the side's own chain: with at most kv_ahead_rows rows per side (calls of
+    // a few pairs: a chain of launches that each fill a fraction of the chip) they run on a third / fourth stream beside the block's self attention, into their own K / V^T
+    // buffers, and the side's stream waits for them in front of the cross attention. Same kernels on the same rows: bit-identical. D3R_DEC_KV_AHEAD=rows (0 = off).
+    hipStream_t kvs[2] = {nullptr, nullptr};
+    hipEvent_t ev_kv_go[2] = {nullptr, nullptr}, ev_kv_done[2] = {nullptr, nullptr};
+    int kv_ahead_rows = 0;
     PostMode post;                          // depth_mode / conf_mode of the heads (d3r_model_set_postprocess; default = the released checkpoints')
     int out_pstride = 3, out_cstride = 1;   // output element strides between pixels (8, 8 while d3r_model_forward_packed runs)
     // ---- hipGraph replay of small-batch forwards (d3r_model_forward* with B <= graph_max_pairs) ------------------------------------
@@ -494,6 +500,10 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     if (const char* e = getenv("D3R_GRAPH_MAX_PAIRS")) m->graph_max_pairs = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("D3R_ENC_SPLIT")) m->enc_split_max = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("D3R_LN_INLINE_ROWS")) m->ln_inline_rows = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("D3R_DEC_KV_AHEAD")) m->kv_ahead_rows = atoi(e) > 0 ? atoi(e) : 0;
+    for (int s = 0; s < 2; ++s)
+        if (hipStreamCreateWithFlags(&m->kvs[s], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_kv_go[s], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&m->ev_kv_done[s], hipEventDisableTiming) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
     (void)hipDeviceSynchronize();
     *out = m;
     return D3R_OK;
@@ -507,6 +517,11 @@ extern "C" int d3r_model_destroy(d3r_model* m) {
     if (m->ev_main) (void)hipEventDestroy(m->ev_main);
     if (m->ev_side) (void)hipEventDestroy(m->ev_side);
     if (m->side) (void)hipStreamDestroy(m->side);
+    for (int s = 0; s < 2; ++s) {
+        if (m->ev_kv_go[s]) (void)hipEventDestroy(m->ev_kv_go[s]);
+        if (m->ev_kv_done[s]) (void)hipEventDestroy(m->ev_kv_done[s]);
+        if (m->kvs[s]) (void)hipStreamDestroy(m->kvs[s]);
+    }
     m->drop_graphs();
     if (m->cap) (void)hipStreamDestroy(m->cap);
     if (m->ws) (void)hipFree(m->ws);
@@ -814,7 +829,10 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
     float *e_part = nullptr, *e_rs = nullptr, *e_nm = nullptr, *l_part[2] = {nullptr, nullptr}, *l_rs[2] = {nullptr, nullptr}, *l_nm[2] = {nullptr, nullptr};
     float *s_part[2] = {nullptr, nullptr}, *s_rs[2] = {nullptr, nullptr}, *s_nm[2] = {nullptr, nullptr};
     void* fr[2] = {nullptr, nullptr};
+    void *ckb = nullptr, *cvtb = nullptr;      // cross-attention K / V^T of the two sides when they are projected ahead on their own streams (d3r_model::kvs)
     if (fold) {
+        ckb = ar.take((size_t)2 * Mmax * Cd * eb);
+        cvtb = ar.take((size_t)2 * B * Hd * 64 * ldv_max * eb);
         e_part = (float*)ar.take((size_t)Me * Ge * 8); e_rs = (float*)ar.take((size_t)Me * 4 + 16); e_nm = (float*)ar.take((size_t)Me * 4 + 16);
         for (int b = 0; b < 2; ++b) {
             fr[b] = ar.take((size_t)M2d * Cd * eb);
@@ -845,6 +863,8 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
             c.chk(hipStreamWaitEvent(S[1], m->ev_main, 0));
         };
         if (d0.ldv != d0.N || d1.ldv != d1.N) D3R_OTHER(hipMemsetAsync(vt, 0, (size_t)nvt * Hmax * 64 * ldv_max * eb, st));
+        const bool kva = two && fold && do_dec && m->kvs[0] && m->kvs[1] && Mmax <= m->kv_ahead_rows;
+        if (kva && (d0.ldv != d0.N || d1.ldv != d1.N)) D3R_OTHER(hipMemsetAsync(cvtb, 0, (size_t)2 * B * Hd * 64 * ldv_max * eb, st));
         if (do_enc) {
             // ---- encoder: all images of the call in one pass when the views share a size (model.py:142-151 concatenates the
             // two views), else view 1's images then view 2's (model.py:148-150) -----------------------------------------------
@@ -969,6 +989,22 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                     const LnStats sx{l_rs[cur] + Roff[s], l_nm[cur] + Roff[s], inl_own ? l_part[cur] + (size_t)Roff[s] * Gd * 2 : nullptr},
                                   sy{l_rs[cur] + Roff[1 - s], l_nm[cur] + Roff[1 - s], inl_oth ? l_part[cur] + (size_t)Roff[1 - s] * Gd * 2 : nullptr},
                                   ss{s_rs[s], s_nm[s], inl_own ? s_part[s] : nullptr};
+                    void* xk = sk;
+                    void* xvt = svt;
+                    if (kva) {
+                        // S[s] stands behind the layer boundary here (the other side's rows and statistics are complete) and behind this side's previous cross attention
+                        // (the last reader of xk / xvt): the projection may start now, beside the self attention
+                        xk = (char*)ckb + (size_t)s * Mmax * Cd * eb;
+                        xvt = (char*)cvtb + (size_t)s * B * Hd * 64 * ldv_max * eb;
+                        c.chk(hipEventRecord(m->ev_kv_go[s], S[s]));
+                        c.chk(hipStreamWaitEvent(m->kvs[s], m->ev_kv_go[s], 0));
+                        c.st = m->kvs[s];
+                        const int kkv[2] = {HEAD_ROPE, HEAD_VT};
+                        void* dkv[2] = {xk, xvt};
+                        gemm_heads(c, frp[cur][1 - s], Cd, b.ckv, Ms[1 - s], Cd, 2, kkv, dkv, Hd, oth.N, oth.tw, oth.ldv, sy);
+                        c.chk(hipEventRecord(m->ev_kv_done[s], m->kvs[s]));
+                        c.st = S[s];
+                    }
                     self_attention(c, frp[cur][s], b.qkv, Ms[s], Cd, Hd, B, own.N, own.tw, own.ldv, sq, sk, svt, sao, sx);      // norm1 folded
                     // the residual stream is the typed rows themselves (GF_X3RES): layer input frp[cur][s] -> sxn (after self attention, then in place after
                     // cross attention) -> the next layer's input fr[cur ^ 1] (or a DPT hook buffer)
@@ -978,11 +1014,14 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
                         const int kq[1] = {HEAD_ROPE};
                         void* dq[1] = {sq};
                         gemm_heads(c, sxn, Cd, b.cq, Ms[s], Cd, 1, kq, dq, Hd, own.N, own.tw, own.ldv, ss);                     // norm2 folded
+                        if (kva) c.chk(hipStreamWaitEvent(S[s], m->ev_kv_done[s], 0));
+                        else {
                         const int kkv[2] = {HEAD_ROPE, HEAD_VT};
                         void* dkv[2] = {sk, svt};
                         gemm_heads(c, frp[cur][1 - s], Cd, b.ckv, Ms[1 - s], Cd, 2, kkv, dkv, Hd, oth.N, oth.tw, oth.ldv, sy);  // norm_y folded: the other side's raw rows and statistics
+                        }
                         AttnParams a;
-                        a.q = sq; a.k = sk; a.vt = svt; a.out = sao; a.B = B; a.H = Hd; a.Nq = own.N; a.Nk = oth.N; a.ldv = oth.ldv; a.scale = 0.125f;
+                        a.q = sq; a.k = xk; a.vt = xvt; a.out = sao; a.B = B; a.H = Hd; a.Nq = own.N; a.Nk = oth.N; a.ldv = oth.ldv; a.scale = 0.125f;
                         a.out_dt = m->bdt;
                         c.mark(PRF_ATTN, 4.0 * B * Hd * (double)own.N * oth.N * 64, B * Hd, own.N, oth.N);
                         c.chk(launch_attention(m->dt, a, c.st));

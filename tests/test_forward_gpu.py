@@ -772,3 +772,32 @@ def test_layernorm_statistics_in_the_consumer_prologue_are_bit_identical(gpu, mo
         eng._destroy_engine()
     for a, b in zip(outs['0'], outs['1000000']):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_cross_attention_kv_projected_ahead_is_bit_identical(gpu, monkeypatch):
+    """D3R_DEC_KV_AHEAD=rows at engine creation: the decoder blocks' cross-attention K | V projection (its input is the OTHER side's previous-layer output, not the
+    side's own chain) runs on a third / fourth stream beside the self attention, into its own K / V^T buffers. Same kernels, same rows: bit-identical to the in-line
+    schedule -- equal views, a ragged token count (96 tokens: V^T rows padded to 128), views of two sizes (Nq != Nk), and repeated calls on one engine (buffer reuse
+    across the layer boundaries and across calls)."""
+    from oracle.dust3r_ref import build_ref_model
+    oracle = _randomize_norms(build_ref_model('tiny_dpt'), seed=6)
+    g = torch.Generator().manual_seed(9)
+    cases = [synthetic_views(3, 128, 128, seed=2), synthetic_views(2, 128, 192, seed=3), synthetic_views(1, 64, 64, seed=4),
+             (dict(img=torch.rand((2, 3, 64, 128), generator=g) * 2 - 1, true_shape=torch.tensor([(64, 128)] * 2, dtype=torch.int32), idx=[0, 2], instance=['0', '2']),
+              dict(img=torch.rand((2, 3, 128, 64), generator=g) * 2 - 1, true_shape=torch.tensor([(128, 64)] * 2, dtype=torch.int32), idx=[1, 3], instance=['1', '3']))]
+    outs = {}
+    for rows in ('0', '1000000'):
+        monkeypatch.setenv('D3R_DEC_KV_AHEAD', rows)
+        eng = engine_from_oracle(oracle, 'tiny_dpt', 'fp16x3', gpu)
+        outs[rows] = []
+        for rep in range(2):
+            for v1, v2 in cases:
+                e1, e2 = eng(v1, v2)
+                outs[rows].append((e1['pts3d'].clone(), e1['conf'].clone(), e2['pts3d_in_other_view'].clone(), e2['conf'].clone()))
+        torch.cuda.synchronize()
+        eng._destroy_engine()
+    for a, b in zip(outs['0'], outs['1000000']):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    n = len(cases)
+    for i in range(n):       # and the second round of calls reproduces the first
+        assert all(torch.equal(x, y) for x, y in zip(outs['1000000'][i], outs['1000000'][n + i]))

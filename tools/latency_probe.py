@@ -1,82 +1,58 @@
-"""GPU probe (not product, not a test): where is the engine launch-bound rather than throughput-bound?
- * forward at B = 1, 2, 4, 8, 32 pairs per call (the reference demo calls inference() with batch_size = 1);
- * aligner iterations/s on small scenes (PairViewer-size to the BASELINE scene).
-Usage (GPU box): python tools/latency_probe.py"""
+"""Same-process A/B of switches the engine reads AT CREATION (D3R_DEC_KV_AHEAD, D3R_LN_INLINE_ROWS, D3R_ENC_SPLIT, D3R_GRAPH_MAX_PAIRS ...)
+on the small-batch forwards of the bench's latency block: one engine per arm on the same weights, alternating repetitions, back-to-back calls of
+1 / 2 / 4 / 8 (and optionally more) pairs of 512x384 in the default precision; the outputs of the arms are compared bit for bit.
+Usage: python tools/latency_probe.py VAR=a,b[,c] [--reps=3] [--pairs=1,2,4,8]"""
+import os
 import sys
 import time
 
-import torch
-
 sys.path.insert(0, '.')
-from bench import build_model, H, W  # noqa: E402
-from dust3r_amd.synthetic import synthetic_scene, synthetic_views  # noqa: E402
+import torch  # noqa: E402
 
-
-def timed_forward(model, B, dev):
-    v1, v2 = synthetic_views(B, H, W, seed=0, device=dev)
-    for _ in range(4):
-        model(v1, v2)
-    torch.cuda.synchronize()
-    n = 20 if B <= 8 else 5
-    t = time.perf_counter()
-    for _ in range(n):
-        model(v1, v2)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t) / n
+import bench  # noqa: E402
 
 
 def main():
-    import os
-    dev = torch.device('cuda', 0)
-    model = build_model('fp16x3', dev)
-    if 'small-tiles' in sys.argv:
-        # the 64 x 64 GEMM tile of the small-batch forwards: crossover sweep (D3R_GEMM_T64 = 128x128-tile count below which it is taken; 0 = never)
-        for ns in ('2', '3', '4'):
-            os.environ['D3R_GEMM_64NS'] = ns
-            for t64 in ('0', '200', '400', '1000'):
-                os.environ['D3R_GEMM_T64'] = t64
-                print(f'D3R_GEMM_64NS={ns} D3R_GEMM_T64={t64:5s}: ' + '  '.join(f'B={B}: {timed_forward(model, B, dev) * 1e3:7.2f} ms' for B in (1, 2, 3, 4, 6, 8)), flush=True)
-        os.environ.pop('D3R_GEMM_T64')
-        os.environ.pop('D3R_GEMM_64NS')
-        # where the one-pair forward spends its time (event-profiled launches; adds event overhead)
-        from bench import read_launch_table, read_profile
-        for t64 in ('0', None):
-            if t64 is not None:
-                os.environ['D3R_GEMM_T64'] = t64
-            else:
-                os.environ.pop('D3R_GEMM_T64', None)
-            v1, v2 = synthetic_views(1, H, W, seed=0, device=dev)
-            from dust3r_amd._lib import lib
-            lib.d3r_model_set_option(model._engine, 1, 1)
-            model(v1, v2)
-            torch.cuda.synchronize()
-            prof, rows = read_profile(model), read_launch_table(model)
-            lib.d3r_model_set_option(model._engine, 1, 0)
-            print(f'-- one pair, D3R_GEMM_T64={t64}: linear {prof["linear"]}, conv {prof["conv"]}, attention {prof["attention"]}, other {prof["other"]}')
-            for r in rows[:28]:
-                print('   ', r)
-        return
-    for graphs in (0, 4):              # eager launches vs the hipGraph replay of small forwards (D3R_MODEL_OPT_GRAPH_MAX_PAIRS)
-        model.set_graph_max_pairs(graphs)
-        for B in ((1, 2, 4, 8, 32) if graphs == 0 else (1, 2, 4)):
-            dt = timed_forward(model, B, dev)
-            print(f"forward B={B:2d} {'graph replay' if graphs else 'eager       '}: {dt * 1e3:8.2f} ms/call  {B / dt:7.1f} pairs/s", flush=True)
-    if 'forward-only' in sys.argv:
-        return
-    del model
-    from dust3r_amd.cloud_opt import global_aligner
-    from dust3r_amd.cloud_opt.base_opt import global_alignment_loop
-    for (n, h, w) in ((2, 224, 224), (4, 224, 224), (4, 384, 512), (8, 384, 512), (20, 384, 512)):
-        out, init, gt = synthetic_scene(n, h, w, seed=0, symmetrize=True)
-        scene = global_aligner(out, dev, verbose=False)
-        scene.load_state_dict(init)
-        global_alignment_loop(scene, lr=0.01, niter=50, schedule='cosine', lr_min=1e-6)
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        global_alignment_loop(scene, lr=0.01, niter=300, schedule='cosine', lr_min=1e-6)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t
-        print(f'aligner n={n:2d} E={scene.n_edges:3d} {h}x{w}: {300 / dt:8.0f} iters/s  ({dt / 300 * 1e6:6.1f} us/iter)', flush=True)
+    spec = next(a for a in sys.argv[1:] if '=' in a and not a.startswith('--'))
+    var, vals = spec.split('=')
+    vals = vals.split(',')
+    reps = int(next((a.split('=')[1] for a in sys.argv if a.startswith('--reps=')), 3))
+    sizes = [int(x) for x in next((a.split('=')[1] for a in sys.argv if a.startswith('--pairs=')), '1,2,4,8').split(',')]
+    dev = torch.device('cuda:0')
+    from dust3r_amd.synthetic import synthetic_views
+    engines = {}
+    for v in vals:
+        os.environ[var] = v
+        engines[v] = bench.build_model('fp16x3', dev)
+    os.environ.pop(var, None)
+    v1, v2 = synthetic_views(max(sizes), bench.H, bench.W, seed=0, device=dev)
+    sub = lambda d, n: {k: x[:n] for k, x in d.items()}  # noqa: E731
+    acc = {(v, n): [] for v in vals for n in sizes}
+    for r in range(reps):
+        for n in sizes:
+            a, b = sub(v1, n), sub(v2, n)
+            calls = max(4, 24 // n)
+            for v in vals:
+                m = engines[v]
+                for _ in range(3):
+                    m(a, b)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(calls):
+                    m(a, b)
+                torch.cuda.synchronize()
+                acc[(v, n)].append((time.perf_counter() - t) / calls * 1e3)
+    print(f'== {var}: arms {vals}, {reps} alternating repetitions, ms per call (min / mean)')
+    for n in sizes:
+        print(f'   {n:3d} pairs: ' + ' | '.join(f'{var}={v}: {min(acc[(v, n)]):7.3f} / {sum(acc[(v, n)]) / reps:7.3f}' for v in vals))
+    for n in sizes:
+        a, b = sub(v1, n), sub(v2, n)
+        outs = []
+        for v in vals:
+            o1, o2 = engines[v](a, b)
+            outs.append((o1['pts3d'].clone(), o1['conf'].clone(), o2['pts3d_in_other_view'].clone(), o2['conf'].clone()))
+        same = all(all(torch.equal(x, y) for x, y in zip(outs[0], o)) for o in outs[1:])
+        print(f'   {n:3d} pairs: outputs of all arms ' + ('bit-identical' if same else 'DIFFER'))
 
 
 if __name__ == '__main__':
