@@ -145,6 +145,28 @@ def similarity_from_moments(m):
     return out
 
 
+def similarities_from_moments(M):
+    """`similarity_from_moments` for a stack (b, 17) -> (b, 4, 4) in one batched SVD (an initialisation at 100 views / 600 edges forms ~650 of them)."""
+    M = np.asarray(M, np.float64).reshape(-1, 17)
+    b = len(M)
+    if b == 0:
+        return np.zeros((0, 4, 4))
+    W = M[:, 0:1]
+    mx, my = M[:, 1:4] / W, M[:, 4:7] / W
+    cov = np.swapaxes(M[:, 7:16].reshape(b, 3, 3) / W[:, :, None], 1, 2) - my[:, :, None] * mx[:, None, :]
+    var = M[:, 16] / W[:, 0] - (mx * mx).sum(axis=1)
+    U, S, Vt = np.linalg.svd(cov)
+    d = np.ones((b, 3))
+    sg = np.sign(np.linalg.det(U @ Vt))
+    d[:, 2] = np.where(sg == 0, 1.0, sg)
+    R = (U * d[:, None, :]) @ Vt
+    s = (S * d).sum(axis=1) / var
+    out = np.tile(np.eye(4), (b, 1, 1))
+    out[:, :3, :3] = s[:, None, None] * R
+    out[:, :3, 3] = my - s[:, None] * np.einsum('bij,bj->bi', R, mx)
+    return out
+
+
 def split_similarity(G):
     """4x4 [sR | t] -> (s, R, t)."""
     A = G[:3, :3]
@@ -176,6 +198,29 @@ def pose_params(R, T, scale=None):
     p = np.concatenate((rotmat_to_quat_xyzw(R), np.sign(T) * np.log1p(np.abs(T))))
     with np.errstate(divide='ignore', invalid='ignore'):
         return p if scale is None else np.concatenate((p, [float(np.log(np.float64(scale)))]))
+
+
+def pose_params_batch(M, with_scale):
+    """`pose_params(*split_similarity(M)[1:], scale)` for a stack of 4x4 [sR | t] (b, 4, 4) -> (b, 8) (with_scale: quaternion XYZW, signed-log of t / s, log s)
+    or (b, 7) (rigid: s is not divided out and not stored)."""
+    M = np.asarray(M, np.float64)
+    A = M[:, :3, :3]
+    sc = np.cbrt(np.linalg.det(A))
+    m = A / sc[:, None, None] if with_scale else A
+    T = M[:, :3, 3] / sc[:, None] if with_scale else M[:, :3, 3]
+    d = np.stack((1 + m[:, 0, 0] - m[:, 1, 1] - m[:, 2, 2], 1 - m[:, 0, 0] + m[:, 1, 1] - m[:, 2, 2], 1 - m[:, 0, 0] - m[:, 1, 1] + m[:, 2, 2],
+                  1 + m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2]), axis=1)
+    c = d.argmax(axis=1)
+    a, bq, cq = m[:, 1, 0] + m[:, 0, 1], m[:, 0, 2] + m[:, 2, 0], m[:, 2, 1] + m[:, 1, 2]
+    x, y, z = m[:, 2, 1] - m[:, 1, 2], m[:, 0, 2] - m[:, 2, 0], m[:, 1, 0] - m[:, 0, 1]
+    cands = np.stack((np.stack((d[:, 0], a, bq, x), 1), np.stack((a, d[:, 1], cq, y), 1), np.stack((bq, cq, d[:, 2], z), 1), np.stack((x, y, z, d[:, 3]), 1)), axis=1)
+    q = cands[np.arange(len(M)), c]
+    q = q / np.linalg.norm(q, axis=1, keepdims=True)
+    out = np.concatenate((q, np.sign(T) * np.log1p(np.abs(T))), axis=1)
+    if with_scale:
+        with np.errstate(divide='ignore', invalid='ignore'):
+            out = np.concatenate((out, np.log(sc)[:, None]), axis=1)
+    return out
 
 
 def align_pose_sets(src, dst):
@@ -295,28 +340,35 @@ def solve_pnp_batch(dev, jobs, iterations=10, reproj_err=5.0, seed=0, refine_ite
     rng = np.random.RandomState(seed)
 
     # ---- hypotheses from minimal samples (the samples are a few hundred points: gathered to the host)
+    # Every job's candidate pixels in ONE device gather and one copy back, every hypothesis' DLT in one batched call (pnp.dlt_pose_batch): the
+    # per-job loop of rounds 2-4 paid two synchronising copies per job and 62 us of numpy call overhead per hypothesis -- 0.08 of the 0.13 s of
+    # init='mst' at 100 views.
     hyp = np.zeros((n, maxh, 12), np.float32)
     valid = np.zeros((n, maxh), bool)
-    for a, j in enumerate(jobs):
-        H, W = j['H'], j['W']
-        cand = rng.randint(0, H * W, size=nh * 48)                    # drawn for every job: the stream does not depend on failures
-        if not (np.isfinite(j['f']) and j['f'] > 0):
-            continue                                                  # degenerate intrinsics: no hypothesis, the job fails
-        cand_t = torch.from_numpy(cand).to(dev)
-        pts = j['points'].reshape(-1, 3)[cand_t].double().cpu().numpy()
-        ok = (j['confs'].reshape(-1)[cand_t] > j['thr']).cpu().numpy()
-        G = np.asarray(j['G'], np.float64).reshape(3, 4)
-        world = pts @ G[:, :3].T + G[:, 3]
-        xn = np.stack((((cand % W) - j['pp'][0]) / j['f'], ((cand // W) - j['pp'][1]) / j['f']), axis=1)
-        for h in range(nh):
-            sel = np.nonzero(ok[h * 48:(h + 1) * 48])[0][:NSAMPLE] + h * 48
-            if len(sel) < 6:
-                continue
-            sol = pnp_host._dlt_pose(world[sel], xn[sel])
-            if sol is None:
-                continue
-            hyp[a, h, :] = np.concatenate((sol[0], sol[1][:, None]), axis=1).reshape(12)
-            valid[a, h] = True
+    cand = np.stack([rng.randint(0, j['H'] * j['W'], size=nh * 48) for j in jobs])       # drawn for every job: the stream does not depend on failures
+    live = [a for a, j in enumerate(jobs) if np.isfinite(j['f']) and j['f'] > 0]     # degenerate intrinsics: no hypothesis, the job fails
+    if live:
+        cand_d = torch.from_numpy(cand).to(dev)
+        pts_d = torch.stack([jobs[a]['points'].reshape(-1, 3)[cand_d[a]] for a in live]).double()
+        ok_d = torch.stack([jobs[a]['confs'].reshape(-1)[cand_d[a]] > jobs[a]['thr'] for a in live])
+        pts, ok = pts_d.cpu().numpy(), ok_d.cpu().numpy()
+        G = np.stack([np.asarray(jobs[a]['G'], np.float64).reshape(3, 4) for a in live])
+        world = np.einsum('apk,aik->api', pts, G[:, :, :3]) + G[:, None, :, 3]
+        Wl = np.array([jobs[a]['W'] for a in live])[:, None]
+        fl = np.array([jobs[a]['f'] for a in live], np.float64)[:, None]
+        ppl = np.array([jobs[a]['pp'] for a in live], np.float64)
+        cl = cand[live]
+        xn = np.stack((((cl % Wl) - ppl[:, 0:1]) / fl, ((cl // Wl) - ppl[:, 1:2]) / fl), axis=2)
+        # hypothesis h of a job: the first NSAMPLE confident candidates of its window of 48
+        okw = ok.reshape(len(live) * nh, 48)
+        sel = okw & (np.cumsum(okw, axis=1) <= NSAMPLE)
+        first = np.argsort(~sel, axis=1, kind='stable')[:, :NSAMPLE]           # the selected candidates first, in their order: NSAMPLE columns instead of 48
+        R, T, good = pnp_host.dlt_pose_batch(np.take_along_axis(world.reshape(len(live) * nh, 48, 3), first[:, :, None], axis=1),
+                                             np.take_along_axis(xn.reshape(len(live) * nh, 48, 2), first[:, :, None], axis=1), np.take_along_axis(sel, first, axis=1))
+        sol = np.concatenate((R, T[:, :, None]), axis=2).reshape(len(live), nh, 12)
+        good = good.reshape(len(live), nh)
+        hyp[live, :nh] = np.where(good[:, :, None], sol, 0.0)
+        valid[live, :nh] = good
     hyp_d = torch.from_numpy(hyp).to(dev)
     counts = torch.zeros((n, maxh), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
@@ -342,25 +394,28 @@ def solve_pnp_batch(dev, jobs, iterations=10, reproj_err=5.0, seed=0, refine_ite
     ju = np.triu_indices(6)
     cand = poses.copy()
     hyp_count = best_count.astype(np.float64)
+    eye6 = 1e-9 * np.eye(6)
     for _ in range(refine_iters):
         g = gn_sums(cand)
-        step = 0.0
-        for a in range(n):
-            if g[a, 28] < 6:
-                continue
-            Hm = np.zeros((6, 6))
-            Hm[ju] = g[a, 0:21]
-            Hm = Hm + Hm.T - np.diag(np.diag(Hm)) + 1e-9 * np.eye(6)
-            if not np.isfinite(g[a]).all():
-                continue
-            try:
-                d = np.linalg.solve(Hm, -g[a, 21:27])
-            except np.linalg.LinAlgError:
-                continue
-            cand[a, :, :3] = pnp_host.rodrigues_to_rotmat(d[:3]) @ cand[a, :, :3]      # R <- exp([w]x) R about the camera origin,
-            cand[a, :, 3] += d[3:]                                                      # t <- t + dt (the kernel's Jacobian convention)
-            step = max(step, float(np.linalg.norm(d)))
-        if step < 1e-9:
+        use = (g[:, 28] >= 6) & np.isfinite(g).all(axis=1)
+        Hm = np.zeros((n, 6, 6))
+        Hm[:, ju[0], ju[1]] = g[:, 0:21]
+        Hm = Hm + np.swapaxes(Hm, 1, 2) - Hm * np.eye(6) + eye6
+        Hm[~use] = np.eye(6)
+        try:
+            d = np.linalg.solve(Hm, -g[:, 21:27, None])[:, :, 0]
+        except np.linalg.LinAlgError:                                   # a singular system somewhere in the stack: job by job, skipping those
+            d = np.zeros((n, 6))
+            for a in np.nonzero(use)[0]:
+                try:
+                    d[a] = np.linalg.solve(Hm[a], -g[a, 21:27])
+                except np.linalg.LinAlgError:
+                    use[a] = False
+        d[~use] = 0.0
+        for a in np.nonzero(use)[0]:
+            cand[a, :, :3] = pnp_host.rodrigues_to_rotmat(d[a, :3]) @ cand[a, :, :3]   # R <- exp([w]x) R about the camera origin,
+        cand[:, :, 3] += d[:, 3:]                                                       # t <- t + dt (the kernel's Jacobian convention)
+        if float(np.linalg.norm(d, axis=1).max(initial=0.0)) < 1e-9:
             break
     g = gn_sums(cand)
     best_count = best_count.astype(np.float64)
@@ -397,7 +452,7 @@ def bootstrap_from_spanning_tree(scene, niter_PnP=10, maps=None):
         else:
             jobs.append(((0, e), plan.anchor[i], (0, e)))
             pw_job.append(len(jobs) - 1)
-    S = [similarity_from_moments(m) for m in maps.similarity_moments(jobs)]
+    S = list(similarities_from_moments(maps.similarity_moments(jobs)))
 
     G = [None] * n
     for k in plan.order:
@@ -419,10 +474,11 @@ def bootstrap_from_spanning_tree(scene, niter_PnP=10, maps=None):
         need = [k for k in range(n) if poses[k] is None]
         if need:
             pjobs, owner = [], []
-            for k in need:
+            confident = torch.stack([(scene.im_conf[k] > scene.min_conf_thr).sum() for k in need]).cpu().tolist()      # one copy back for all images
+            for k, n_conf in zip(need, confident):
                 side, e = plan.anchor[k]
                 H, W = scene.imshapes[k]
-                if int((scene.im_conf[k] > scene.min_conf_thr).sum()) < 4:
+                if n_conf < 4:
                     continue
                 conf_t = scene.im_conf[k].contiguous()
                 sweep = [focals[k]] if focals[k] is not None else list(np.geomspace(max(W, H) / 2, max(W, H) * 3, 21))
@@ -461,11 +517,7 @@ def _commit(scene, maps, anchor, G, S, pw_job, focals, poses):
             poses[:, :3, :3] /= s
             G = [trf @ g for g in G]
     # pairwise poses: cloud of image i as seen from edge e's frame
-    pw = np.zeros((len(edges), 8), np.float32)
-    for e, (i, j) in enumerate(edges):
-        M = G[i] if pw_job[e] is None else G[i] @ S[pw_job[e]]
-        s, R, T = split_similarity(M)
-        pw[e] = pose_params(R, T, scale=s)
+    pw = pose_params_batch(np.stack([G[i] if pw_job[e] is None else G[i] @ S[pw_job[e]] for e, (i, j) in enumerate(edges)]), True).astype(np.float32)
     if scene.pw_poses.requires_grad:
         scene.pw_poses.data.copy_(torch.from_numpy(pw).to(scene.pw_poses.device))
     s_factor = float(scene.get_pw_norm_scale_factor())
@@ -477,7 +529,7 @@ def _commit(scene, maps, anchor, G, S, pw_job, focals, poses):
         rows = [(np.linalg.inv(poses[k]) @ G[k])[2] for k in range(n)]
         maps.anchor_depth([anchor[k] for k in range(n)], rows, scene.im_depthmaps.data)
     if scene.im_poses.requires_grad:
-        scene.im_poses.data.copy_(torch.from_numpy(np.stack([pose_params(p[:3, :3], p[:3, 3]) for p in poses]).astype(np.float32)).to(scene.im_poses.device))
+        scene.im_poses.data.copy_(torch.from_numpy(pose_params_batch(poses, False).astype(np.float32)).to(scene.im_poses.device))
     if scene.im_focals.requires_grad:
         vals = scene.im_focals.data.clone()
         for k, f in enumerate(focals):

@@ -80,6 +80,46 @@ def _dlt_pose(X, xn):
     return R, T
 
 
+def dlt_pose_batch(X, xn, sel):
+    """`_dlt_pose` for a stack of point sets in one pass of batched LAPACK calls: X (b, p, 3) world points, xn (b, p, 2) normalised image
+    coordinates, sel (b, p) bool = the points of set b that take part (unselected rows enter the normal matrix with weight zero, which is the
+    system without them). Returns R (b, 3, 3), T (b, 3), valid (b,): the same null vector / SO(3) projection / cheirality rule per set.
+    The 100-view spanning-tree initialisation forms 960 six-to-twelve-point hypotheses: one call instead of 960 (0.06 s of numpy call overhead)."""
+    X = np.asarray(X, np.float64)
+    xn = np.asarray(xn, np.float64)
+    b, p = X.shape[:2]
+    w = np.asarray(sel, np.float64)
+    Xh = np.concatenate((X, np.ones((b, p, 1))), axis=2) * w[:, :, None]
+    a1 = np.zeros((b, p, 12))
+    a2 = np.zeros((b, p, 12))
+    a1[:, :, 0:4] = -Xh
+    a1[:, :, 8:12] = xn[:, :, 0:1] * Xh
+    a2[:, :, 4:8] = -Xh
+    a2[:, :, 8:12] = xn[:, :, 1:2] * Xh
+    AtA = np.einsum('bpi,bpj->bij', a1, a1) + np.einsum('bpi,bpj->bij', a2, a2)
+    valid = np.isfinite(AtA).all(axis=(1, 2)) & (w.sum(axis=1) >= 6)
+    AtA[~valid] = np.eye(12)
+    _, V = np.linalg.eigh(AtA)
+    P = V[:, :, 0].reshape(b, 3, 4)
+    U, S, Vt = np.linalg.svd(P[:, :, :3])
+    sm = S.mean(axis=1)
+    valid &= sm >= 1e-12
+    sm = np.where(sm < 1e-12, 1.0, sm)
+    R = U @ Vt
+    sgn = np.where(np.linalg.det(R) < 0, -1.0, 1.0)
+    R = R * sgn[:, None, None]
+    T = sgn[:, None] * P[:, :, 3] / sm[:, None]
+    z = np.einsum('bpk,bk->bp', X, R[:, 2, :]) + T[:, 2:3]
+    z = np.where(np.asarray(sel, bool), z, np.nan)
+    with np.errstate(all='ignore'):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)
+            med = np.nanmedian(z, axis=1)
+    valid &= np.nan_to_num(med, nan=-1.0) >= 0          # cheirality: most points in front of the camera
+    return R, T, valid
+
+
 def _project(X, R, T, K):
     Xc = X @ R.T + T
     z = np.where(np.abs(Xc[:, 2]) < 1e-12, 1e-12, Xc[:, 2])

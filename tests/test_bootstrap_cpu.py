@@ -265,3 +265,73 @@ def test_pnp_batch_host_logic(monkeypatch):
         for (ok, M, cnt), (R, T) in zip(run_pnp_batch_on_cpu(monkeypatch, jobs, iterations=10), truth):
             assert ok and cnt > 0.5 * H * W
             assert np.abs(M[:3, :3] - R).max() < tol and np.abs(M[:3, 3] - T).max() < tol, (noise, np.abs(M[:3, :3] - R).max())
+
+
+def test_dlt_pose_batch_equals_the_per_set_solver():
+    """pnp.dlt_pose_batch (one batched eigh / svd for all hypotheses of an initialisation) against pnp._dlt_pose per set: sets of 6..12 selected
+    points out of 48 candidates, a set with too few points, a set behind the camera, a set with a non-finite point."""
+    from dust3r_amd.cloud_opt import pnp
+    from dust3r_amd.synthetic import _axis_angle_R
+    rng = np.random.RandomState(3)
+    b, p = 40, 48
+    X, xn, sel = np.zeros((b, p, 3)), np.zeros((b, p, 2)), np.zeros((b, p), bool)
+    for k in range(b):
+        R, T = _axis_angle_R(rng.randn(3), 0.5 * rng.randn()), 0.3 * rng.randn(3)
+        cam = np.stack((rng.randn(p), rng.randn(p), 2 + rng.rand(p)), axis=1) * (-1 if k == 5 else 1)     # set 5: every point behind the camera
+        X[k] = (cam - T) @ R + 0.003 * rng.randn(p, 3)
+        xn[k] = cam[:, :2] / cam[:, 2:3]
+        ok = rng.rand(p) < 0.6
+        sel[k] = ok & (np.cumsum(ok) <= (4 if k == 7 else 6 + k % 7))                                       # set 7: four points only
+    X[9, np.nonzero(sel[9])[0][0]] = np.nan
+    R, T, good = pnp.dlt_pose_batch(X, xn, sel)
+    for k in range(b):
+        idx = np.nonzero(sel[k])[0]
+        one = pnp._dlt_pose(X[k, idx], xn[k, idx]) if len(idx) >= 6 else None
+        assert (one is not None) == bool(good[k]), k
+        if one is not None:
+            assert np.abs(one[0] - R[k]).max() < 1e-8 and np.abs(one[1] - T[k]).max() < 1e-8, k
+    assert not good[5] and not good[7] and not good[9] and good.sum() >= b - 4
+
+
+def test_batched_host_algebra_equals_the_per_item_functions():
+    """bootstrap.similarities_from_moments / pose_params_batch (one batched LAPACK call per initialisation) against similarity_from_moments /
+    split_similarity + pose_params per item: random weighted point-set moments (incl. a reflection case), similarities with every quaternion branch."""
+    from dust3r_amd.cloud_opt.bootstrap import (pose_params, pose_params_batch, similarities_from_moments, similarity_from_moments, split_similarity)
+    from dust3r_amd.synthetic import _axis_angle_R
+    rng = np.random.RandomState(5)
+    M = []
+    for k in range(30):
+        x = rng.randn(50, 3)
+        R, t, sc = _axis_angle_R(rng.randn(3), 3 * rng.rand()), rng.randn(3), 0.5 + rng.rand()
+        y = sc * x @ R.T + t + 0.01 * rng.randn(50, 3)
+        if k == 3:
+            y[:, 0] = -y[:, 0]                      # a mirrored target: the d[2] = -1 branch
+        w = rng.rand(50)
+        m = np.zeros(17)
+        m[0], m[1:4], m[4:7] = w.sum(), (w[:, None] * x).sum(0), (w[:, None] * y).sum(0)
+        m[7:16] = (w[:, None, None] * x[:, :, None] * y[:, None, :]).sum(0).ravel()
+        m[16] = (w * (x * x).sum(1)).sum()
+        M.append(m)
+    S = similarities_from_moments(np.stack(M))
+    for k, m in enumerate(M):
+        assert np.abs(S[k] - similarity_from_moments(m)).max() < 1e-12, k
+    assert similarities_from_moments(np.zeros((0, 17))).shape == (0, 4, 4)
+    # similarities whose rotations cover the four quaternion branches (angles near 0 and near pi about each axis)
+    G = []
+    for axis in (np.eye(3)[0], np.eye(3)[1], np.eye(3)[2], rng.randn(3)):
+        for ang in (0.1, 3.1, 1.7):
+            g = np.eye(4)
+            g[:3, :3] = (0.3 + rng.rand() * 3) * _axis_angle_R(axis, ang)
+            g[:3, 3] = 5 * rng.randn(3)
+            G.append(g)
+    G = np.stack(G)
+    pb = pose_params_batch(G, True)
+    for k, g in enumerate(G):
+        sc, R, T = split_similarity(g)
+        assert np.abs(pb[k] - pose_params(R, T, scale=sc)).max() < 1e-12, k
+    rigid = G.copy()
+    for g in rigid:
+        g[:3, :3] /= split_similarity(g)[0]
+    pr = pose_params_batch(rigid, False)
+    for k, g in enumerate(rigid):
+        assert np.abs(pr[k] - pose_params(g[:3, :3], g[:3, 3])).max() < 1e-12, k

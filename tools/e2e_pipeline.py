@@ -65,9 +65,16 @@ def align_stage(n, graph, H, W, dev):
     if host_out:
         out = {k: ({kk: (vv.cpu() if isinstance(vv, torch.Tensor) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in out.items()}
     print(f'  (synthetic scene built in {time.time() - t:.1f} s: {len(out["view1"]["idx"])} edges; predictions {"on the host" if host_out else "resident in HBM"})')
+    reps = int(next((a.split('=')[1] for a in sys.argv if a.startswith('--repeat=')), 1))
+    for rep in range(reps):
+        _align_once(out, gt, dev, last=rep == reps - 1)
+
+
+def _align_once(out, gt, dev, last):
+    from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
     torch.cuda.synchronize()
     t0 = time.time()
-    if '--profile-build' in sys.argv:
+    if '--profile-build' in sys.argv and last:
         import cProfile
         import pstats
         pr = cProfile.Profile()
@@ -75,13 +82,21 @@ def align_stage(n, graph, H, W, dev):
     scene = global_aligner(out, device=dev, mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
     torch.cuda.synchronize()
     t1 = time.time()
-    if '--profile-build' in sys.argv:
+    if '--profile-build' in sys.argv and last:
         pr.disable()
-        pstats.Stats(pr).sort_stats('cumulative').print_stats(14)
+        pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
     from dust3r_amd.cloud_opt import init_im_poses as init_fun
+    if '--profile-init' in sys.argv and last:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
     init_fun.init_minimum_spanning_tree(scene, niter_PnP=10)
     torch.cuda.synchronize()
     t2 = time.time()
+    if '--profile-init' in sys.argv and last:
+        pr.disable()
+        pstats.Stats(pr).sort_stats('cumulative').print_stats(30)
     loss = scene.compute_global_alignment(init=None, niter=300, schedule='cosine', lr=0.01)
     torch.cuda.synchronize()
     t3 = time.time()
