@@ -8,7 +8,7 @@ to the HIP engine; pairs can additionally be sharded over ranks with `dust3r_amd
 import torch
 import tqdm
 
-from .utils.device import collate_with_cat, to_cpu
+from .utils.device import collate_with_cat, host_tensor, to_cpu, upload_stack
 
 
 def _interleave_imgs(img1, img2):
@@ -91,6 +91,9 @@ def _encode_once_ok(pairs, model):
 
 
 def _alloc_outputs(P, H, W, out_device):
+    """The four result tensors. On the host: zero-filled and touched, on huge pages when they are large (utils/device.py:host_tensor)."""
+    if torch.device(out_device).type == 'cpu':
+        return (dict(pts3d=host_tensor((P, H, W, 3)), conf=host_tensor((P, H, W))), dict(pts3d_in_other_view=host_tensor((P, H, W, 3)), conf=host_tensor((P, H, W))))
     kw = dict(dtype=torch.float32, device=out_device)
     return (dict(pts3d=torch.empty((P, H, W, 3), **kw), conf=torch.empty((P, H, W), **kw)),
             dict(pts3d_in_other_view=torch.empty((P, H, W, 3), **kw), conf=torch.empty((P, H, W), **kw)))
@@ -177,7 +180,7 @@ def _collate_views(pairs, shared=None, device_stack=None, ready=None):
     side = torch.cuda.Stream(device=dev) if ready is not None else None
 
     def gather(index, chunk=128):      # in chunks: 2 x len(pairs) whole images never sit in HBM at once (2.8 GB for 600 pairs at 512x384)
-        out = torch.zeros((len(index),) + tuple(device_stack.shape[1:]), dtype=device_stack.dtype)     # zeros: the pages are touched before the copies need them
+        out = host_tensor((len(index),) + tuple(device_stack.shape[1:]), dtype=device_stack.dtype)     # zero-filled: the pages are touched before the copies need them
         if side is None:
             idx = torch.tensor(index, device=dev)
             for i in range(0, len(index), chunk):
@@ -232,14 +235,12 @@ def inference_encode_once(pairs, model, device, batch_size=8, verbose=True, outp
                 order.append(k)
     pos = {k: i for i, k in enumerate(order)}
     H, W = pairs[0][0]['img'].shape[-2:]
-    host_out = torch.device(output_device).type == 'cpu'
-    outputs = _Background(lambda: tuple({k: torch.zeros_like(t) for k, t in d.items()} for d in _alloc_outputs(len(pairs), H, W, output_device))
-                          if host_out else _alloc_outputs(len(pairs), H, W, output_device))
+    outputs = _Background(lambda: _alloc_outputs(len(pairs), H, W, output_device))
     feats, dev_imgs = [], []
     batch_size = _engine_step(model, batch_size, engine_batch)
     enc_bs = max(2, 2 * batch_size)
     for i in tqdm.trange(0, len(order), enc_bs, disable=not verbose, desc='encode'):
-        dev_imgs.append(torch.cat([imgs[k] for k in order[i:i + enc_bs]], dim=0).to(device, non_blocking=True))
+        dev_imgs.append(upload_stack([imgs[k] for k in order[i:i + enc_bs]], device))
         feats.append(model.encode_images(dev_imgs[-1]))
     feats = torch.cat(feats, dim=0)
     i1h, i2h = [pos[int(a['idx'])] for a, _ in pairs], [pos[int(b['idx'])] for _, b in pairs]
@@ -303,7 +304,7 @@ def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None
     sink = _PredictionSink(len(pairs), H, W, output_device, device)
     views = None
     if shared is not None:       # the distinct images go up once; every batch is gathered on the device
-        stack = torch.cat(shared[0], dim=0).to(device, non_blocking=True)
+        stack = upload_stack(shared[0], device)
         i1, i2 = torch.tensor(shared[1], device=stack.device), torch.tensor(shared[2], device=stack.device)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(stack.device))

@@ -20,7 +20,7 @@ in the caller's order by the same index_select that used to drop the padding row
 import torch
 import torch.distributed as dist
 
-from .utils.device import collate_with_cat
+from .utils.device import collate_with_cat, upload_stack
 
 
 def shard_bounds(n_items, rank, world_size):
@@ -148,6 +148,25 @@ def unpack_predictions(packed):
     return pred1, pred2
 
 
+def _unpack_to_host(gathered, keep, chunk=64):
+    """The gathered packed payload (rows, H, W, 8) -> the caller's pair order, as the four result tensors of `inference()` ON THE HOST. From a GPU: the rows
+    are selected and the four tensors sliced on the device, chunk by chunk, and each piece is copied into host result memory on huge pages
+    (utils/device.py:host_tensor) -- `.cpu()` of the whole payload followed by four strided host copies moved the 3.8 GB of 600 pairs three times."""
+    if not gathered.is_cuda:
+        return unpack_predictions(gathered.index_select(0, keep.to(gathered.device)))
+    from .inference import _alloc_outputs
+    P, (H, W) = len(keep), gathered.shape[1:3]
+    pred1, pred2 = _alloc_outputs(P, H, W, 'cpu')
+    keep_d = keep.to(gathered.device)
+    for i in range(0, P, chunk):
+        rows = gathered.index_select(0, keep_d[i:i + chunk])
+        pred1['pts3d'][i:i + chunk].copy_(rows[..., 0:3].contiguous())
+        pred1['conf'][i:i + chunk].copy_(rows[..., 3].contiguous())
+        pred2['pts3d_in_other_view'][i:i + chunk].copy_(rows[..., 4:7].contiguous())
+        pred2['conf'][i:i + chunk].copy_(rows[..., 7].contiguous())
+    return pred1, pred2
+
+
 def all_gather_packed(local, group=None, async_op=False, out=None):
     """All-gather equal-sized per-rank payloads (per, ...) -> (world*per, ...). The one collective of the path."""
     world = dist.get_world_size(group)
@@ -197,7 +216,7 @@ def _local_same_size(shard, per, model, device, batch_size, gather_device, encod
                     order.append(k)
         pos = {k: i for i, k in enumerate(order)}
         enc_bs = max(2, 2 * batch_size)
-        feats = torch.cat([model.encode_images(torch.cat([imgs[k] for k in order[i:i + enc_bs]], dim=0).to(device)) for i in range(0, len(order), enc_bs)], dim=0)
+        feats = torch.cat([model.encode_images(upload_stack([imgs[k] for k in order[i:i + enc_bs]], device)) for i in range(0, len(order), enc_bs)], dim=0)
         i1 = torch.tensor([pos[int(a['idx'])] for a, _ in shard], device=feats.device)
         i2 = torch.tensor([pos[int(b['idx'])] for _, b in shard], device=feats.device)
         for i in range(0, len(shard), batch_size):
@@ -262,11 +281,20 @@ def inference_sharded(pairs, model, device, batch_size=8, verbose=False, group=N
     keep = plan.source                                             # caller's order <- gathered rows (also drops the padding rows of short shards)
     if same:
         H, W = pairs[0][0]['img'].shape[-2:]
+        from .inference import _Background, _collate_views, _shared_images
+        # the collated view images of the result (rebuilt deterministically on every rank) leave for the host on a thread of their own
+        # while the shard runs: gathered on the GPU from the distinct images when the pair list shares them, like inference()
+        views = None
+        shared = _shared_images(pairs) if torch.device(device).type == 'cuda' else None
+        if shared is not None:
+            stack = upload_stack(shared[0], device)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(stack.device))
+            views = _Background(_collate_views, pairs, shared, stack, ready)
         local = _local_same_size([pairs[k] for k in mine], per, model, device, batch_size, gather_device, enc1, H, W)
         gathered = all_gather_packed(local, group)
-        pred1, pred2 = unpack_predictions(gathered.index_select(0, keep.to(gathered.device)).cpu())
-        # view metadata is rebuilt deterministically on every rank (host side), as SURVEY.md 8(e) prescribes
-        view1, view2 = collate_with_cat([(p[0], p[1]) for p in pairs])
+        pred1, pred2 = _unpack_to_host(gathered, keep)
+        view1, view2 = views.join() if views is not None else collate_with_cat([(p[0], p[1]) for p in pairs])
         view1 = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in view1.items()}
         view2 = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in view2.items()}
         return dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)

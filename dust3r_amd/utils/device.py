@@ -1,5 +1,7 @@
 """Container plumbing of the inference path: moving nested view / prediction structures between devices and collating per-batch
 results into the reference's return format (`dust3r/utils/device.py:11-76`: `to_cpu`, `to_numpy`, `collate_with_cat`)."""
+import mmap
+
 import numpy as np
 import torch
 
@@ -63,4 +65,65 @@ def collate_with_cat(items, lists=False):
     out = seq_type()
     for it in items:
         out = out + it
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- host memory of the results, image upload
+_HUGE = 1 << 21
+
+
+def host_tensor(shape, dtype=torch.float32):
+    """Zero-filled CPU tensor for results that a device -> host copy is about to fill (the 3.8 GB of predictions and the 2.8 GB of collated view
+    images `inference()` returns for 600 pairs at 512x384). Large tensors come from an anonymous mapping marked MADV_HUGEPAGE -- this image's
+    kernel has transparent huge pages in `madvise` mode -- and are touched here: measured on the MI355X box (tools/hostmem_probe.py,
+    profiles/r05_y) allocate + first touch of 1.9 GB takes 7 ms instead of 130-200 ms (torch.zeros: 4 KiB page faults), and the first
+    device -> host pass into it runs at 35-39 GB/s instead of 16 (the runtime pins the destination of a large pageable copy on the fly: 512x
+    fewer pages to pin). Falls back to torch.zeros where the platform has no madvise / huge pages, and for small tensors."""
+    shape = tuple(int(x) for x in shape)
+    n = 1
+    for x in shape:
+        n *= x
+    item = torch.empty((), dtype=dtype).element_size()
+    nbytes = n * item
+    if nbytes < 8 * _HUGE or not hasattr(mmap, 'MADV_HUGEPAGE'):
+        return torch.zeros(shape, dtype=dtype)
+    try:
+        mm = mmap.mmap(-1, (nbytes + _HUGE - 1) // _HUGE * _HUGE, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+        mm.madvise(mmap.MADV_HUGEPAGE)
+        t = torch.frombuffer(mm, dtype=dtype, count=n).view(shape)       # the tensor keeps the mapping alive (buffer protocol)
+    except (OSError, ValueError, AttributeError):
+        return torch.zeros(shape, dtype=dtype)
+    return t.zero_()
+
+
+def upload_stack(tensors, device, non_blocking=True):
+    """A list of equally shaped CPU tensors (1, ...) -> one (n, ...) tensor on `device`, ONE COPY PER LIST ENTRY into a device tensor allocated here.
+    `torch.cat(tensors).to(device)` -- a fresh 236 MB pageable region handed to one copy -- runs at 0.5-1 GB/s on the MI355X box (100 images of
+    512x384: 230-470 ms); the runtime moves copies of a few MB through its pinned staging buffers at 25-38 GB/s (the same 100 images one by one:
+    6-9 ms; tools/hostmem_probe.py --upload, profiles/r05_y). Anything that is not that shape of input takes the plain route."""
+    device = torch.device(device)
+    ok = (device.type == 'cuda' and len(tensors) > 0 and all(isinstance(t, torch.Tensor) and t.device.type == 'cpu' and t.dim() >= 1 and t.shape[0] == 1
+                                                              and t.shape == tensors[0].shape and t.dtype == tensors[0].dtype for t in tensors))
+    if not ok:
+        return torch.cat(list(tensors), dim=0).to(device, non_blocking=non_blocking)
+    out = torch.empty((len(tensors),) + tuple(tensors[0].shape[1:]), dtype=tensors[0].dtype, device=device)
+    for i, t in enumerate(tensors):
+        out[i:i + 1].copy_(t, non_blocking=non_blocking)
+    return out
+
+
+def upload_rows(t, device, piece_bytes=4 << 20):
+    """One large CPU tensor -> `device`, copied in pieces of a few MB along dim 0 (see upload_stack: a multi-GB pageable region handed to ONE copy moves at
+    0.5-1 GB/s on the MI355X box, pieces of 2-4 MB at 25-38 GB/s). Small tensors, tensors already on a device and non-CUDA targets take `.to(device)`."""
+    device = torch.device(device)
+    if not isinstance(t, torch.Tensor) or t.device.type != 'cpu' or device.type != 'cuda' or t.dim() == 0 or t.numel() * t.element_size() <= 2 * piece_bytes:
+        return t.to(device) if isinstance(t, torch.Tensor) else t
+    t = t.detach()
+    if not t.is_contiguous():
+        t = t.contiguous()
+    row = max(t[0].numel() * t.element_size(), 1)
+    step = max(int(piece_bytes // row), 1)
+    out = torch.empty(t.shape, dtype=t.dtype, device=device)
+    for i in range(0, t.shape[0], step):
+        out[i:i + step].copy_(t[i:i + step], non_blocking=True)
     return out

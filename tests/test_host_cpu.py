@@ -446,3 +446,27 @@ def test_bench_workload_flop_accounting_matches_the_survey():
     bench.py count executed flops with the same constants."""
     import bench
     assert abs(2 * bench.ENC_GFLOP_PER_IMAGE + bench.DEC_HEAD_GFLOP_PER_PAIR - bench.GFLOP_PER_PAIR) < 0.5
+
+
+def test_host_result_tensors_and_image_upload_helpers():
+    """utils/device.py: host_tensor (the result memory of inference(): zero-filled, on huge pages when large, an ordinary CPU tensor for every
+    consumer) and upload_stack (falls back to cat + to for anything that is not a list of equally shaped one-image CPU tensors going to a GPU)."""
+    import gc
+
+    import numpy as np
+    from dust3r_amd.utils.device import host_tensor, upload_stack
+    big = host_tensor((12, 96, 128, 3))                      # 1.7 MB: plain route
+    huge = host_tensor((24, 384, 512, 3))                    # 56 MB: the mapped route where the platform has it
+    for t in (big, huge):
+        assert t.dtype == torch.float32 and t.device.type == 'cpu' and t.is_contiguous() and float(t.abs().max()) == 0.0
+        t[1, 2, 3] = torch.tensor([1.0, 2.0, 3.0])
+        assert np.asarray(t.numpy()[1, 2, 3]).tolist() == [1.0, 2.0, 3.0]
+    keep = huge[5:7]                                         # a view must keep the mapping alive after the parent name is gone
+    keep.fill_(4.0)
+    del huge
+    gc.collect()
+    assert float(keep.sum()) == 4.0 * keep.numel()
+    assert torch.equal(torch.cat((keep, keep)), keep.repeat(2, 1, 1, 1)) and host_tensor((3, 5), dtype=torch.int64).dtype == torch.int64
+    imgs = [torch.full((1, 3, 4, 4), float(k)) for k in range(5)]
+    assert torch.equal(upload_stack(imgs, 'cpu'), torch.cat(imgs))
+    assert torch.equal(upload_stack([torch.ones(2, 3), torch.zeros(1, 3)], 'cpu'), torch.tensor([[1.0] * 3, [1.0] * 3, [0.0] * 3]))
