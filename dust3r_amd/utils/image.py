@@ -75,21 +75,32 @@ def load_images(folder_or_list, size, square_ok=False, verbose=True, patch_size=
         root, names = '', folder_or_list
     else:
         raise ValueError(f'bad {folder_or_list=} ({type(folder_or_list)})')
-    views = []
-    for name in names:
-        if not name.lower().endswith(IMAGE_EXTENSIONS):
-            continue
+    names = [name for name in names if name.lower().endswith(IMAGE_EXTENSIONS)]
+
+    def decode(name):
+        """One file -> (cropped uint8 pixels, source size). PIL releases the GIL while it decodes and resamples, so the files of a folder are
+        prepared on a thread pool (DUST3R_AMD_LOAD_THREADS, default min(16, cores)): same PIL calls per image, same pixels, same order."""
         pil = exif_transpose(PIL.Image.open(os.path.join(root, name))).convert('RGB')
         W1, H1 = pil.size
         new_size, box = fit_geometry(W1, H1, size, square_ok=square_ok, patch_size=patch_size)
         # the filter is chosen on the source's long edge against the long-edge TARGET of the resize call (not the rounded result)
         target = round(size * max(W1 / H1, H1 / W1)) if size == 224 else size
         pil = pil.resize(new_size, PIL.Image.LANCZOS if max(W1, H1) > target else PIL.Image.BICUBIC).crop(box)
-        W2, H2 = pil.size
+        return np.asarray(pil, dtype=np.uint8), (W1, H1)
+
+    threads = max(1, min(int(os.environ.get('DUST3R_AMD_LOAD_THREADS', 16)), os.cpu_count() or 1, len(names)))
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            decoded = list(pool.map(decode, names))
+    else:
+        decoded = [decode(name) for name in names]
+    views = []
+    for name, (pixels, (W1, H1)) in zip(names, decoded):
+        H2, W2 = pixels.shape[:2]
         if verbose:
             print(f' - adding {name} with resolution {W1}x{H1} --> {W2}x{H2}')
-        views.append(dict(img=normalize_pixels(np.asarray(pil, dtype=np.uint8), device), true_shape=np.int32([[H2, W2]]), idx=len(views),
-                          instance=str(len(views))))
+        views.append(dict(img=normalize_pixels(pixels, device), true_shape=np.int32([[H2, W2]]), idx=len(views), instance=str(len(views))))
     assert views, 'no images foud at ' + root
     if verbose:
         print(f' (Found {len(views)} images)')

@@ -470,3 +470,20 @@ def test_host_result_tensors_and_image_upload_helpers():
     imgs = [torch.full((1, 3, 4, 4), float(k)) for k in range(5)]
     assert torch.equal(upload_stack(imgs, 'cpu'), torch.cat(imgs))
     assert torch.equal(upload_stack([torch.ones(2, 3), torch.zeros(1, 3)], 'cpu'), torch.tensor([[1.0] * 3, [1.0] * 3, [0.0] * 3]))
+
+
+def test_load_images_thread_pool_keeps_pixels_and_order(tmp_path, monkeypatch):
+    """load_images decodes / resamples the files of a folder on a thread pool (PIL releases the GIL): same tensors, same idx / instance order as the
+    serial loop (DUST3R_AMD_LOAD_THREADS=1), files that are not images skipped as in the reference (image.py:84-86)."""
+    from dust3r_amd.utils.image import load_images
+    sizes = [(640, 480), (480, 640), (500, 500), (1280, 720), (333, 222), (64, 48), (800, 600)]
+    for k, (W, H) in enumerate(sizes):
+        _write_case_png(tmp_path, k, W, H)
+    (tmp_path / 'notes.txt').write_text('not an image')
+    monkeypatch.setenv('DUST3R_AMD_LOAD_THREADS', '8')
+    many = load_images(str(tmp_path), size=512, verbose=False)
+    monkeypatch.setenv('DUST3R_AMD_LOAD_THREADS', '1')
+    one = load_images(str(tmp_path), size=512, verbose=False)
+    assert len(many) == len(one) == len(sizes)
+    for k, (a, b) in enumerate(zip(many, one)):
+        assert torch.equal(a['img'], b['img']) and (a['true_shape'] == b['true_shape']).all() and a['idx'] == b['idx'] == k and a['instance'] == b['instance'] == str(k)
