@@ -9,3 +9,9 @@ Python host mirroring the reference API of naver/dust3r for that path:
 The arithmetic lives in csrc/ (hand-written HIP for CDNA4) behind the C ABI of include/dust3r_hip.h.
 """
 __version__ = '0.1.0'
+
+# Host-side tensor work of the path (collation, result memory, scene construction) runs on torch's intra-op pool: keep that pool inside the CPU quota
+# this process actually has (utils/device.py:fit_host_threads -- never raises the count; DUST3R_AMD_KEEP_TORCH_THREADS=1 opts out).
+from .utils.device import fit_host_threads as _fit_host_threads  # noqa: E402
+
+_fit_host_threads()

@@ -99,6 +99,20 @@ def _alloc_outputs(P, H, W, out_device):
             dict(pts3d_in_other_view=torch.empty((P, H, W, 3), **kw), conf=torch.empty((P, H, W), **kw)))
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device, role):
+    """The side stream of `role` on `device`, created once per process. A stream per inference() call meant an HSA queue created and -- whenever the garbage
+    collector got to the previous call's -- destroyed per call: sporadic 30-100 ms stalls at arbitrary places of a one-pair call on the MI355X box
+    (profiles/r05_y/cat_probe.log), 54 ms per call on average against 10 ms of GPU work."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class _PredictionSink:
     """Where the per-batch predictions go. Device outputs: a plain copy. Host outputs (the reference's format, inference.py:68): the
     D2H copies of batch k are issued on a side stream AFTER batch k + 1 has been enqueued, so the blocking copy into the (pageable,
@@ -114,7 +128,7 @@ class _PredictionSink:
         self.compute_device = torch.device(compute_device)
         self.stash = None
         if self.host:
-            self.stream = torch.cuda.Stream(device=compute_device)
+            self.stream = _side_stream(compute_device, 'predictions')
 
     def _flush(self):
         if self.stash is None:
@@ -177,7 +191,7 @@ def _collate_views(pairs, shared=None, device_stack=None, ready=None):
     light = [tuple({k: v for k, v in view.items() if k != 'img'} for view in p) for p in pairs]
     view1, view2 = collate_with_cat(light)
     dev = device_stack.device
-    side = torch.cuda.Stream(device=dev) if ready is not None else None
+    side = _side_stream(dev, 'views') if ready is not None else None
 
     def gather(index, chunk=128):      # in chunks: 2 x len(pairs) whole images never sit in HBM at once (2.8 GB for 600 pairs at 512x384)
         out = host_tensor((len(index),) + tuple(device_stack.shape[1:]), dtype=device_stack.dtype)     # zero-filled: the pages are touched before the copies need them

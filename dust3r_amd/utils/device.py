@@ -6,6 +6,45 @@ import numpy as np
 import torch
 
 
+def usable_cpus(cap=64):
+    """CPU threads this process may actually use: min(affinity mask, cgroup CPU quota, cap). The MI355X boxes report 256 logical CPUs to
+    os.cpu_count() and run the container under a quota of 16: torch then sizes its intra-op pool at 128 threads, and a host-side `torch.cat` of ONE
+    2.4 MB image now and then takes 30-100 ms instead of 0.03 (128 OpenMP threads passing a barrier on 16 cores; profiles/r05_y/cat_probe.log)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path_q, path_p in (('/sys/fs/cgroup/cpu.max', None), ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', '/sys/fs/cgroup/cpu/cpu.cfs_period_us')):
+        try:
+            with open(path_q) as f:
+                fields = f.read().split()
+            if path_p is None:
+                if fields[0] == 'max':
+                    break
+                quota, period = int(fields[0]), int(fields[1])
+            else:
+                quota = int(fields[0])
+                with open(path_p) as f:
+                    period = int(f.read())
+                if quota <= 0:
+                    break
+            n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, cap))
+
+
+def fit_host_threads():
+    """Cap torch's intra-op thread pool at usable_cpus() (never raises it; DUST3R_AMD_KEEP_TORCH_THREADS=1 leaves torch alone). Called when the package is
+    imported: every host-side tensor operation of the inference path (collation, result allocation, the aligner's initialisation) runs on that pool."""
+    import os
+    if os.environ.get('DUST3R_AMD_KEEP_TORCH_THREADS', '') not in ('', '0'):
+        return torch.get_num_threads()
+    n = usable_cpus()
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()
+
+
 def _map_leaves(x, fn):
     """Apply fn to every leaf of nested dicts / lists / tuples, keeping the container types."""
     if isinstance(x, dict):

@@ -79,7 +79,7 @@ def load_images(folder_or_list, size, square_ok=False, verbose=True, patch_size=
 
     def decode(name):
         """One file -> (cropped uint8 pixels, source size). PIL releases the GIL while it decodes and resamples, so the files of a folder are
-        prepared on a thread pool (DUST3R_AMD_LOAD_THREADS, default min(16, cores)): same PIL calls per image, same pixels, same order."""
+        prepared on a thread pool (DUST3R_AMD_LOAD_THREADS, default min(16, usable cores)): same PIL calls per image, same pixels, same order."""
         pil = exif_transpose(PIL.Image.open(os.path.join(root, name))).convert('RGB')
         W1, H1 = pil.size
         new_size, box = fit_geometry(W1, H1, size, square_ok=square_ok, patch_size=patch_size)
@@ -88,7 +88,8 @@ def load_images(folder_or_list, size, square_ok=False, verbose=True, patch_size=
         pil = pil.resize(new_size, PIL.Image.LANCZOS if max(W1, H1) > target else PIL.Image.BICUBIC).crop(box)
         return np.asarray(pil, dtype=np.uint8), (W1, H1)
 
-    threads = max(1, min(int(os.environ.get('DUST3R_AMD_LOAD_THREADS', 16)), os.cpu_count() or 1, len(names)))
+    from .device import usable_cpus
+    threads = max(1, min(int(os.environ.get('DUST3R_AMD_LOAD_THREADS', 16)), usable_cpus(), len(names)))
     if threads > 1:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=threads) as pool:

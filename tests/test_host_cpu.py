@@ -487,3 +487,24 @@ def test_load_images_thread_pool_keeps_pixels_and_order(tmp_path, monkeypatch):
     assert len(many) == len(one) == len(sizes)
     for k, (a, b) in enumerate(zip(many, one)):
         assert torch.equal(a['img'], b['img']) and (a['true_shape'] == b['true_shape']).all() and a['idx'] == b['idx'] == k and a['instance'] == b['instance'] == str(k)
+
+
+def test_host_thread_pool_is_capped_at_the_usable_cpus(monkeypatch):
+    """utils/device.py: usable_cpus() = min(affinity, cgroup quota); fit_host_threads() lowers torch's intra-op pool to it, never raises it, and
+    DUST3R_AMD_KEEP_TORCH_THREADS=1 leaves torch alone. Importing the package applies it."""
+    import dust3r_amd  # noqa: F401
+    from dust3r_amd.utils import device as D
+    n = D.usable_cpus()
+    assert 1 <= n <= max(1, len(os.sched_getaffinity(0)))
+    assert torch.get_num_threads() <= max(n, 1)
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setattr(D, 'usable_cpus', lambda cap=64: 1)
+        monkeypatch.setenv('DUST3R_AMD_KEEP_TORCH_THREADS', '1')
+        assert D.fit_host_threads() == before
+        monkeypatch.delenv('DUST3R_AMD_KEEP_TORCH_THREADS')
+        assert D.fit_host_threads() == 1 and torch.get_num_threads() == 1
+        monkeypatch.setattr(D, 'usable_cpus', lambda cap=64: 64)
+        assert D.fit_host_threads() == 1                      # never raised
+    finally:
+        torch.set_num_threads(before)
