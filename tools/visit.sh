@@ -22,7 +22,7 @@ case $mode in
     done; done ;;
   collect)
     dst=profiles/$name; mkdir -p $dst
-    for f in device.txt prof_summary.txt bench.json bench.log pytest_gpu.log pytest_gpu_fast.log smoke.log latency.log e2e_full.log probe.log; do [ -f $OUT/$f ] && cp $OUT/$f $dst/; done
+    for f in device.txt prof_summary.txt prof_bench.json bench.json bench.log pytest_gpu.log pytest_gpu_fast.log smoke.log latency.log e2e_full.log probe.log; do [ -f $OUT/$f ] && cp $OUT/$f $dst/; done
     cp $OUT/ab_*.txt $OUT/*selftest*.json $OUT/bench_*.json $dst/ 2>/dev/null
     f=$(find $OUT/prof -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $dst/bench_kernel_stats.csv
     if [ -f $OUT/pmc_latest.json ]; then cp $OUT/pmc_latest.json $dst/; cp $OUT/pmc_latest.json profiles/pmc_latest.json; fi
