@@ -518,7 +518,8 @@ def self_launch(args):
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), D3R_BENCH_SELF_LAUNCHED='1')
-    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    from dust3r_amd.utils.device import usable_cpus
+    env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cpus() // max(args.gpus, 1))))       # the CPUs this container may use (not the box's logical CPUs), shared by the ranks
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.abspath(__file__)] + sys.argv[1:]
     log('[bench] WORLD_SIZE unset: launching ' + ' '.join(cmd))

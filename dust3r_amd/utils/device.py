@@ -40,6 +40,10 @@ def fit_host_threads():
     if os.environ.get('DUST3R_AMD_KEEP_TORCH_THREADS', '') not in ('', '0'):
         return torch.get_num_threads()
     n = usable_cpus()
+    try:                                       # one process per GPU under torch.distributed.run: the ranks of a node share the quota
+        n = max(1, n // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1'))))
+    except ValueError:
+        pass
     if torch.get_num_threads() > n:
         torch.set_num_threads(n)
     return torch.get_num_threads()
