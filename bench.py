@@ -715,6 +715,41 @@ def main():
             log('[bench] latency: ' + ', '.join(f"{k} {v['ms_per_call']:.2f} ms" for k, v in lat.items()))
         except Exception as e:
             result['latency'] = {'error': repr(e)}
+        # the same calls through the PUBLIC API, host to host: CPU images in, CPU predictions out (what dust3r/demo.py:156 and visloc.py:88 time)
+        try:
+            from dust3r_amd.image_pairs import make_pairs
+            from dust3r_amd.inference import inference
+            from dust3r_amd.synthetic import synthetic_image_list
+            host = {}
+            imgs = synthetic_image_list(100, H, W, seed=0)
+            one = [(imgs[0], imgs[1])]
+            for _ in range(3):
+                inference(one, model, device, batch_size=1, verbose=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                inference(one, model, device, batch_size=1, verbose=False)
+            torch.cuda.synchronize()
+            host['one_pair_ms'] = (time.perf_counter() - t1) / 20 * 1e3
+            many = make_pairs(imgs, scene_graph='swin-3', prefilter=None, symmetrize=True)
+            inference(many[:64], model, device, batch_size=32, verbose=False)
+            runs = []
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                out = inference(many, model, device, batch_size=32, verbose=False)
+                torch.cuda.synchronize()
+                runs.append(time.perf_counter() - t1)
+                del out
+            host['pairs_600_s'], host['pairs_600_pairs_per_s'] = min(runs), len(many) / min(runs)
+            host['what'] = ('dust3r_amd.inference.inference() host to host (CPU image tensors in, CPU prediction + view tensors out, the reference\'s return format): one pair per call '
+                            '(batch_size=1), and BASELINE configs[4]\'s pair list (100 views, swin-3 symmetrised = 600 pairs, each distinct image encoded once), best of two')
+            result['latency']['public_api_host_to_host'] = host
+            log(f"[bench] public API host to host: one pair {host['one_pair_ms']:.2f} ms, 600 pairs {host['pairs_600_s']:.2f} s = {host['pairs_600_pairs_per_s']:.0f} pairs/s")
+            del imgs, many, one
+        except Exception as e:
+            if isinstance(result.get('latency'), dict):
+                result['latency']['public_api_host_to_host'] = {'error': repr(e)}
 
     # ---- opt-in fast modes: NOT parity-grade, reported with their measured error and their own roofline block --------------
     # Error = per-pixel relative pointmap difference against the headline (parity-grade) engine on the same weights and the
