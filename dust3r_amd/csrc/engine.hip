@@ -14,6 +14,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -66,6 +68,25 @@ struct DptHead {
 
 }  // namespace
 
+// The engines of a process share their helper streams (per device and role; never destroyed). A HIP stream is bound to one of a few hardware queues (4 by default,
+// GPU_MAX_HW_QUEUES) in creation order: with a stream per engine, the n-th engine of a process could find its second stream on the caller's own hardware queue -- the
+// two decoder sides then run one after the other (measured on MI355X: the THIRD engine created in a process took 13.1 ms per one-pair call against 10.1 ms for the
+// first, second and fourth; profiles/r05_y/ln_inline3.log). One process-wide stream per role keeps every engine on the placement the first one got. Stream order only
+// adds dependencies, so engines driven from different host threads stay correct (their side work serialises on the shared stream).
+static hipStream_t shared_stream(int role) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, hipStream_t> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pool.find({dev, role});
+    if (it != pool.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    pool[{dev, role}] = s;
+    return s;
+}
+
 struct d3r_model {
     d3r_model_config cfg;
     int dt = 0, ktile = 64;
@@ -74,9 +95,10 @@ struct d3r_model {
     // and norm1 / norm2 / norm3 / norm_y of the decoder blocks are not launched -- the fp32-residual epilogue in front of them also stores the RAW
     // typed rows and per-row partial sums, the nn.Linear behind them is packed as W diag(gamma) and applies rstd / mean in its epilogue.
     // enc_norm / dec_norm (their outputs leave the engine or feed the heads) stay kernels. D3R_LN_FOLD=0|1 at model creation.
-    int ln_inline_rows = 0;   // probe D3R_LN_INLINE_ROWS=n: folded LayerNorms of at most n rows get their statistics in the consumer's prologue (GemmParams::ln_part_in) instead
-                              // of an ln_finalize launch. Bit-identical; measured SLOWER (one pair 10.57 vs 10.17 ms, four 27.2 vs 25.5: profiles/r05_v) -- the fp64 butterflies
-                              // in front of every tile cost more than the launch they replace. Default 0 = always launch.
+    int ln_inline_rows = 3072; // folded LayerNorms of at most this many rows (calls of one or two pairs; the decoder sides of four) get their statistics in the consumer GEMM's prologue
+                              // (GemmParams::ln_part_in; kernels.hpp ln_row_stats = ln_finalize_kernel's arithmetic with four adjacent lanes per row) instead of by an ln_finalize
+                              // launch: bit-identical, one pair 10.32 -> 10.10 ms, two 15.27 -> 15.09, four and eight equal (profiles/r05_y/ln_inline3.log; the first version, 32
+                              // lanes per row with five fp64 exchange levels in front of every tile, was SLOWER: r05_v). D3R_LN_INLINE_ROWS=n at creation; 0 = always launch.
     int enc_split_max = 0;    // encoder of calls with <= this many images (two views): the two views as two concurrent chains on the two streams (D3R_ENC_SPLIT)
     bool ln_fold = false, fold_dirty = false;
     std::vector<Lin*> fold_lins;
@@ -495,15 +517,19 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     m->zero_page = m->dalloc(4096);
     if (!m->rope_table || !m->zero_page) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
     if (launch_rope_table(m->rope_table, 512, cfg->rope_freq, 1.0f, nullptr) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_LAUNCH; }
-    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming) != hipSuccess ||
+    m->side = shared_stream(0);
+    if (!m->side || hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
     if (const char* e = getenv("D3R_GRAPH_MAX_PAIRS")) m->graph_max_pairs = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("D3R_ENC_SPLIT")) m->enc_split_max = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("D3R_LN_INLINE_ROWS")) m->ln_inline_rows = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("D3R_DEC_KV_AHEAD")) m->kv_ahead_rows = atoi(e) > 0 ? atoi(e) : 0;
-    for (int s = 0; s < 2; ++s)
-        if (hipStreamCreateWithFlags(&m->kvs[s], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_kv_go[s], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&m->ev_kv_done[s], hipEventDisableTiming) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
+    if (m->kv_ahead_rows > 0)          // probe only: its two streams and four events exist when it is switched on
+        for (int s = 0; s < 2; ++s) {
+            m->kvs[s] = shared_stream(1 + s);
+            if (!m->kvs[s] || hipEventCreateWithFlags(&m->ev_kv_go[s], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&m->ev_kv_done[s], hipEventDisableTiming) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
+        }
     (void)hipDeviceSynchronize();
     *out = m;
     return D3R_OK;
@@ -516,11 +542,11 @@ extern "C" int d3r_model_destroy(d3r_model* m) {
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     if (m->ev_main) (void)hipEventDestroy(m->ev_main);
     if (m->ev_side) (void)hipEventDestroy(m->ev_side);
-    if (m->side) (void)hipStreamDestroy(m->side);
+    if (m->side) (void)hipStreamSynchronize(m->side);      // shared with the process' other engines (shared_stream): drained, never destroyed
     for (int s = 0; s < 2; ++s) {
+        if (m->kvs[s]) (void)hipStreamSynchronize(m->kvs[s]);
         if (m->ev_kv_go[s]) (void)hipEventDestroy(m->ev_kv_go[s]);
         if (m->ev_kv_done[s]) (void)hipEventDestroy(m->ev_kv_done[s]);
-        if (m->kvs[s]) (void)hipStreamDestroy(m->kvs[s]);
     }
     m->drop_graphs();
     if (m->cap) (void)hipStreamDestroy(m->cap);

@@ -199,30 +199,24 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     // swapped for that block (square tiles only) so that a lane owns 4 consecutive tokens.
     const bool vt_wide = (DT == D3R_BF16 || DT == D3R_F16) && p.epi == EPI_HEADS && (p.ntok & 63) == 0 && !(p.flags & GF_NOWIDE);
     const bool swap = !vt_wide && (BM == BN) && (p.epi == EPI_HEADS) && (head_kind_of(p, n0 / p.head_c) == HEAD_VT);
-    // Folded LayerNorm, SMALL problems (GemmParams::ln_part_in, the one- to four-pair forwards): the rstd / -mean rstd of this tile's BM rows are formed HERE from the
-    // producer's partial sums instead of by a launch of ln_finalize_kernel between the two GEMMs (9 us in a dependent chain of ~25 us kernels). The arithmetic IS that
-    // kernel's -- 32 lanes per row, pairs g and g + 32 added in fp64, xor butterfly 1 .. 16 -- so a row's statistics are bit-identical whichever route formed them
-    // (the batch-vs-one-pair tests compare the two). Every column tile of a row panel writes the same values to the same addresses and reads back what it wrote itself;
-    // the stores are complete before the epilogue through the K loop's barriers (each waits vmcnt(0)).
+    // Folded LayerNorm, SMALL problems (GemmParams::ln_part_in, the one- to eight-pair forwards): the rstd / -mean rstd of this tile's BM rows are formed HERE from the
+    // producer's partial sums instead of by a launch of ln_finalize_kernel between the two GEMMs (a launch + gap in a dependent chain of ~25 us kernels). The arithmetic IS
+    // that kernel's (ln_row_stats, kernels.hpp: its 32-lane butterfly as a binary tree, lower levels in registers, upper levels by lane exchange), so a row's statistics are
+    // bit-identical whichever route formed them and however many threads shared the row (the batch-vs-one-pair tests compare the routes). Every column tile of a row panel writes the same values
+    // to the same addresses and reads back what it wrote itself; the stores are complete before the epilogue through the K loop's barriers (each waits vmcnt(0)).
     if constexpr (DT == D3R_F16X3) {
         if (p.ln_part_in) {
+            constexpr int TPR = (CF::NT / BM) >= 4 ? 4 : ((CF::NT / BM) >= 2 ? 2 : 1);      // threads per row (adjacent lanes)
             const int G = p.K >> 5;
-            const double inv_c = (double)p.ln_inv_c;      // 1 / C as the host rounds it: the value ln_finalize_kernel is launched with
-            for (int t = tid; t < BM * 32; t += CF::NT) {
-                const int g = t & 31, m = m0 + (t >> 5);
-                const float2* pr = reinterpret_cast<const float2*>(p.ln_part_in) + (size_t)min(m, p.M - 1) * G;
-                double sm = 0.0, sq = 0.0;
-                if (g < G) { const float2 v = pr[g]; sm = (double)v.x; sq = (double)v.y; }
-                if (g + 32 < G) { const float2 v = pr[g + 32]; sm += (double)v.x; sq += (double)v.y; }
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
-                if (g == 0 && m < p.M) {
-                    const double mean = sm * inv_c;
-                    double var = sq * inv_c - mean * mean;
-                    var = var > 0.0 ? var : 0.0;
-                    const float rs = (float)(1.0 / sqrt(var + (double)p.ln_eps));
+            // uniform trip count, no branch around the lane exchanges: threads past the tile's rows work on a clamped row and only the store is predicated
+#pragma unroll 1
+            for (int r0 = 0; r0 < BM; r0 += CF::NT / TPR) {
+                const int r = r0 + tid / TPR, m = m0 + r;
+                float rs, nm;
+                ln_row_stats<TPR>(reinterpret_cast<const float2*>(p.ln_part_in) + (size_t)min(m, p.M - 1) * G, G, tid % TPR, p.ln_inv_c, p.ln_eps, rs, nm);
+                if (tid % TPR == 0 && r < BM && m < p.M) {
                     const_cast<float*>(p.ln_rstd)[m] = rs;
-                    const_cast<float*>(p.ln_nmr)[m] = (float)(-mean) * rs;
+                    const_cast<float*>(p.ln_nmr)[m] = nm;
                 }
             }
         }

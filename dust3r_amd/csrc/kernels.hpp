@@ -131,4 +131,37 @@ hipError_t launch_pack_convt_bias(const float* src, float* dst, int cout, int co
 // ------------------------------------------------------------------------------ aligner
 struct AlignerDev;  // defined in aligner.hip
 
+// Row statistics of a folded LayerNorm from the producer's G partial (sum x, sum x^2) pairs, formed by TPR = 1, 2 or 4 ADJACENT lanes per row in the consumer GEMM's prologue
+// (GemmParams::ln_part_in) with EXACTLY the arithmetic of ln_finalize_kernel (elementwise.hip: 32 lanes per row, lane g adds pairs g and g + 32 in fp64, xor butterfly 1 .. 16):
+// a butterfly over lanes is a balanced binary tree with adjacent pairing, and fp addition commutes, so a thread that owns W = 32 / TPR consecutive lane values reproduces the tree's
+// lower levels in registers (a[i] += a[i + o], o = 1, 2, ...) and the upper levels by lane exchange (xor 1, xor 2 = the kernel's xor W, xor 2 W). rstd = 1 / sqrt(max(var, 0) + eps),
+// nmr = -mean rstd; every lane of the row returns them.
+#if defined(__HIPCC__)
+template <int TPR> D3R_DEV void ln_row_stats(const float2* __restrict__ pr, int G, int sub, float inv_c, float eps, float& rstd, float& nmr) {
+    static_assert(TPR == 1 || TPR == 2 || TPR == 4, "threads per row");
+    constexpr int W = 32 / TPR;
+    double a[W], b[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const int g = sub * W + i;
+        double s = 0.0, t = 0.0;
+        if (g < G) { const float2 v = pr[g]; s = (double)v.x; t = (double)v.y; }
+        if (g + 32 < G) { const float2 v = pr[g + 32]; s += (double)v.x; t += (double)v.y; }
+        a[i] = s; b[i] = t;
+    }
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1)
+#pragma unroll
+        for (int i = 0; i < W; i += 2 * o) { a[i] += a[i + o]; b[i] += b[i + o]; }
+    double s = a[0], t = b[0];
+    if constexpr (TPR >= 2) { s += __shfl_xor(s, 1); t += __shfl_xor(t, 1); }
+    if constexpr (TPR == 4) { s += __shfl_xor(s, 2); t += __shfl_xor(t, 2); }
+    const double mean = s * (double)inv_c;
+    double var = t * (double)inv_c - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    nmr = (float)(-mean) * rstd;
+}
+#endif
+
 }  // namespace d3r

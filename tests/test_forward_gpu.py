@@ -751,9 +751,9 @@ def test_encoder_views_on_two_streams_is_bit_identical(gpu, monkeypatch):
 
 
 def test_layernorm_statistics_in_the_consumer_prologue_are_bit_identical(gpu, monkeypatch):
-    """D3R_LN_INLINE_ROWS=n at engine creation (round 5 probe, default off: measured slower): folded LayerNorms of at most n rows get rstd / -mean rstd from the consumer GEMM's prologue
-    instead of an ln_finalize launch. The prologue repeats that kernel's arithmetic (32 lanes per row, fp64 butterfly), so outputs are bit-identical -- which is what keeps a batch bit-equal
-    to its one-pair calls if the two ever take different routes."""
+    """D3R_LN_INLINE_ROWS=n at engine creation (default 3072: calls of one or two pairs): folded LayerNorms of at most n rows get rstd / -mean rstd from the consumer GEMM's prologue
+    instead of an ln_finalize launch. The prologue repeats that kernel's arithmetic (kernels.hpp ln_row_stats: its 32-lane fp64 butterfly as a binary tree, 1 / 2 / 4 adjacent lanes
+    per row by tile), so outputs are bit-identical -- which is what keeps a batch (launch route) bit-equal to its one-pair calls (prologue route)."""
     from oracle.dust3r_ref import build_ref_model
     oracle = _randomize_norms(build_ref_model('tiny_dpt'), seed=5)
     monkeypatch.setenv('D3R_LN_FOLD', '1')
