@@ -401,6 +401,15 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
         scene_views = (scene_out['view1'], scene_out['view2'])
         del scene_out
         log(f'[bench] consistent synthetic scene for the alignment stage built + packed in {time.time() - t:.1f} s')
+    if c5 and world > 1:
+        # Stage B on ALL ranks (round 5: compute_global_alignment(group=...), one contiguous range of images per rank, one all-reduce of the reduced sums per iteration,
+        # bit-identical to the one-GPU loop): every rank needs the scene's values and its view metadata -- broadcast once, ahead of the timed region
+        if rank != 0:
+            scene_payload = torch.empty((P, H, W, 8), dtype=torch.float32, device=device)
+        dist.broadcast(scene_payload, src=0)
+        meta = [scene_views if rank == 0 else None]
+        dist.broadcast_object_list(meta, src=0)
+        scene_views = meta[0]
     stage = {}
 
     def step():
@@ -410,7 +419,7 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
             allp = gathered
         else:
             allp = local
-        if not c5 or rank != 0:
+        if not c5:
             return allp, None
         from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
         torch.cuda.synchronize()
@@ -422,12 +431,13 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
         del handed
         output = dict(view1=scene_views[0], view2=scene_views[1], pred1=pred1, pred2=pred2, loss=None)
         scene = global_aligner(output, device, mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
-        loss = scene.compute_global_alignment(init='mst', niter=300, schedule='cosine', lr=0.01)
+        loss = scene.compute_global_alignment(init='mst', niter=300, schedule='cosine', lr=0.01, group=True if world > 1 else None)
         poses, focals = scene.get_im_poses(), scene.get_focals()
         torch.cuda.synchronize()
         stage['align_s'] = time.perf_counter() - t
         stage['loss'], stage['poses_finite'] = float(loss), bool(torch.isfinite(poses).all())
-        stage['focal_err'] = float((focals.detach().flatten().cpu() / scene_gt['focal'] - 1).abs().max())
+        if scene_gt is not None:
+            stage['focal_err'] = float((focals.detach().flatten().cpu() / scene_gt['focal'] - 1).abs().max())
         return allp, scene
 
     for _ in range(args.warmup):
@@ -459,7 +469,7 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
                   data='synthetic' + selftest)
     cfg = {'workload': f'{MODEL}, {n_views} synthetic 512x384 views -> make_pairs({graph!r}, symmetrize={sym}) = {P} pairs (BASELINE configs[{4 if c5 else 2}]), cost-balanced shards (dust3r_amd.parallel.shard_plan: <= '
                        f'{per} pairs per rank), each distinct image of a shard encoded once, ONE all-gather of the packed predictions per job'
-                       + ('; then global_aligner(PointCloudOptimizer) + init=mst + 300 cosine Adam iterations on rank 0 (values of a consistent synthetic scene of the same shape, fed through the gathered payload tensor)' if c5 else '') + '; random-init weights, images resident in HBM',
+                       + ('; then on every rank global_aligner(PointCloudOptimizer) + init=mst (replicated) + 300 cosine Adam iterations SHARED by the ranks (a contiguous range of images each, one all-reduce of the reduced sums per iteration: compute_global_alignment(group=...)); values of a consistent synthetic scene of the same shape, fed through the gathered payload tensor' if c5 else '') + '; random-init weights, images resident in HBM',
            'pairs': P, 'views': n_views, 'pairs_per_rank': counts, 'distinct_images_per_rank': images_per_rank,
            'distinct_images_per_rank_max_min': [max(images_per_rank), min(images_per_rank)], 'shard_plan': plan.summary(), 'pairs_per_engine_call': args.pairs,
            'parallelism': f'pair-sharded dp{world}'}

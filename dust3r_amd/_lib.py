@@ -75,6 +75,11 @@ def _load():
         'd3r_aligner_set_option': (i, [vp, i, i]),
         'd3r_aligner_run': (i, [vp, i, i, i, f, f, i, fp, vp]),
         'd3r_aligner_loss_grad': (i, [vp, fp, fp, fp, fp, fp, fp, fp, vp]),
+        'd3r_aligner_set_image_range': (i, [vp, i, i]),
+        'd3r_aligner_step_begin': (i, [vp, i, i, i, f, f, i, vp]),
+        'd3r_aligner_step_end': (i, [vp, i, i, i, f, f, i, vp]),
+        'd3r_aligner_reduced_sums': (i, [vp, C.POINTER(vp), C.POINTER(C.c_longlong)]),
+        'd3r_aligner_read_losses': (i, [vp, i, fp, vp]),
         'd3r_nearest_neighbors': (i, [fp, i, fp, i, ip, vp]),
         'd3r_clean_pointcloud': (i, [i, fp, fp, fp, fp, fp, ip, ip, i, f, f, vp]),
         'd3r_row_means': (i, [fp, i, i, i, fp, vp]),

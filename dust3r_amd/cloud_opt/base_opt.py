@@ -305,7 +305,10 @@ class BasePCOptimizer(nn.Module):
     def forward(self, ret_details=False):
         raise NotImplementedError()
 
-    def compute_global_alignment(self, init=None, niter_PnP=10, **kw):
+    def compute_global_alignment(self, init=None, niter_PnP=10, group=None, **kw):
+        """`group` (new; the reference's loop is single-device): a torch.distributed process group (or True for the default one) whose ranks each hold this
+        scene -- the return value of `inference_sharded` -- and then share the loop: every rank owns a contiguous range of images (global_alignment_loop_sharded).
+        The initialisation runs replicated (it is deterministic); poses, focals and the final loss are the same on every rank, bit for bit what one GPU computes."""
         if init is None:
             pass
         elif init in ('msp', 'mst'):
@@ -314,6 +317,8 @@ class BasePCOptimizer(nn.Module):
             init_fun.init_from_known_poses(self, min_conf_thr=self.min_conf_thr, niter_PnP=niter_PnP)
         else:
             raise ValueError(f'bad value for {init=}')
+        if group is not None and group is not False:
+            return global_alignment_loop_sharded(self, group=None if group is True else group, **kw)
         return global_alignment_loop(self, **kw)
 
 
@@ -350,6 +355,93 @@ def global_alignment_loop(net, lr=0.01, niter=300, schedule='cosine', lr_min=1e-
     if bar is not None:
         bar.close()
     return loss
+
+
+def image_ranges(edges, imshapes, world):
+    """Contiguous image ranges [(first, count)] * world with balanced work: the main pass of an image costs its area times (the edge sides projected onto it + 1.5
+    for its own depth map and Adam state: 32 B per edge-side pixel against 24 + 24 B per pixel). Ranks beyond the number of images get empty ranges."""
+    n = len(imshapes)
+    sides = [0] * n
+    for i, j in edges:
+        sides[i] += 1
+        sides[j] += 1
+    cost = [(sides[k] + 1.5) * imshapes[k][0] * imshapes[k][1] for k in range(n)]
+    cum = [0.0]
+    for c in cost:
+        cum.append(cum[-1] + c)
+    cuts = [0]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        k = cuts[-1]
+        while k < n and cum[k + 1] <= target:
+            k += 1
+        if k < n and target - cum[k] > cum[k + 1] - target:       # the nearer of the two neighbouring cuts
+            k += 1
+        cuts.append(max(k, cuts[-1]))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
+
+
+@torch.no_grad()
+def global_alignment_loop_sharded(net, group=None, lr=0.01, niter=300, schedule='cosine', lr_min=1e-6):
+    """global_alignment_loop over the ranks of `group` (one process per GPU; every rank holds the whole scene). Rank r runs the main pass of ITS images
+    (include/dust3r_hip.h, d3r_aligner_set_image_range / step_begin / step_end); the reduced fp64 sums ((2 E + n) x 16 doubles: 160 KB at 100 views / 600 edges) are
+    all-reduced once per iteration, and the pose / focal step runs replicated. Every partial record belongs to one image, i.e. to one rank: the other ranks add exact
+    zeros, so losses and parameters are bit-identical to the single-GPU loop for any number of ranks. Start: the trainable parameters are broadcast from rank 0 (a
+    random `init=None` start differs between processes); end: every rank receives the other ranks' rows of im_depthmaps."""
+    import torch.distributed as dist
+    if schedule not in ('cosine', 'linear'):
+        raise ValueError(f'bad lr {schedule=}')
+    if niter <= 0:
+        return float('inf')
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    for name in net.trainable_names():
+        dist.broadcast(getattr(net, name).data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    eng = net._ensure_engine()
+    ranges = image_ranges(net.edges, net.imshapes, world)
+    first, count = ranges[rank]
+    check(lib.d3r_aligner_set_option(eng, 2, 0), 'reset adam')
+    check(lib.d3r_aligner_set_image_range(eng, first, count), 'set_image_range')
+    red_ptr, red_n = C.c_void_p(), C.c_longlong()
+    check(lib.d3r_aligner_reduced_sums(eng, C.byref(red_ptr), C.byref(red_n)), 'reduced_sums')
+    # the engine's reduction buffer seen as a tensor (no copy): the collective works on it in place
+    red = _device_view(red_ptr.value, int(red_n.value), torch.float64, net.device)
+    sched = 0 if schedule == 'cosine' else 1
+    cap = int(getattr(net, '_engine_max_iters', 1024))
+    losses = torch.empty(min(niter, cap), dtype=torch.float32, device=net.device)
+    done, loss = 0, float('inf')
+    try:
+        while done < niter:
+            k_run = min(cap, niter - done)
+            for k in range(k_run):
+                check(lib.d3r_aligner_step_begin(eng, k, done, niter, float(lr), float(lr_min), sched, current_stream()), 'aligner_step_begin')
+                dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)
+                check(lib.d3r_aligner_step_end(eng, k, done, niter, float(lr), float(lr_min), sched, current_stream()), 'aligner_step_end')
+            check(lib.d3r_aligner_read_losses(eng, k_run, ptr(losses), current_stream()), 'aligner_read_losses')
+            done += k_run
+            loss = float(losses[k_run - 1])
+    finally:
+        check(lib.d3r_aligner_set_image_range(eng, 0, net.n_imgs), 'set_image_range(all)')
+    # every rank's own rows of the log-depth maps -> all ranks (sum with zeros elsewhere: exact)
+    depth = net.im_depthmaps.data
+    own = torch.zeros_like(depth)
+    own[first:first + count] = depth[first:first + count]
+    dist.all_reduce(own, op=dist.ReduceOp.SUM, group=group)
+    depth.copy_(own)
+    return loss
+
+
+def _device_view(address, numel, dtype, device):
+    """A torch tensor over `numel` elements of device memory the engine owns (no copy, no ownership)."""
+    class _Span:
+        pass
+    span = _Span()
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    span.__cuda_array_interface__ = {'shape': (numel,), 'typestr': {torch.float64: '<f8', torch.float32: '<f4'}[dtype], 'data': (int(address), False), 'version': 2,
+                                     'strides': None}
+    t = torch.as_tensor(span, device=device)
+    assert t.data_ptr() == int(address) and t.numel() == numel and t.element_size() == itemsize
+    return t
 
 
 @torch.no_grad()

@@ -26,6 +26,7 @@ static constexpr int PW = 16;            // floats per partial record
 
 struct AlignerView {
     int n, E, maxA, nslot;  // nslot = workgroups (1024-pixel chunks) per image: one partial record per workgroup
+    int img0;               // first image of this launch (d3r_aligner image range: one process per GPU owns a contiguous range of images)
     const int* img_w;       // [n]
     const int* img_area;    // [n]
     const int* adj_off;     // [n+1]
@@ -105,7 +106,8 @@ template <bool L2, int PF, int NWV = 4, int PROBE = 0, int LAY = 0>   // PF = pr
 __global__ __launch_bounds__(NWV * 64) void aligner_main_kernel(AlignerView a) {
     constexpr int NTH = NWV * 64, CHUNK_T = NTH * PPT;
     const int nchunk = a.nslot;
-    const int img = blockIdx.x / nchunk, chunk = blockIdx.x - img * nchunk;
+    const int img_l = blockIdx.x / nchunk, chunk = blockIdx.x - img_l * nchunk;
+    const int img = a.img0 + img_l;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p0 = chunk * CHUNK_T + threadIdx.x * PPT;
     const int area = a.img_area[img], W = a.img_w[img];
@@ -745,6 +747,12 @@ struct d3r_aligner {
     float base_scale = 0.5f, pw_break = 20.f, focal_break = 20.f, inv_area[2] = {0, 0};
     int l2 = 0, norm_pw_scale = 1, opt_poses = 1, opt_focals = 1, opt_pp = 0, opt_adapt = 0, use_dpp = 1;
     long step = 0;
+    // Image range (d3r_aligner_set_image_range; default: all images): the main kernel runs over the images [img0, img0 + imgc) only. A partial record belongs to
+    // exactly one image -- the one whose pixels an edge side is compared with -- so with one process per GPU owning a contiguous range of images, the reduced
+    // sums of the other images' records are exact zeros here, and an all-reduce (sum) of the reduced buffer across the ranks between d3r_aligner_step_begin and
+    // d3r_aligner_step_end gives every rank bit for bit the sums of the single-GPU iteration; the pose / focal step then runs replicated.
+    int img0 = 0, imgc = -1;
+    bool part_clear_pending = false;
     bool reset_pending = false;   // D3R_ALIGNER_OPT_RESET_ADAM: cleared on the next run's stream
     bool generic_small = false;   // D3R_ALIGNER_OPT_GENERIC_SMALL
     int loss_cap = 0;
@@ -893,8 +901,9 @@ static AdamCoef adam_coef(double lr, long step) {
     return c;
 }
 
+// phase 0: the whole iteration; 1: [derived matrices] + main kernel + reduction (d3r_aligner_step_begin); 2: pose / focal step + step count (d3r_aligner_step_end)
 static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, float* g_pw, float* g_imp, float* g_depth, float* g_foc,
-                        bool refresh_derived_first, hipStream_t st, float* g_pp = nullptr, float* g_pa = nullptr) {
+                        bool refresh_derived_first, hipStream_t st, float* g_pp = nullptr, float* g_pa = nullptr, int phase = 0) {
     SmallView s;
     s.n = a->n; s.E = a->E; s.pw_poses = a->pw_poses; s.pw_adaptors = a->pw_adaptors; s.im_poses = a->im_poses;
     s.im_focals = a->im_focals; s.im_pp = a->im_pp; s.img_w = a->d_w; s.img_h = a->d_h;
@@ -906,12 +915,25 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
     s.base_scale = a->base_scale; s.pw_break = a->pw_break; s.focal_break = a->focal_break;
     s.norm_pw_scale = a->norm_pw_scale; s.opt_poses = a->opt_poses; s.opt_focals = a->opt_focals;
     s.update = 0; s.adam = adam_coef(lr, a->step + 1);
+    if (phase == 2) {
+        s.update = update ? 1 : 0;
+        s.g_pw = g_pw; s.g_imp = g_imp; s.g_foc = g_foc; s.g_pp = g_pp; s.g_pa = g_pa;
+        launch_small(s, st, a->generic_small);
+        if (update) a->step++;
+        return hipGetLastError() == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
+    }
     if (refresh_derived_first) {
         SmallView s0 = s;
         s0.loss_hist = nullptr;
         launch_small(s0, st, a->generic_small);
     }
+    const int imgc = a->imgc < 0 ? a->n : a->imgc;
+    if (a->part_clear_pending) {        // records of images outside the range must read as zero (they are never written here)
+        HIPCHK(hipMemsetAsync(a->part_edge, 0, (size_t)(2 * a->E + a->n) * a->nslot * PW * sizeof(float), st));
+        a->part_clear_pending = false;
+    }
     AlignerView v;
+    v.img0 = a->img0;
     v.n = a->n; v.E = a->E; v.maxA = a->maxA; v.nslot = a->nslot; v.img_w = a->d_w; v.img_area = a->d_area;
     v.adj_off = a->d_adj_off; v.adj_es = a->d_adj_es; v.pred[0] = a->pred[0]; v.pred[1] = a->pred[1]; v.inter = a->inter; v.maxAp = a->maxAp;
     v.wgt[0] = a->wgt[0]; v.wgt[1] = a->wgt[1]; v.depth = a->im_depth; v.depth_m = a->depth_m; v.depth_v = a->depth_v;
@@ -920,7 +942,8 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
     v.use_dpp = a->use_dpp; v.adam = s.adam;
     // D3R_ALIGNER_PF=2: two edges of the stream in flight per wave (probe; 16 more VGPRs, 3 instead of 4 waves per SIMD)
     static const int pf = [] { const char* e = getenv("D3R_ALIGNER_PF"); return (e && e[0] == '2') ? 2 : 1; }();
-    const dim3 grid(a->n * a->nslot);
+    const dim3 grid(imgc * a->nslot);
+    if (imgc > 0) {
     if (a->probe && !a->l2) {
         if (a->probe == 1 && pf == 2) hipLaunchKernelGGL((aligner_main_kernel<false, 2, 4, 1>), grid, dim3(256), 0, st, v);
         else if (a->probe == 1) hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 1>), grid, dim3(256), 0, st, v);
@@ -938,8 +961,10 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
         if (pf == 2) hipLaunchKernelGGL((aligner_main_kernel<false, 2>), grid, dim3(256), 0, st, v);
         else hipLaunchKernelGGL((aligner_main_kernel<false, 1>), grid, dim3(256), 0, st, v);
     }
+    }
     // part_edge | part_img and red_edge | red_img are contiguous: one launch reduces the 2E + n entries
     hipLaunchKernelGGL(aligner_reduce_kernel, dim3(2 * a->E + a->n), dim3(256), 0, st, a->part_edge, a->red_edge, a->nslot);
+    if (phase == 1) return hipGetLastError() == hipSuccess ? D3R_OK : D3R_ERR_LAUNCH;
     s.update = update ? 1 : 0;
     s.g_pw = g_pw; s.g_imp = g_imp; s.g_foc = g_foc; s.g_pp = g_pp; s.g_pa = g_pa;
     launch_small(s, st, a->generic_small);
@@ -983,6 +1008,50 @@ extern "C" int d3r_aligner_run(d3r_aligner* a, int niter, int iter0, int niter_t
         if (rc != D3R_OK) return rc;
     }
     if (losses_out_device) HIPCHK(hipMemcpyAsync(losses_out_device, a->loss_hist, niter * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return D3R_OK;
+}
+
+// ---- one iteration in two calls, for one process per GPU (include/dust3r_hip.h) ------------------------------------------------------------------
+static double sched_lr(int k, int iter0, int niter_total, float lr_base, float lr_min, int schedule) {
+    const double t = (double)(iter0 + k) / (double)niter_total;
+    return schedule == D3R_SCHEDULE_COSINE ? (double)lr_min + ((double)lr_base - (double)lr_min) * (1.0 + cos(t * M_PI)) / 2.0
+                                           : (double)lr_base + ((double)lr_min - (double)lr_base) * t;
+}
+
+extern "C" int d3r_aligner_set_image_range(d3r_aligner* a, int first, int count) {
+    if (!a || first < 0 || count < 0 || first + count > a->n) return D3R_ERR_INVALID;
+    a->img0 = first;
+    a->imgc = (first == 0 && count == a->n) ? -1 : count;
+    a->part_clear_pending = true;
+    return D3R_OK;
+}
+
+extern "C" int d3r_aligner_step_begin(d3r_aligner* a, int k, int iter0, int niter_total, float lr_base, float lr_min, int schedule, void* stream) {
+    if (!a || k < 0 || k >= a->loss_cap || niter_total <= 0) return D3R_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    aligner_wait_ready(a, st);
+    if (a->reset_pending) {
+        HIPCHK(hipMemsetAsync(a->depth_m, 0, (size_t)((char*)a->d_edge - (char*)a->depth_m), st));
+        a->reset_pending = false;
+    }
+    return aligner_pass(a, true, sched_lr(k, iter0, niter_total, lr_base, lr_min, schedule), k, nullptr, nullptr, nullptr, nullptr, k == 0, st, nullptr, nullptr, 1);
+}
+
+extern "C" int d3r_aligner_step_end(d3r_aligner* a, int k, int iter0, int niter_total, float lr_base, float lr_min, int schedule, void* stream) {
+    if (!a || k < 0 || k >= a->loss_cap || niter_total <= 0) return D3R_ERR_INVALID;
+    return aligner_pass(a, true, sched_lr(k, iter0, niter_total, lr_base, lr_min, schedule), k, nullptr, nullptr, nullptr, nullptr, false, (hipStream_t)stream, nullptr, nullptr, 2);
+}
+
+extern "C" int d3r_aligner_reduced_sums(d3r_aligner* a, void** ptr, long long* count) {
+    if (!a || !ptr || !count) return D3R_ERR_INVALID;
+    *ptr = a->red_edge;                               // red_edge | red_img: contiguous fp64 [2E + n][16]
+    *count = (long long)(2 * a->E + a->n) * PW;
+    return D3R_OK;
+}
+
+extern "C" int d3r_aligner_read_losses(d3r_aligner* a, int niter, float* losses_out_device, void* stream) {
+    if (!a || niter <= 0 || niter > a->loss_cap || !losses_out_device) return D3R_ERR_INVALID;
+    HIPCHK(hipMemcpyAsync(losses_out_device, a->loss_hist, niter * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return D3R_OK;
 }
 

@@ -249,6 +249,22 @@ int d3r_aligner_set_option(d3r_aligner* a, int option, int value);
  * at base_opt.py:366 -- but without the reference's per-iteration host synchronisation. */
 int d3r_aligner_run(d3r_aligner* a, int niter, int iter0, int niter_total, float lr_base, float lr_min, int schedule,
                     float* losses_out, void* stream);
+/* The alignment loop over SEVERAL GPUs (one process per GPU; new: the reference's loop, base_opt.py:326-366, is single-device; SURVEY.md 8(e) names it as the
+ * optional next step). Every rank holds the whole scene (what the all-gather of the forward hands over) and the replicated parameters, and owns a contiguous range
+ * of IMAGES: d3r_aligner_set_image_range(first, count). One iteration is then
+ *     d3r_aligner_step_begin   [derived matrices on the first iteration] + the main pass over the owned images (their edge sides, their depth maps and the fused
+ *                              Adam step of those) + the fixed-order fp64 reduction of the partial records
+ *     all-reduce (sum) of the buffer d3r_aligner_reduced_sums returns (fp64 [2 E + n][16] on the device), by the caller's collective library
+ *     d3r_aligner_step_end     the pose / focal / pairwise-pose step (replicated: same inputs, same arithmetic on every rank) and the loss of iteration k
+ * A partial record belongs to exactly one image, so the other ranks contribute exact zeros to every sum: the all-reduced sums -- and with them the trajectory --
+ * equal the single-GPU iteration bit for bit, whatever the number of ranks. The log-depth maps (and their Adam moments) of an image are updated on its owner
+ * only; the caller exchanges the owned rows of im_depthmaps when the loop is over. k, iter0, niter_total, lr_base, lr_min, schedule as in d3r_aligner_run
+ * (k < max_iters_per_run); d3r_aligner_read_losses copies the losses of iterations 0 .. niter-1 of the current run to a device array. */
+int d3r_aligner_set_image_range(d3r_aligner* a, int first_image, int n_images);
+int d3r_aligner_step_begin(d3r_aligner* a, int k, int iter0, int niter_total, float lr_base, float lr_min, int schedule, void* stream);
+int d3r_aligner_step_end(d3r_aligner* a, int k, int iter0, int niter_total, float lr_base, float lr_min, int schedule, void* stream);
+int d3r_aligner_reduced_sums(d3r_aligner* a, void** device_ptr, long long* n_doubles);
+int d3r_aligner_read_losses(d3r_aligner* a, int niter, float* losses_out, void* stream);
 /* one forward/backward without a step (parity tests): loss[1] and the gradients w.r.t. each parameter tensor (any may be NULL);
  * g_im_pp [n][2]: principal-point parameters (optimizer.py:141-142, trained when optimize_pp=True); g_pw_adaptors [E][2]: pairwise
  * xy / z adaptors (base_opt.py:143-149, trained when allow_pw_adaptors=True) */

@@ -47,3 +47,40 @@ def worker(rank, world, port, outdir):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------- the alignment loop over two ranks on one GPU
+ALIGN_SCENE = dict(n_views=7, H=96, W=128, seed=3, scene_graph='complete', symmetrize=True, noise=0.005)
+ALIGN_NITER = 40
+
+
+def aligned_scene(gpu, group, init):
+    import torch
+    from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
+    from dust3r_amd.synthetic import synthetic_scene
+    out, state, _ = synthetic_scene(device=gpu, **ALIGN_SCENE)
+    torch.manual_seed(11)                                    # the random start of init=None (every process draws the same; rank 0's is broadcast anyway)
+    scene = global_aligner(out, device=gpu, mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
+    if init == 'state':
+        scene.load_state_dict(state)
+        loss = scene.compute_global_alignment(init=None, niter=ALIGN_NITER, schedule='cosine', lr=0.01, group=group)
+    else:
+        loss = scene.compute_global_alignment(init='mst', niter=ALIGN_NITER, schedule='cosine', lr=0.01, group=group)
+    res = {k: getattr(scene, k).detach().cpu().clone() for k in ('pw_poses', 'im_poses', 'im_depthmaps', 'im_focals')}
+    res['loss'] = float(loss)
+    return res
+
+
+def align_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    gpu = torch.device('cuda', 0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        out = {init: aligned_scene(gpu, True, init) for init in ('state', 'mst')}
+        torch.save(out, os.path.join(outdir, f'align_rank{rank}.pt'))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()

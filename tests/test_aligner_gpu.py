@@ -427,3 +427,37 @@ def test_pair_viewer_matches_reference(gpu):
         assert a.shape == b.shape and float((a.cpu() - b).norm(dim=-1).median()) < 2e-2
     assert scene.get_intrinsics().shape == (2, 3, 3) and len(scene.get_masks()) == 2
     assert math.isnan(scene.compute_global_alignment(init='mst', niter=10))
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_alignment_loop_over_ranks_is_bit_identical_to_one_gpu(gpu, tmp_path, world):
+    """compute_global_alignment(group=...) (new: SURVEY 8(e)'s optional step; include/dust3r_hip.h d3r_aligner_set_image_range / step_begin / step_end): `world` ranks on
+    this box's one GPU (gloo moves the CUDA sums; RCCL refuses several ranks on one device), each owning a contiguous range of the 7 images, one all-reduce of the reduced
+    sums per iteration, the pose / focal step replicated. Every partial record belongs to one image, i.e. one rank, and the others add exact zeros: loss, poses, focals,
+    pairwise poses and depth maps after 40 iterations must EQUAL the single-process loop bit for bit on every rank -- from a loaded state and after init='mst'."""
+    import os
+    import socket
+    import sys
+    import torch.multiprocessing as mp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from tests._dist_worker import align_worker, aligned_scene
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=align_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    ref = {init: aligned_scene(gpu, None, init) for init in ('state', 'mst')}      # meanwhile: the single-process loop
+    for p in procs:
+        p.join(timeout=500)
+        assert p.exitcode == 0
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f'align_rank{r}.pt'), weights_only=False)
+        for init in ('state', 'mst'):
+            assert got[init]['loss'] == ref[init]['loss'], (r, init, got[init]['loss'], ref[init]['loss'])
+            for k in ('pw_poses', 'im_poses', 'im_focals', 'im_depthmaps'):
+                assert torch.equal(got[init][k], ref[init][k]), (r, init, k, float((got[init][k] - ref[init][k]).abs().max()))
+    assert ref['state']['loss'] < 0.1 and ref['mst']['loss'] < 0.1
