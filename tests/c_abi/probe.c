@@ -17,6 +17,12 @@ int main(void) {
     if (d3r_model_profile_launch(NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL) == D3R_OK) { printf("FAIL profile_launch(NULL)\n"); ++fails; }
     if (d3r_aligner_run(NULL, 1, 0, 1, 0.01f, 1e-6f, D3R_SCHEDULE_COSINE, NULL, NULL) == D3R_OK) { printf("FAIL aligner_run(NULL)\n"); ++fails; }
     if (d3r_aligner_set_option(NULL, D3R_ALIGNER_OPT_DPP_REDUCE, 1) != D3R_ERR_INVALID) { printf("FAIL aligner_set_option(NULL)\n"); ++fails; }
+    if (d3r_aligner_set_image_range(NULL, 0, 1) != D3R_ERR_INVALID) { printf("FAIL aligner_set_image_range(NULL)\n"); ++fails; }
+    if (d3r_aligner_step_begin(NULL, 0, 0, 1, 0.01f, 1e-6f, D3R_SCHEDULE_COSINE, NULL) != D3R_ERR_INVALID) { printf("FAIL aligner_step_begin(NULL)\n"); ++fails; }
+    if (d3r_aligner_step_end(NULL, 0, 0, 1, 0.01f, 1e-6f, D3R_SCHEDULE_COSINE, NULL) != D3R_ERR_INVALID) { printf("FAIL aligner_step_end(NULL)\n"); ++fails; }
+    { void* sums = NULL; long long count = 0;
+      if (d3r_aligner_reduced_sums(NULL, &sums, &count) != D3R_ERR_INVALID) { printf("FAIL aligner_reduced_sums(NULL)\n"); ++fails; } }
+    if (d3r_aligner_read_losses(NULL, 1, NULL, NULL) != D3R_ERR_INVALID) { printf("FAIL aligner_read_losses(NULL)\n"); ++fails; }
     if (d3r_layernorm(NULL, NULL, NULL, NULL, 1, 64, 1e-6f, D3R_DTYPE_F32, NULL) != D3R_ERR_INVALID) { printf("FAIL layernorm(NULL)\n"); ++fails; }
     /* the host-only gradient self test runs without a device: one edge between two 2x2 images */
     {
