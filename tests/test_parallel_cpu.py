@@ -224,3 +224,33 @@ def test_shard_plan_weights_mixed_image_sizes_by_area():
     pairs = _mixed_pairs()
     plan = shard_plan(pairs, 3, encode_once=False)
     assert sorted(k for r in range(3) for k in plan.shard(r)) == list(range(len(pairs))) and max(plan.cost) / min(plan.cost) < 1.35
+
+
+def test_image_ranges_of_the_rank_shared_alignment_loop():
+    """cloud_opt.base_opt.image_ranges (host logic of compute_global_alignment(group=...)): contiguous, disjoint, covering ranges; balanced by area x (incident edge sides + 1.5);
+    more ranks than images leaves some ranks empty; one rank owns everything."""
+    from dust3r_amd.cloud_opt.base_opt import image_ranges
+    from dust3r_amd.synthetic import scene_edges
+    for n, graph, sym, world in ((20, 'complete', False, 8), (100, 'swin-3', True, 8), (3, 'complete', True, 8), (20, 'complete', False, 1), (7, 'complete', True, 2), (11, 'swin-2', True, 3)):
+        edges = scene_edges(n, graph, sym)
+        shapes = [(384, 512)] * n
+        r = image_ranges(edges, shapes, world)
+        assert len(r) == world and r[0][0] == 0 and sum(c for _, c in r) == n and all(c >= 0 for _, c in r)
+        assert all(r[k][0] + r[k][1] == r[k + 1][0] for k in range(world - 1))
+        if n >= 2 * world:                                      # uniform graphs: no rank more than one image above another
+            counts = [c for _, c in r]
+            assert max(counts) - min(counts) <= 1, (n, graph, world, counts)
+    # mixed sizes and degrees: a star graph (image 0 carries every edge) with one more large image -- the heavy image gets a rank of its own
+    edges = [(0, k) for k in range(1, 9)] + [(k, 0) for k in range(1, 9)]
+    shapes = [(384, 512)] + [(96, 128)] * 7 + [(384, 512)]
+    r = image_ranges(edges, shapes, 3)
+    assert sum(c for _, c in r) == 9 and [c for f, c in r if f <= 0 < f + c] == [1]       # image 0 alone on its rank (the bound of the job: it cannot be split)
+
+
+def test_upload_helpers_fall_back_off_gpu():
+    """utils/device.py upload_rows / upload_stack with a non-CUDA target (and small or non-tensor inputs): plain .to() semantics."""
+    from dust3r_amd.utils.device import upload_rows
+    t = torch.arange(24, dtype=torch.float32).reshape(4, 6)
+    assert torch.equal(upload_rows(t, 'cpu'), t) and upload_rows('x', 'cpu') == 'x'
+    big = torch.rand(40, 256, 256)                            # 10 MB: above the piece size, still the plain route on a CPU target
+    assert torch.equal(upload_rows(big, torch.device('cpu')), big)
