@@ -81,7 +81,8 @@ GEMM_CFG_NAMES = {0: 'GemmCfg<2,2,4,4,2,128,2> (128x128 tile)', 1: 'GemmCfg<2,4,
                   3: 'GemmCfg<1,8,8,4,2,128,2> (512x128 tile)', 4: 'GemmCfg<1,4,8,4,2,64,3> (256x128, 4 waves)', 5: 'GemmCfg<2,4,8,4,2,64,4> (256x256, 4 stages)', 6: 'GemmCfg<2,4,8,4,2,64,4,1> (256x256, ping-pong)',
                   7: 'GemmCfg<1,4,8,4,2,128,2,6> (256x128 tile, 4 waves, weights of a K step in registers, 2 blocks / CU)',
                   8: 'GemmCfg<2,2,2,2,4,128,2> (64x64 tile, small-batch forwards)',
-                  9: 'GemmCfg<1,8,12,3,2,128,2> (M 384 x N 192 tile: whole rounds of 256 CUs for the 24576-row decoder GEMMs)'}
+                  9: 'GemmCfg<1,8,12,3,2,128,2> (M 384 x N 192 tile: whole rounds of 256 CUs for the 24576-row decoder GEMMs)',
+                  10: 'gemm_p4_kernel (persistent, M 256 x N 128 tile by four waves with two accumulator sets: epilogue under the next tile\'s K loop)'}
 
 
 def read_profile(model):
@@ -95,8 +96,9 @@ def read_profile(model):
         return dict(launches=n.value, ms=ms.value, gflop=work.value / 1e9)
     out = {'gemm_cfg': {}, 'gemm_f8_cfg': {}, 'linear': dict(launches=0, ms=0.0, gflop=0.0), 'conv': dict(launches=0, ms=0.0, gflop=0.0)}
     zero = dict(launches=0, ms=0.0, gflop=0.0)
-    for cfg in range(10):
-        lin, cv, f8 = (rd(cfg), rd(8 + cfg), rd(24 + cfg)) if cfg < 8 else (rd(18), rd(19), dict(zero)) if cfg == 8 else (rd(21), dict(zero), dict(zero))
+    for cfg in range(11):
+        lin, cv, f8 = ((rd(cfg), rd(8 + cfg), rd(24 + cfg)) if cfg < 8 else (rd(18), rd(19), dict(zero)) if cfg == 8 else (rd(21), dict(zero), dict(zero)) if cfg == 9
+                       else (rd(22), dict(zero), dict(zero)))
         if lin is None or cv is None or f8 is None:
             return None
         for k in ('launches', 'ms', 'gflop'):
@@ -120,7 +122,7 @@ def read_launch_table(model):
         idx += 1
         k = kind.value
         name = (f'linear cfg{k}' if k < 8 else f'conv cfg{k - 8}' if k < 16 else 'attention' if k == 16 else f'lin-f8 cfg{k - 24}' if k >= 24
-                else 'linear cfg8' if k == 18 else 'conv cfg8' if k == 19 else 'linear cfg9' if k == 21 else 'other')
+                else 'linear cfg8' if k == 18 else 'conv cfg8' if k == 19 else 'linear cfg9' if k == 21 else 'linear p4' if k == 22 else 'other')
         a = agg.setdefault((name, M.value, N.value, K.value), [0, 0.0, 0.0])
         a[0] += 1
         a[1] += ms.value

@@ -44,6 +44,7 @@ def _load():
         'd3r_rope2d': (i, [vp, vp, i, i, i, i, f, f, i, vp]),
         'd3r_layernorm': (i, [fp, fp, fp, vp, i, i, f, i, vp]),
         'd3r_linear': (i, [vp, vp, fp, vp, fp, i, i, i, i, i, vp]),
+        'd3r_linear_x3res': (i, [vp, vp, fp, vp, vp, fp, i, i, i, vp]),
         'd3r_conv2d_nhwc': (i, [vp, vp, fp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp, i, vp]),
         'd3r_conv_k_slice_major': (i, []),
         'd3r_attention': (i, [vp, vp, vp, vp, i, i, i, i, i, f, i, vp]),

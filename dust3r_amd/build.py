@@ -7,14 +7,14 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['gemm.hip', 'attention.hip', 'elementwise.hip', 'aligner.hip', 'bootstrap.hip', 'engine.hip', 'capi.hip']
+SOURCES = ['gemm.hip', 'gemm_p4.hip', 'attention.hip', 'elementwise.hip', 'aligner.hip', 'bootstrap.hip', 'engine.hip', 'capi.hip']
 HEADERS = ['common.hpp', 'kernels.hpp', 'aligner_math.hpp', os.path.join('..', '..', 'include', 'dust3r_hip.h')]
 LIB = os.path.join(CSRC, 'libdust3r_hip.so')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-inline-asm']
 # attention.hip: no SLP vectorisation -- its scalar-VALU softmax slices (attention_x3_kernel<..., SC = true>) must stay v_fma_f32 / v_add_f32
 # pairs; hipcc -O3 re-packs adjacent scalar fp32 operations into v_pk_* (an anti-lever beside MFMAs, MI355X_MICROARCH.md). The packed
 # variants of the same kernel use explicit 2-vectors and are not affected.
-EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize']}
+EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize'], 'gemm_p4.hip': ['-fno-slp-vectorize']}     # gemm_p4.hip: its drain's scalar GELU pieces sit between MFMAs too
 
 
 def _hipcc():

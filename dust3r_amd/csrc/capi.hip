@@ -27,6 +27,17 @@ extern "C" int d3r_linear(const void* act, const void* wgt, const float* bias, v
     return rc_of(launch_gemm(dtype, p, (hipStream_t)stream));
 }
 
+// nn.Linear whose output joins the typed residual stream of a folded-LayerNorm engine (GemmParams GF_X3RES): out_rows = split-fp16 rows of
+// (act . wgt^T + bias + residual_rows), ln_part (optional) = the (sum, sum of squares) of every 32-column group of every stored row.
+extern "C" int d3r_linear_x3res(const void* act, const void* wgt, const float* bias, void* out_rows, const void* residual_rows, float* ln_part, int M, int N,
+                                int K, void* stream) {
+    if (!act || !wgt || !out_rows || N % 8 != 0) return D3R_ERR_INVALID;
+    GemmParams p;
+    p.act = act; p.lda = K; p.wgt = wgt; p.bias = bias; p.M = M; p.K = K; p.n_pad = rup(N, 128); p.n_rows = rup(N, 256); p.n_store = N;
+    p.epi = EPI_F32; p.flags = GF_X3RES; p.res1 = residual_rows; p.ldr = N; p.out2 = out_rows; p.ldo2 = N; p.ln_part = ln_part;
+    return rc_of(launch_gemm(D3R_F16X3, p, (hipStream_t)stream));
+}
+
 extern "C" int d3r_conv_k_slice_major(void) { return d3r::conv_k_slice_major() ? 1 : 0; }
 
 extern "C" int d3r_conv2d_nhwc(const void* in, const void* wgt, const float* bias, void* out, const void* res1, const void* res2, void* out_relu_copy,

@@ -1660,8 +1660,8 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
                                 store16(o2, odd ? make_uint4(u0, u1, l.x, l.y) : make_uint4(h.x, h.y, u0, u1), nt && x3nt);
                             }
                             if (p.ln_part) {    // folded LayerNorm: (sum, sum of squares) of the 32 values of row m in this column group (8 lanes x 4), one fixed tree
-                                float sm = (v.x + v.y) + (v.z + v.w);
-                                float sq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                                float sm, sq;
+                                ln_quad_sums(v, sm, sq);
                                 // the 8 lanes of a row (rch = lane & 7): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror -- VALU-side DPP moves, not the LDS crossbar
                                 sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), 0xB1, 0xF, 0xF, false));
                                 sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0xB1, 0xF, 0xF, false));
@@ -1985,7 +1985,20 @@ static int device_cus() {
 }
 // the tile configuration a launch of (p, dt) RUNS on -- what the engine's profile records and d3r_gemm_tile_config reports: the heuristic's
 // choice, then the remaps launch_t applies for operand types that do not have every shape
+int gemm_p4_mode() {
+    const char* e = getenv("D3R_GEMM_PERSIST");
+    return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1;
+}
+// persistent kernel (gemm_p4.hip) for this launch?
+static bool use_p4(const GemmParams& p, int dt) {
+    if (dt != D3R_F16X3 || p.force_cfg >= 0 || getenv("D3R_GEMM_CFG")) return false;
+    const int mode = gemm_p4_mode();
+    if (mode == 0 || !gemm_p4_eligible(p, dt)) return false;
+    if (mode == 1) return true;
+    return false;        // heuristic: set from measurements (see launch_gemm)
+}
 int gemm_pick_config(const GemmParams& p, int dt) {
+    if (use_p4(p, dt)) return GEMM_CFG_P4;
     int cfg = pick_config_raw(p, dt);
     const bool split = dt == D3R_F16X3 || dt == D3R_F16F8 || dt == D3R_F16X2F8;
     if (cfg == GEMM_CFG_256x128W4 && split) cfg = GEMM_CFG_256x128;
@@ -2207,6 +2220,7 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     if (f8rows && (p.amode != AMODE_LINEAR || p.K % 64 != 0 || p.lda % 64 != 0 || p.epi == EPI_CONVT || p.res2 ||
                             (p.epi == EPI_T && (p.res1 || p.out2)) || ((p.epi == EPI_T || p.epi == EPI_GELU) && (p.ldo % 64 != 0 || p.n_store % 4 != 0))))
         return hipErrorInvalidValue;
+    if (use_p4(p, dt)) return launch_gemm_p4(p, s);
 #ifdef D3R_GEMM_ONLY_DT      // development builds (-DD3R_GEMM_ONLY_DT=4): one precision mode only, a tenth of the compile time
     if (dt == D3R_GEMM_ONLY_DT) return launch_t<D3R_GEMM_ONLY_DT>(p, s);
 #else

@@ -13,7 +13,7 @@ enum { EPI_T = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_HEADS = 3, EPI_CONVT = 4, EPI_H
 // ldo2 = its pixel stride, res1 = the 1x1 weights [4][n_store] fp32, res2 = its bias [4] fp32. Nothing of the C-channel map is stored.
 enum { HEAD_ROPE = 1, HEAD_VT = 2, HEAD_PLAIN = 3 };
 enum { GF_RELU = 1, GF_NOSTORE = 2, GF_NOWIDE = 4, GF_NTSTORE = 8, GF_X3RES = 16 };   // GF_X3RES (EPI_F32, split-fp16): res1 and the result live in split-fp16 rows only (out2); no fp32 row is stored   // GF_NTSTORE: wide epilogues store with the non-temporal policy (default; D3R_GEMM_NT=0 clears it)
-enum { GEMM_CFG_128 = 0, GEMM_CFG_256 = 1, GEMM_CFG_256x128 = 2, GEMM_CFG_512x128 = 3, GEMM_CFG_256x128W4 = 4, GEMM_CFG_256S4 = 5, GEMM_CFG_256PP = 6, GEMM_CFG_256x128R = 7, GEMM_CFG_64 = 8, GEMM_CFG_384x192 = 9 };
+enum { GEMM_CFG_128 = 0, GEMM_CFG_256 = 1, GEMM_CFG_256x128 = 2, GEMM_CFG_512x128 = 3, GEMM_CFG_256x128W4 = 4, GEMM_CFG_256S4 = 5, GEMM_CFG_256PP = 6, GEMM_CFG_256x128R = 7, GEMM_CFG_64 = 8, GEMM_CFG_384x192 = 9, GEMM_CFG_P4 = 10 };
 
 struct GemmParams {
     const void* act = nullptr;   // [M][lda] (linear) or NHWC image batch (conv), element type DT
@@ -71,6 +71,10 @@ void gemm_set_trace(unsigned long long* buf, size_t capacity_blocks);
 
 hipError_t launch_gemm(int dt, const GemmParams& p, hipStream_t s);
 int gemm_pick_config(const GemmParams& p, int dt);
+// gemm_p4.hip: the persistent split-fp16 kernel whose epilogue runs under the next tile's K loop (tile configuration 10 in profiles)
+bool gemm_p4_eligible(const GemmParams& p, int dt);
+hipError_t launch_gemm_p4(const GemmParams& p, hipStream_t s);
+int gemm_p4_mode();              // -1: the heuristic decides, 0: never, 1: every eligible launch (D3R_GEMM_PERSIST, read per call: probes and tests move it)
 
 // ------------------------------------------------------------------------------ attention
 struct AttnParams {
@@ -137,6 +141,13 @@ struct AlignerDev;  // defined in aligner.hip
 // lower levels in registers (a[i] += a[i + o], o = 1, 2, ...) and the upper levels by lane exchange (xor 1, xor 2 = the kernel's xor W, xor 2 W). rstd = 1 / sqrt(max(var, 0) + eps),
 // nmr = -mean rstd; every lane of the row returns them.
 #if defined(__HIPCC__)
+// (sum, sum of squares) of the 4 values a lane holds in the read phase of a typed-residual-stream epilogue: the leaves of the fixed tree of GemmParams::ln_part.
+// Written with explicit fmas: under -ffp-contract=fast hipcc otherwise fuses `x*x + y*y` differently from kernel to kernel (gemm.hip and gemm_p4.hip
+// disagreed in 6 % of the sums' last bits), and the statistics must not depend on which kernel stored the row.
+D3R_DEV void ln_quad_sums(const float4& v, float& sm, float& sq) {
+    sm = (v.x + v.y) + (v.z + v.w);
+    sq = __builtin_fmaf(v.x, v.x, v.y * v.y) + __builtin_fmaf(v.z, v.z, v.w * v.w);
+}
 template <int TPR> D3R_DEV void ln_row_stats(const float2* __restrict__ pr, int G, int sub, float inv_c, float eps, float& rstd, float& nmr) {
     static_assert(TPR == 1 || TPR == 2 || TPR == 4, "threads per row");
     constexpr int W = 32 / TPR;

@@ -76,6 +76,13 @@ int d3r_layernorm(const float* x, const float* gamma, const float* beta, void* o
 int d3r_linear(const void* act, const void* wgt, const float* bias, void* out, const float* residual, int M, int N, int K,
                int epilogue, int dtype, void* stream);
 
+/* The same nn.Linear as the producer of a folded LayerNorm (split-fp16 only): out_rows [M][N] split-fp16 rows =
+ * act . wgt^T + bias + residual_rows (split-fp16 rows [M][N] or NULL; may alias out_rows) -- croco Block: x = x + proj(attn) / x + fc2(...)
+ * (dust3r/model.py:136-137 via croco blocks.py) -- and, when ln_part != NULL, ln_part[m][N / 32][2] = (sum, sum of squares) of each 32-column group of the
+ * stored row, from which the next LayerNorm's statistics are formed. N % 8 == 0 (ln_part: N % 32 == 0). */
+int d3r_linear_x3res(const void* act, const void* wgt, const float* bias, void* out_rows, const void* residual_rows, float* ln_part, int M, int N,
+                     int K, void* stream);
+
 /* 2-D convolution, NHWC, as implicit GEMM: in [B][Hin][Win][Cin] dtype, wgt [round_up(Cout,256)][k*k*Cin] dtype;
  * out [B][Hout][Wout][Cout] dtype = [relu](conv + bias + res1 + res2)   (DPT head convs, dust3r/heads/dpt_head.py:34-65).
  * K order of a weight row: with S = 128 / sizeof(dtype) channels per K step (Cin % S == 0),
