@@ -51,6 +51,92 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+STAGE = ['start']        # what this rank is doing, for the error line of guarded_main
+
+
+class Telemetry:
+    """Shader clock / socket power / temperature of THIS rank's GPU, sampled from the amdgpu hwmon files (/sys/class/drm/card*/device/hwmon/hwmon*:
+    freq1_input Hz, power1_input uW, power1_cap uW, temp*_input m degC) by a host thread every `period` seconds while a timed region runs. The chip is
+    power-managed: two boxes -- or two visits of one box -- run the MFMA-dense kernels at different clocks, and without these numbers beside `value` nobody can
+    tell a slower box from a regression (the round-5 driver box ran the nn.Linear launches 9.6 % slower than the builder's with convolutions equal).
+    The device's hwmon directory is found through its PCI address; failing that, the card that draws the most power while sampling."""
+
+    def __init__(self, device, period=0.02):
+        import glob
+        self.period, self.samples, self._stop, self._thread = period, [], None, None
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            want = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+        except Exception:        # noqa: BLE001 -- older torch: no PCI ids
+            pass
+        cands = []
+        for d in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
+            if os.path.exists(os.path.join(d, 'power1_input')) and os.path.exists(os.path.join(d, 'freq1_input')):
+                cands.append((os.path.basename(os.path.realpath(os.path.join(d, 'device'))), d))
+        self.matched = [d for a, d in cands if want and a.lower() == want.lower()]
+        self.dirs = self.matched or [d for _, d in cands]
+        self.pci = want
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _loop(self):
+        while not self._stop.is_set():
+            row = []
+            for d in self.dirs:
+                row.append((self._read(os.path.join(d, 'freq1_input')), self._read(os.path.join(d, 'power1_input')), self._read(os.path.join(d, 'temp2_input'))))
+            self.samples.append(row)
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        if not self.dirs:
+            return self
+        self.samples, self._stop = [], threading.Event()
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        """-> dict for the JSON line (None when the box exposes no hwmon files)."""
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join()
+        if not self.samples:
+            return None
+        n = len(self.dirs)
+        pw = [[r[k][1] for r in self.samples if r[k][1] is not None] for k in range(n)]
+        k = max(range(n), key=lambda i: sum(pw[i]) / max(len(pw[i]), 1)) if not self.matched else 0     # unmatched: the card under load
+        f = [r[k][0] / 1e6 for r in self.samples if r[k][0] is not None]
+        p = [r[k][1] / 1e6 for r in self.samples if r[k][1] is not None]
+        t = [r[k][2] / 1e3 for r in self.samples if r[k][2] is not None]
+        cap = self._read(os.path.join(self.dirs[k], 'power1_cap'))
+        mean = lambda x: sum(x) / len(x) if x else None       # noqa: E731
+        return dict(source=self.dirs[k], matched_by_pci_address=bool(self.matched), pci_address=self.pci, samples=len(self.samples), period_s=self.period,
+                    sclk_mhz_mean=mean(f), sclk_mhz_min=min(f) if f else None, sclk_mhz_max=max(f) if f else None,
+                    power_w_mean=mean(p), power_w_max=max(p) if p else None, power_cap_w=cap / 1e6 if cap else None, temp_c_max=max(t) if t else None)
+
+
+def nccl_log_path(rank):
+    return os.path.join(os.environ.get('TMPDIR', '/tmp'), f'd3r_bench_nccl_{os.environ.get("MASTER_PORT", "0")}_{rank}.log')
+
+
+def nccl_log_tail(rank, n=12):
+    """Last lines RCCL wrote for this rank (NCCL_DEBUG=WARN goes to a per-rank file: main() sets NCCL_DEBUG_FILE) -- warnings only, usually empty."""
+    try:
+        with open(nccl_log_path(rank)) as f:
+            return [ln.rstrip() for ln in f.readlines()[-n:]]
+    except OSError:
+        return []
+
+
 def emit(result):
     """ONE strictly valid JSON line: json.dumps would print NaN / Infinity for non-finite floats, which no JSON parser has to accept."""
     def clean(o):
@@ -414,16 +500,24 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
         scene_views = meta[0]
     stage = {}
 
+    ev_g0, ev_g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
     def step():
+        STAGE[0] = f'{args.workload}: forward of the shard'
         local = _local_same_size(my_pairs, per, model, device, args.pairs, device, True, H, W)
         if world > 1:
+            STAGE[0] = f'{args.workload}: all_gather of the packed predictions ({world} x {per} pairs x {H * W * 32 / 1e6:.1f} MB)'
+            ev_g0.record()
             all_gather_packed(local, out=gathered)
+            ev_g1.record()
+            stage['gather_events'] = True
             allp = gathered
         else:
             allp = local
         if not c5:
             return allp, None
         from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
+        STAGE[0] = 'c5: global_aligner + init=mst + 300 iterations'
         torch.cuda.synchronize()
         t = time.perf_counter()
         handed = allp.index_select(0, keep)                       # the caller's pair order (drops padding rows, undoes the shard plan's order)
@@ -461,6 +555,13 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    STAGE[0] = 'rank table'
+    gather_ms = None
+    if world > 1 and stage.get('gather_events'):
+        torch.cuda.synchronize()
+        g = torch.tensor([ev_g0.elapsed_time(ev_g1)], dtype=torch.float64, device=device)        # the LAST job's collective on this rank (incl. waiting for the slowest rank's shard)
+        dist.all_reduce(g, op=dist.ReduceOp.MAX)
+        gather_ms = float(g.item())
     who = rank_table(world, rank, device, len(my_pairs))
     if rank != 0:
         return None
@@ -468,6 +569,7 @@ def run_sharded(args, model, world, rank, device, one_device, backend):
     gflop = n_views * ENC_GFLOP_PER_IMAGE + P * DEC_HEAD_GFLOP_PER_PAIR if world == 1 else sum(images_per_rank) * ENC_GFLOP_PER_IMAGE + P * DEC_HEAD_GFLOP_PER_PAIR
     selftest = ' (SELF-TEST: all ranks on one device, backend ' + backend + ' -- not a scaling measurement)' if one_device and world > 1 else ''
     common = dict(n_gpus=world, rccl_world_size=who['rccl_world_size'], collective_backend=who['backend'], distinct_devices=who['distinct_devices'], ranks=who['ranks'], steps=args.steps, warmup=args.warmup, ms_per_step=sec * 1e3, scaling='strong', vs_baseline=None, dtype=args.precision,
+                  gather_ms=gather_ms, gather_note='HIP-event time of the ONE all-gather of the last job, max over ranks (includes waiting for the slowest shard); null at N = 1: nothing is gathered',
                   data='synthetic' + selftest)
     cfg = {'workload': f'{MODEL}, {n_views} synthetic 512x384 views -> make_pairs({graph!r}, symmetrize={sym}) = {P} pairs (BASELINE configs[{4 if c5 else 2}]), cost-balanced shards (dust3r_amd.parallel.shard_plan: <= '
                        f'{per} pairs per rank), each distinct image of a shard encoded once, ONE all-gather of the packed predictions per job'
@@ -545,7 +647,7 @@ def rank_table(world, rank, device, units):
     over the process group, and the world size the COLLECTIVE LIBRARY reports (dist.get_world_size(), not the --gpus argument)."""
     prop = torch.cuda.get_device_properties(device)
     row = dict(rank=rank, device=str(device), name=prop.name, gcn_arch=getattr(prop, 'gcnArchName', None), pci_bus_id=getattr(prop, 'pci_bus_id', None),
-               uuid=str(getattr(prop, 'uuid', '')) or None, pairs_per_step=units, host=os.uname().nodename, pid=os.getpid())
+               uuid=str(getattr(prop, 'uuid', '')) or None, pairs_per_step=units, host=os.uname().nodename, pid=os.getpid(), nccl_warnings=nccl_log_tail(rank))
     if world > 1 and dist.is_initialized():
         rows = [None] * world
         dist.all_gather_object(rows, row)
@@ -595,10 +697,21 @@ def main():
     if world > 1 or force_gather:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
+        import datetime
+        os.environ.setdefault('NCCL_DEBUG', 'WARN')                       # RCCL reads the NCCL_* variables; warnings of each rank go to its own file and into the rank table
+        os.environ.setdefault('NCCL_DEBUG_FILE', nccl_log_path(rank))
+        STAGE[0] = f'init_process_group({backend})'
+        tmo = datetime.timedelta(seconds=int(os.environ.get('D3R_BENCH_COLLECTIVE_TIMEOUT', '300')))
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+        STAGE[0] = 'first collective'
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)                                            # the first collective builds the communicators: fail HERE, with a name, not inside the timed loop
+        torch.cuda.synchronize()
+        assert int(probe.item()) == world, f'all_reduce of ones returned {probe.item()} on a world of {world}'
+    STAGE[0] = 'build model'
 
     from dust3r_amd import _lib
     from dust3r_amd.parallel import all_gather_packed
@@ -652,6 +765,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    STAGE[0] = 'c2: timed steps'
+    tele = Telemetry(device).start()
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
@@ -662,6 +777,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    telemetry = tele.stop()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -683,7 +799,10 @@ def main():
             'forward_tflops_per_gpu': value / world * GFLOP_PER_PAIR / 1e3,
             'forward_frac_of_bf16_mfma_peak': value / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS,
         }
-        log(f'[bench] {value:.2f} pairs/s on {world} GPU(s), {dt / args.steps * 1e3:.1f} ms/step')
+        result['telemetry'] = telemetry
+        if telemetry:
+            result['sclk_mhz_mean'], result['power_w_mean'] = telemetry['sclk_mhz_mean'], telemetry['power_w_mean']
+        log(f'[bench] {value:.2f} pairs/s on {world} GPU(s), {dt / args.steps * 1e3:.1f} ms/step; telemetry {telemetry}')
 
     # ---- parity of the timed configuration itself: the last timed step's outputs vs one-pair-per-call runs -----------
     if rank == 0 and not args.no_parity and last is not None:
@@ -703,9 +822,18 @@ def main():
 
     # ---- live per-kernel timing (HIP events on the launch stream, outside the timed region) ---------------------
     if rank == 0 and not args.no_profile:
+        STAGE[0] = 'c2: profiled forward'
+        tele2 = Telemetry(device).start()
         blk = profile_mode(model, v1, v2, args.precision)
+        t2 = tele2.stop()
         if blk:
             result.update(blk)
+            rf = result.get('roofline')
+            if rf and telemetry and telemetry.get('sclk_mhz_mean'):
+                # the peak in `roofline.peak` is the nominal 2.4 GHz figure; the chip ran the timed steps at sclk_mhz_mean: frac against the peak AT THAT CLOCK
+                rf['frac_at_sampled_clock'] = rf['frac'] * 2400.0 / telemetry['sclk_mhz_mean']
+                rf['sampled_clock_note'] = ('frac x 2400 MHz / telemetry.sclk_mhz_mean (the clock the power management held during the timed steps'
+                                            + (f'; {t2["sclk_mhz_mean"]:.0f} MHz during the profiled single-stream forward' if t2 and t2.get('sclk_mhz_mean') else '') + ')')
 
     # ---- small batches: the reference's own call shape (dust3r/demo.py:156 batch_size=1, visloc.py:88 one pair per query) ----------------
     if rank == 0 and world == 1 and not args.no_latency:
@@ -857,5 +985,33 @@ def main():
         dist.destroy_process_group()
 
 
+def guarded_main():
+    """Scale-run hygiene (round 6): a rank that fails -- RCCL initialisation, the all-gather, an engine error -- or exceeds its wall-clock limit prints ONE JSON line
+    {"error": ..., "rank": ..., "stage": ...} on stdout and exits non-zero, instead of a hang or a bare traceback: the first 8-GPU run is diagnosable from its output.
+    D3R_BENCH_RANK_TIMEOUT (seconds, default 1500) bounds every rank; collectives carry the process group's own timeout (D3R_BENCH_COLLECTIVE_TIMEOUT, default 300 s)."""
+    import signal
+    import traceback
+    rank = int(os.environ.get('RANK', '0'))
+
+    def fail(kind, detail):
+        tail = nccl_log_tail(rank)
+        print(json.dumps({'error': kind, 'detail': detail[-2000:], 'rank': rank, 'world_size': int(os.environ.get('WORLD_SIZE', '1')), 'stage': STAGE[0],
+                          'host': os.uname().nodename, 'pid': os.getpid(), 'nccl_log_tail': tail}), flush=True)
+
+    def on_alarm(signum, frame):
+        fail('rank timeout', f'rank {rank} exceeded D3R_BENCH_RANK_TIMEOUT in stage {STAGE[0]!r}:\n' + ''.join(traceback.format_stack(frame)[-6:]))
+        os._exit(3)
+    if 'WORLD_SIZE' in os.environ or '--gpus' not in sys.argv:
+        signal.signal(signal.SIGALRM, on_alarm)
+        signal.alarm(int(os.environ.get('D3R_BENCH_RANK_TIMEOUT', '1500')))
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:      # noqa: BLE001 -- whatever it is, it becomes the one line
+        fail(type(e).__name__, traceback.format_exc())
+        os._exit(2)
+
+
 if __name__ == '__main__':
-    main()
+    guarded_main()

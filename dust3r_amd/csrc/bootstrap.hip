@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const PnpJob* jobs, cons
 }
 
 // Gauss-Newton sums over the inliers of pose[job] (reprojection error^2 < thr2, in front of the camera), unknowns = (rotation increment
-// w about the camera origin, translation increment), Huber-weighted (delta = 1 px): J^T W J (21, upper triangle row-major), J^T W r (6),
+// w about the camera origin, translation increment), plain least squares over the consensus set, like the refinement behind cv2.solvePnPRansac (round 6; rounds 2-5 weighted it Huber-wise, delta = 1 px: a different
+// estimator, a few 1e-3 rad away from the reference's on noisy pointmaps): J^T W J (21, upper triangle row-major), J^T W r (6),
 // cost, inlier count.
 // (A DLT refit of the consensus set from fp32 moments was tried first: the 12x12 normal matrix is too ill-conditioned for it.)
 static constexpr int PNP_NV = 29;
@@ -296,8 +297,9 @@ __global__ __launch_bounds__(256) void pnp_sums_kernel(const PnpJob* jobs, const
             }
             Ju[3] = fx; Ju[4] = 0.f; Ju[5] = a0;
             Jv[3] = 0.f; Jv[4] = fx; Jv[5] = a1;
-            // Huber weight (delta = 1 pixel): a stray point that happens to reproject inside the consensus band pulls with a bounded force
-            const float rn = sqrtf(ru * ru + rv * rv), hw = rn > 1.f ? 1.f / rn : 1.f;
+            // unit weight: the reference refines the RANSAC consensus set in plain least squares (init_im_poses.py:272-275 -> cv2.solvePnPRansac); the 5-pixel
+            // band already bounds what a stray point can pull
+            const float hw = 1.f;
             int k = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a)

@@ -44,12 +44,15 @@ struct Slot {
     std::string mirror;       // dec_blocks.* -> dec_blocks2.* duplication
     struct Lin* fold = nullptr;   // PK_MAT: this matrix has the LayerNorm in front of it folded in (ln_fold engines): staged in fp32, packed by finalize_fold
     bool refold = false;          // PK_VEC: a LayerNorm weight / bias or the bias of a folded nn.Linear -- a new value makes the fold stale
+    std::vector<struct Lin*> refold_lins;   // ... of these matrices (only THEY are re-folded: round 6)
+    unsigned fold_bit = 0;        // PK_MAT with a fold: this slot's bit in Lin::want_mask (a Lin fed by several tensors -- projk | projv -- is complete when all were staged)
 };
 
 struct LNp { float* g = nullptr; float* b = nullptr; };
 // dt: operand layout of this GEMM. ln != nullptr (ln_fold engines): W is packed as W diag(gamma), b_fold = b + W beta, ln_s[n] = sum_k of the packed row n
 struct Lin { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, n_pad = 0, n_rows = 0, dt = 0;
-             const LNp* ln = nullptr; float* ln_s = nullptr; float* b_fold = nullptr; float* w32 = nullptr; };
+             const LNp* ln = nullptr; float* ln_s = nullptr; float* b_fold = nullptr; float* w32 = nullptr;
+             bool fold_dirty = false; unsigned want_mask = 0, have_mask = 0; };      // fold bookkeeping per matrix: stale? which of its weight tensors sit in w32?
 struct EncBlk { LNp n1, n2; Lin qkv, proj, fc1, fc2; };
 struct DecBlk { LNp n1, n2, n3, ny; Lin qkv, proj, cq, ckv, cproj, fc1, fc2; };
 struct ConvW { void* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0, cin_pad = 0, k = 1, n_pad = 0, n_rows = 0, K = 0; };
@@ -237,10 +240,10 @@ bool reg_fold(d3r_model* m, Lin& L, const LNp& ln, const std::string& lnkey, std
     L.ln_s = (float*)m->dalloc((size_t)L.n_rows * sizeof(float));
     L.b_fold = (float*)m->dalloc((size_t)L.n_rows * sizeof(float));
     if (!L.ln_s || !L.b_fold) return false;
-    for (auto& k : wkeys) m->slots[k].fold = &L;
-    for (auto& k : bkeys) m->slots[k].refold = true;
-    m->slots[lnkey + ".weight"].refold = true;
-    m->slots[lnkey + ".bias"].refold = true;
+    unsigned bit = 1;
+    for (auto& k : wkeys) { m->slots[k].fold = &L; m->slots[k].fold_bit = bit; L.want_mask |= bit; bit <<= 1; }
+    for (auto& k : bkeys) { m->slots[k].refold = true; m->slots[k].refold_lins.push_back(&L); }
+    for (const char* sfx : {".weight", ".bias"}) { Slot& ls = m->slots[lnkey + sfx]; ls.refold = true; ls.refold_lins.push_back(&L); }
     m->fold_lins.push_back(&L);
     return true;
 }
@@ -348,14 +351,19 @@ int pack_slot(d3r_model* m, Slot& s, const float* data, int ndim, const int64_t*
         case PK_IGNORE: return D3R_OK;
         case PK_VEC:
             if (numel != (size_t)s.rows) return D3R_ERR_SHAPE;
-            if (s.refold) m->fold_dirty = true;
+            if (s.refold) { m->fold_dirty = true; for (Lin* L : s.refold_lins) L->fold_dirty = true; }
             return hipMemcpyAsync(s.dst, data, numel * sizeof(float), hipMemcpyDeviceToDevice, nullptr) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
         case PK_MAT:
             if (ndim < 2 || shape[0] != s.rows || numel != (size_t)s.rows * s.cols) return D3R_ERR_SHAPE;
             pp.kind = PACK_MAT; pp.cols = s.cols; pp.row_off = s.row_off;
             if (s.fold) {       // the LayerNorm in front of this matrix is folded into it: keep the fp32 rows until finalize_fold packs W diag(gamma)
                 Lin& L = *s.fold;
-                if (!L.w32 && hipMalloc((void**)&L.w32, (size_t)L.N * L.K * sizeof(float)) != hipSuccess) { L.w32 = nullptr; return D3R_ERR_ALLOC; }
+                if (!L.w32) {
+                    if (hipMalloc((void**)&L.w32, (size_t)L.N * L.K * sizeof(float)) != hipSuccess) { L.w32 = nullptr; return D3R_ERR_ALLOC; }
+                    L.have_mask = 0;            // a fresh staging copy holds nothing yet
+                }
+                L.have_mask |= s.fold_bit;
+                L.fold_dirty = true;
                 m->fold_dirty = true;
                 return hipMemcpyAsync(L.w32 + (size_t)s.row_off * L.K, data, numel * sizeof(float), hipMemcpyDeviceToDevice, nullptr) == hipSuccess ? D3R_OK : D3R_ERR_ALLOC;
             }
@@ -1133,13 +1141,17 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
 
 }  // namespace
 
-// ln_fold engines: (re)pack every nn.Linear behind a folded LayerNorm as W diag(gamma) and form its column sums / folded bias, from the fp32
-// rows staged by pack_slot. Runs once after a load (the first forward finds fold_dirty); the staging copies are released afterwards, so a later
-// load of ONLY a LayerNorm vector or a bias (without the matrices) cannot be folded: D3R_ERR_STATE (include/dust3r_hip.h, d3r_model_load_tensor).
+// ln_fold engines: (re)pack the nn.Linear matrices behind a folded LayerNorm whose inputs changed as W diag(gamma) and form their column sums / folded bias,
+// from the fp32 rows staged by pack_slot. Runs at the first forward after a load; the staging copies are released afterwards. Bookkeeping is PER MATRIX
+// (round 6; before, one stale vector made every one of the ~100 folded matrices demand a reload): a matrix is re-folded when one of its weight tensors, its
+// bias or its LayerNorm's vectors were loaded, and it needs ALL of its weight tensors staged for that (projk | projv: both). A vector-only update of a
+// matrix whose staging copy is gone cannot be folded: D3R_ERR_STATE until that matrix's weights are loaded again (include/dust3r_hip.h, d3r_model_load_tensor);
+// the other matrices are unaffected.
 static int finalize_fold(d3r_model* m) {
     if (!m->ln_fold || !m->fold_dirty) return D3R_OK;
-    for (Lin* L : m->fold_lins) if (!L->w32) return D3R_ERR_STATE;
+    for (Lin* L : m->fold_lins) if (L->fold_dirty && (!L->w32 || L->have_mask != L->want_mask)) return D3R_ERR_STATE;
     for (Lin* L : m->fold_lins) {
+        if (!L->fold_dirty) continue;
         PackParams pp;
         pp.src = L->w32; pp.numel = (size_t)L->N * L->K; pp.dst = L->w; pp.dst_cols = L->K; pp.kind = PACK_MAT; pp.cols = L->K; pp.row_off = 0;
         pp.kscale = L->ln->g;
@@ -1147,7 +1159,13 @@ static int finalize_fold(d3r_model* m) {
         if (launch_ln_fold_vectors(L->dt, L->w32, L->ln->g, L->ln->b, L->b, L->ln_s, L->b_fold, L->N, L->K, nullptr) != hipSuccess) return D3R_ERR_LAUNCH;
     }
     if (hipDeviceSynchronize() != hipSuccess) return D3R_ERR_LAUNCH;
-    for (Lin* L : m->fold_lins) { (void)hipFree(L->w32); L->w32 = nullptr; }
+    for (Lin* L : m->fold_lins) {
+        if (!L->fold_dirty) continue;
+        (void)hipFree(L->w32);
+        L->w32 = nullptr;
+        L->have_mask = 0;
+        L->fold_dirty = false;
+    }
     m->fold_dirty = false;
     return D3R_OK;
 }

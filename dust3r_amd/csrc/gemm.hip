@@ -1985,17 +1985,26 @@ static int device_cus() {
 }
 // the tile configuration a launch of (p, dt) RUNS on -- what the engine's profile records and d3r_gemm_tile_config reports: the heuristic's
 // choice, then the remaps launch_t applies for operand types that do not have every shape
+static int device_cus();
 int gemm_p4_mode() {
     const char* e = getenv("D3R_GEMM_PERSIST");
     return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1;
 }
-// persistent kernel (gemm_p4.hip) for this launch?
+// persistent kernel (gemm_p4.hip) for this launch? Measured on MI355X inside the 32-pair forward (tools/launch_table.py, profiles/r06_*): it wins where the
+// epilogue is a large share of a tile's life and the tiles fill whole rounds of the CUs -- fc1 + GELU 395 -> 427 (encoder) / 363 -> 398 TFLOP/s (decoder),
+// the typed-residual projections at K <= 1024 348 -> 362, typed stores +4..12 % -- ties at K = 4096 (fc2: the K loop dominates; the one-tile-per-block
+// kernels keep it) and loses where its 256 x 128 tiles leave the last round of CUs mostly empty (the decoder's N = 768 GEMMs: 576 tiles = 2.25 rounds).
 static bool use_p4(const GemmParams& p, int dt) {
     if (dt != D3R_F16X3 || p.force_cfg >= 0 || getenv("D3R_GEMM_CFG")) return false;
     const int mode = gemm_p4_mode();
     if (mode == 0 || !gemm_p4_eligible(p, dt)) return false;
     if (mode == 1) return true;
-    return false;        // heuristic: set from measurements (see launch_gemm)
+    const long tiles = (long)(p.M / 256) * (p.n_store / 128);
+    const int cus = device_cus();
+    const long rounds = (tiles + cus - 1) / cus;
+    if (tiles < cus || tiles * 100 < rounds * cus * 88) return false;      // the last round at least ~half full on average: >= 88 % of the tile slots used
+    if (p.epi == EPI_F32 && p.K > 1024) return false;
+    return true;
 }
 int gemm_pick_config(const GemmParams& p, int dt) {
     if (use_p4(p, dt)) return GEMM_CFG_P4;

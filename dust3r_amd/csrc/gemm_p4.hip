@@ -1,23 +1,24 @@
 // dust3r_amd -- persistent split-fp16 GEMM whose epilogue runs UNDER the next tile's K loop (gfx950; round 6).
 //
 // What it is for (reference call sites): the nn.Linear layers of the 24 encoder / 2 x 12 decoder blocks at batch sizes whose GEMMs fill the
-// chip (dust3r/model.py:136-137,180-186 -> croco Block / DecoderBlock: qkv, proj, fc1, fc2, projq / projk|projv). In gemm.hip one block
-// computes one tile and then stores it: for K <= 1024 a tile spends 15-25 % of its life in the epilogue with the CU's matrix pipes idle
-// (tools/tile_probe.py: the same launches without their epilogue run 505-514 TFLOP/s against 371-438 with it).
+// chip (dust3r/model.py:136-137,180-186 -> croco Block / DecoderBlock: proj, fc1, fc2). In gemm.hip one block computes one tile and then
+// stores it: for K <= 1024 a tile spends 15-25 % of its life in the epilogue with the CU's matrix pipes idle (tools/tile_probe.py: the same
+// launches without their epilogue run 505-514 TFLOP/s against 371-438 with it).
 //
 // Shape. One block per CU, FOUR waves, one per SIMD, each with the whole 512-entry register file: 256 accumulator registers = TWO sets of
 // the 128 (n) x 64 (m) wave tile (8 x 4 fragments of v_mfma_f32_16x16x32_f16, the wave tile of gemm.hip's 256 x 256 shape, so the LDS read
 // traffic per MFMA is the same). Block tile M 256 x N 128. A block walks its tiles (the XCD-contiguous panel order of gemm.hip, strided by
-// the grid); set C accumulates tile t while set D -- tile t - 1 -- is drained in 16 micro-slices, one per K step, placed between the MFMAs:
-// accumulator -> bias / folded LayerNorm / GELU / split -> wave-private LDS rows -> 16-byte global stores. Operands arrive by
-// global_load_lds DMA into a THREE-slot ring that never drains between tiles (the loads run two K steps ahead of the math, across tile
-// boundaries); one s_barrier per K step, in the MIDDLE of the step's MFMA stream (the slot it publishes is the NEXT step's, the slot it
-// frees is filled behind it), the 12 DMA pieces of a step and the head fragments of the next are spread between the MFMA rows.
-// Every VMEM operation of the kernel is issued from inline asm and counted by hand (hipcc's own counter cannot see the DMA: any load it
-// knows about would wait for everything in flight): vmcnt(n) below always names how many YOUNGER operations may stay outstanding.
+// the grid); set C accumulates tile t while set D -- tile t - 1 -- is drained ONE FRAGMENT PER K STEP (two when the tile has fewer than 32
+// steps), a few instructions behind each group of four MFMAs: accumulator -> bias / folded LayerNorm / GELU / residual -> split -> the lanes
+// that hold the two halves of an 8-element group swap them (v_permlane16_swap) -> one 16-byte global store per lane. No LDS staging.
+// Operands arrive by global_load_lds DMA into a THREE-slot ring that never drains between tiles (the loads run two K steps ahead of the
+// math, across tile boundaries); one s_barrier per K step, in the MIDDLE of the step's MFMA stream (the slot it publishes is the NEXT
+// step's, the slot it frees is filled behind it), the 12 DMA pieces of a step and the head fragments of the next are spread between the
+// MFMA rows. Every VMEM operation of the kernel is issued from inline asm and counted by hand (hipcc's own counter cannot see the DMA: any
+// load it knows about would wait for everything in flight): vmcnt(n) below always names how many YOUNGER operations may stay outstanding.
 //
 // Arithmetic: per output element the same MFMA sequence as every gemm.hip tile (per 32 k: lo.hi, hi.lo, hi.hi; K ascending) and the same
-// epilogue expressions, so results are bit-identical to them (tests/test_kernels_gpu.py::test_persistent_gemm_*).
+// epilogue expressions and summation trees, so results are bit-identical to them (tests/test_kernels_gpu.py::test_persistent_gemm_*).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -31,22 +32,29 @@ namespace p4 {
 
 constexpr int BM = 256, BN = 128, NW = 4, NT = 256, FI = 8, FJ = 4, KTB = 128, NST = 3;
 constexpr int A_BYTES = BM * KTB, W_BYTES = BN * KTB, STAGE = A_BYTES + W_BYTES;   // 32 KiB + 16 KiB per ring slot
-constexpr int STG0 = NST * STAGE, STG_W = 16 * 128;          // drain staging: 16 rows x 128 bytes per wave (XOR-swizzled 16-byte slots)
-constexpr int SIDE0 = STG0 + NW * STG_W, SIDE_W = 1536;      // per wave: bias[128] | colsum[128] | rstd[64] | nmr[64]  (fp32)
+constexpr int SIDE0 = NST * STAGE, SIDE_W = 1536;            // per wave: bias[128] | colsum[128] | rstd[64] | nmr[64]  (fp32)
 constexpr int DUMMY0 = SIDE0 + NW * SIDE_W;                  // 256 bytes per wave: where the DMA of an operand the launch does not have lands
-constexpr int LDS = DUMMY0 + NW * 256;                       // 162 816 of the CU's 163 840 bytes
-constexpr int DS = 16;                                       // drain micro-slices = K steps that carry one
+constexpr int RBUF0 = DUMMY0 + NW * 256;                     // residual rows: 1 KiB (64 lanes x 16 bytes) per wave and drain lane, filled by DMA
+constexpr int LDS = RBUF0 + NW * 2 * 1024;                   // 162 816 of the CU's 163 840 bytes
+constexpr int NFRAG = FI * FJ;                               // 32 fragments per wave tile
 static_assert(LDS <= 160 * 1024, "one block owns the CU's LDS");
 
-enum { EPK_TYPED = 0, EPK_GELU = 1, EPK_X3RES = 2, EPK_X3RES_LN = 3, EPK_NONE = 4 };   // _LN: the launch also writes the row partial sums of a folded LayerNorm; NONE: probe builds (GF_NOSTORE), the K loops alone
+// epilogue kinds; _LN: the launch also writes the row partial sums of a folded LayerNorm; NONE: probe builds (GF_NOSTORE), the K loops alone
+enum { EPK_TYPED = 0, EPK_GELU = 1, EPK_X3RES = 2, EPK_X3RES_LN = 3, EPK_NONE = 4 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <int V> using IC = std::integral_constant<int, V>;
+template <bool V> using BC = std::integral_constant<bool, V>;
 
 // 4-byte LDS-DMA: lane l's dword lands at lds_dst + 4 l
 D3R_DEV void glds4(const void* gsrc, uint32_t lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
-// 16-byte store, wave-uniform 64-bit base + per-lane 32-bit byte offset; NT: non-temporal policy
+// LDS-DMA piece: source = wave-uniform 64-bit base + this lane's 32-bit offset; destination = slot base (SGPR) + a compile-time offset, formed in M0
+template <int IMM> D3R_DEV void glds16_imm(const void* sbase, uint32_t voff, uint32_t lds_slot) {
+    asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_slot), "n"(IMM) : "memory", "m0", "scc");     // s_add writes SCC
+}
+// 16-byte store, wave-uniform 64-bit base + per-lane 32-bit byte offset; NTP: non-temporal policy
 template <bool NTP> D3R_DEV void gst16(void* sbase, uint32_t voff, const u32x4_t v) {
     if constexpr (NTP) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
@@ -54,19 +62,21 @@ template <bool NTP> D3R_DEV void gst16(void* sbase, uint32_t voff, const u32x4_t
 D3R_DEV void gst8(void* sbase, uint32_t voff, const float2 v) {
     asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
-// 16-byte load into registers, invisible to hipcc's vmcnt bookkeeping: the caller waits (counted) before the first use and passes the
-// value through use_after_wait() so that no consumer is scheduled above the wait
+// 16-byte load into registers, invisible to hipcc's vmcnt bookkeeping: the caller waits (counted) before the first use and pins the value behind the wait.
+// (A request whose value is never used must not exist: its destination is dead to the compiler while the data is still in flight.)
 D3R_DEV u32x4_t gld16(const void* sbase, uint32_t voff) {
     u32x4_t v;
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
     return v;
 }
-// LDS-DMA piece: source = wave-uniform 64-bit base + this lane's 32-bit offset; destination = slot base (SGPR) + a compile-time offset, formed in M0
-template <int IMM> D3R_DEV void glds16_imm(const void* sbase, uint32_t voff, uint32_t lds_slot) {
-    asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_slot), "n"(IMM) : "memory", "m0", "scc");     // s_add writes SCC
-}
 template <int N> D3R_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 D3R_DEV void pin(u32x4_t& v) { asm volatile("" : "+v"(v)); }
+// rows {1, 3} (16-lane groups) of a  <->  rows {0, 2} of b   (wait states around the swap inside the statement: hipcc does not pad asm)
+D3R_DEV void swap16(uint32_t& a, uint32_t& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+D3R_DEV void swap32(uint32_t& a, uint32_t& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+// x[l] + x[l ^ 16], x[l] + x[l ^ 32]: both lanes of a pair get the same sum
+D3R_DEV float add_xor16(float x) { uint32_t a = __float_as_uint(x), b = a; swap16(a, b); return __uint_as_float(a) + __uint_as_float(b); }
+D3R_DEV float add_xor32(float x) { uint32_t a = __float_as_uint(x), b = a; swap32(a, b); return __uint_as_float(a) + __uint_as_float(b); }
 
 D3R_DEV void tile_origin(int v, int ntiles, int tiles_m, int tiles_n, int panel_w, int& m0, int& n0) {
     const int lid = xcd_remap(v, ntiles);
@@ -78,32 +88,50 @@ D3R_DEV void tile_origin(int v, int ntiles, int tiles_m, int tiles_n, int panel_
     n0 = tn * BN;
 }
 
-D3R_DEV int key2(int row) { return (row ^ (row >> 3)) & 7; }      // staging rows 0..15: rows r, r + 8 and the 8 rows of a pass all differ
+// compile-time loop: fn(IC<A>), ..., fn(IC<B>)
+template <int A, int B, class Fn> D3R_DEV void for_pairs(Fn&& fn) {
+    fn(IC<A>());
+    if constexpr (A < B) for_pairs<A + 1, B>(fn);
+}
 
-template <int EPK>
+// stores / residual requests of a K step that drains DR (0 nothing, 1 one fragment: A half, 2 one fragment: B half, 3 two fragments: A, B)
+constexpr int nst_of(int dr, bool lnp) { return dr == 0 ? 0 : dr == 3 ? 2 + (lnp ? 1 : 0) : 1 + (lnp && dr == 2 ? 1 : 0); }
+
+// NF: fragments of the drain set per K step (1: K >= 1024, every one of a tile's first 32 steps carries one; 2: 16 steps carry two)
+// L32 (NF == 1 only): a tile has exactly 32 K steps, so its last step also carries the previous tile's last fragment
+template <int EPK, int NF, bool L32, int DBG = 0>      // DBG: probe instances (results invalid): 1 no stores, 2 no lane swaps, 4 stores early in the step, 5 plain instead of non-temporal stores, 6 the row-2 wait does not wait
 __global__ __launch_bounds__(NT, 1) void gemm_p4_kernel(GemmParams p, int tiles_m, int tiles_n, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TX = Traits<D3R_F16X3>;
-    typedef std::integral_constant<bool, true> T_;
-    typedef std::integral_constant<bool, false> F_;
+    typedef BC<true> T_;
+    typedef BC<false> F_;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = p.K >> 5;
     const int G = gridDim.x;
     constexpr bool X3R = EPK == EPK_X3RES || EPK == EPK_X3RES_LN;     // typed residual stream epilogue (GF_X3RES)
     constexpr bool LNP = EPK == EPK_X3RES_LN;
+    constexpr bool DRAINS = EPK != EPK_NONE;
+    constexpr int NREQ = X3R ? NF : 0;                                 // residual-row requests of a draining K step
 
-    // ---- DMA: one 32-bit offset per operand, the 32-row pass stride added to the wave-uniform tile base (SGPRs) --------------------------
-    const int lrow = wave * 8 + (lane >> 3);
-    const int lslot = (lane & 7) ^ ((lrow >> 1) & 7);
-    const int lchunk = (lslot & 3) * 2 + (lslot >> 2);            // LDS image [hi0..hi3 | lo0..lo3] of the memory row's [hi x8][lo x8] groups
-    // per-lane byte offsets of the 8 activation and 4 weight passes of a K step (32 rows apart): every piece then takes the SAME wave-uniform base
+    // ---- DMA: per-lane byte offsets of the 8 activation and 4 weight passes of a K step (32 rows apart); every piece takes the SAME wave-uniform base ----
+    // Weight rows (read by all four waves): pass q covers rows 32 q + 8 wave + lane / 8. Activation rows are read by ONE wave each (rows 64 wave .. + 63 of
+    // the tile): that wave stages them itself, pass q = rows 64 wave + 8 q + lane / 8 -- nobody else has to wait for them (see the K step).
     uint32_t a_off[8], w_off[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) a_off[q] = (uint32_t)(((size_t)(q * 32 + lrow) * p.lda) * 4 + lchunk * 16);
+    for (int q = 0; q < 4; ++q) {
+        const int row = q * 32 + wave * 8 + (lane >> 3);
+        const int ls = (lane & 7) ^ ((row >> 1) & 7);             // LDS slot = chunk ^ key(row), key = (row >> 1) & 7: the fragment reads' swizzle
+        w_off[q] = (uint32_t)(((size_t)row * p.K) * 4 + ((ls & 3) * 2 + (ls >> 2)) * 16);      // LDS image [hi0..hi3 | lo0..lo3] of the memory row's [hi x8][lo x8] groups
+    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) w_off[q] = (uint32_t)(((size_t)(q * 32 + lrow) * p.K) * 4 + lchunk * 16);
-    const uint32_t lds0 = lds_addr(smem) + (uint32_t)wave * 1024;
+    for (int q = 0; q < 8; ++q) {
+        const int row = wave * 64 + q * 8 + (lane >> 3);
+        const int ls = (lane & 7) ^ ((row >> 1) & 7);
+        a_off[q] = (uint32_t)(((size_t)row * p.lda) * 4 + ((ls & 3) * 2 + (ls >> 2)) * 16);
+    }
+    const uint32_t lds0 = lds_addr(smem);
+    const uint32_t a_dst = (uint32_t)wave * 8192, w_dst = A_BYTES + (uint32_t)wave * 1024;        // of piece 0, inside a ring slot
     // The load cursor runs two K steps ahead of the math and never stops: behind this block's last tile it wraps to its first one (two steps of
     // loads nobody reads) so that every step issues exactly 12 pieces -- no branch in the MFMA stream, and the vmcnt arithmetic below is exact.
     int ld_v = blockIdx.x, ld_kt = 0;
@@ -116,11 +144,11 @@ __global__ __launch_bounds__(NT, 1) void gemm_p4_kernel(GemmParams p, int tiles_
         ld_a = reinterpret_cast<const char*>(p.act) + (size_t)m0 * p.lda * 4;
         ld_w = reinterpret_cast<const char*>(p.wgt) + (size_t)n0 * p.K * 4;
     };
-    // piece IDX (0..11) of the load cursor's K step: 8 activation passes, 4 weight passes
+    // piece 0..11 of the cursor's K step: the 4 weight passes FIRST (vmcnt completes in order: the barrier's wait for them leaves the 8 activation passes in flight)
     auto dma_piece = [&](auto idx_tag) __attribute__((always_inline)) {
         constexpr int IDX = decltype(idx_tag)::value;
-        if constexpr (IDX < 8) glds16_imm<IDX * 4096>(ld_a, a_off[IDX], ld_sb);
-        else glds16_imm<A_BYTES + (IDX - 8) * 4096>(ld_w, w_off[IDX - 8], ld_sb);
+        if constexpr (IDX < 4) glds16_imm<IDX * 4096>(ld_w, w_off[IDX], ld_sb + w_dst);
+        else glds16_imm<(IDX - 4) * 1024>(ld_a, a_off[IDX - 4], ld_sb + a_dst);
     };
     auto dma_advance = [&]() __attribute__((always_inline)) {
         ld_a += KTB;
@@ -142,9 +170,9 @@ __global__ __launch_bounds__(NT, 1) void gemm_p4_kernel(GemmParams p, int tiles_
     auto frag = [&](int slot, int off) __attribute__((always_inline)) { return *reinterpret_cast<const uint4*>(smem + slot * STAGE + off); };
 
     // ---- drain: constants and state -----------------------------------------------------------------------------------------------------------
-    const int i4 = (lane >> 4) * 4, jl = lane & 15;
-    const int rrow = lane >> 3, rch = lane & 7;
-    char* const stg = smem + STG0 + wave * STG_W;
+    const int i4 = (lane >> 4) * 4, jl = lane & 15;               // accumulator fragment: this lane holds columns i4..i4+3 of row jl
+    // a lane's 16 bytes of a stored row: 8-group (lane >> 5) of the fragment's 16 columns, hi half (lanes with (lane >> 4) even) or lo half (odd)
+    const uint32_t half_off = (uint32_t)((lane >> 5) * 32 + ((lane >> 4) & 1) * 16);
     float* const side = reinterpret_cast<float*>(smem + SIDE0 + wave * SIDE_W);
     const bool has_ln = p.ln_rstd != nullptr, has_bias = p.bias != nullptr;
     const float* const bsrc = p.bias ? p.bias : reinterpret_cast<const float*>(p.wgt);
@@ -152,192 +180,151 @@ __global__ __launch_bounds__(NT, 1) void gemm_p4_kernel(GemmParams p, int tiles_
     const float* const lnn = has_ln ? p.ln_nmr : bsrc;
     const float* const lns = has_ln ? p.ln_colsum : bsrc;
     const bool has_res = p.res1 != nullptr;
+    const char* const rsrc = reinterpret_cast<const char*>(has_res ? p.res1 : (const void*)p.out2);
+    const int rld = has_res ? p.ldr : p.ldo2;
+    const int old_ = X3R ? p.ldo2 : p.ldo;                        // row stride (elements) of the stored rows
+    char* const obase0 = reinterpret_cast<char*>(X3R ? p.out2 : p.out);
+    const uint32_t o_voff = (uint32_t)((size_t)jl * old_ * 4) + half_off, r_voff = (uint32_t)((size_t)jl * rld * 4) + half_off;
+    const uint32_t part_voff = (uint32_t)((size_t)jl * (p.n_store >> 5) * 8);
     int dm0 = 0, dn0 = 0;                                          // origin of the tile held by the drain set
+    int cm0 = 0, cn0 = 0;                                          // origin of the tile being accumulated
     // Side buffer of this wave: bias[128] | colsum[128] | rstd[64] | nmr[64]. An operand the launch does not have keeps the NEUTRAL value written
     // here once (bias 0; no folded LayerNorm: colsum 0, rstd 1, nmr 0 -- fma(acc, 1, fma(0, 0, b)) = acc + b bit for bit, as in gemm.hip) and its
     // DMA is pointed at a dummy area instead: the same six instructions every tile, no branch, no select in the drain.
     const uint32_t sd = lds_addr(side), dummy = lds_addr(smem) + DUMMY0 + (uint32_t)wave * 256;
     side[lane] = 0.f; side[64 + lane] = 0.f; side[128 + lane] = 0.f; side[192 + lane] = 0.f; side[256 + lane] = 1.f; side[320 + lane] = 0.f;
-    auto side_loads = [&]() __attribute__((always_inline)) {
-        glds4(bsrc + dn0 + lane, has_bias ? sd : dummy);
-        glds4(bsrc + dn0 + 64 + lane, has_bias ? sd + 256 : dummy);
-        glds4(lns + (has_ln ? dn0 : 0) + lane, has_ln ? sd + 512 : dummy);
-        glds4(lns + (has_ln ? dn0 + 64 : 0) + lane, has_ln ? sd + 768 : dummy);
-        glds4(lnr + (has_ln ? dm0 + wave * 64 : 0) + lane, has_ln ? sd + 1024 : dummy);
-        glds4(lnn + (has_ln ? dm0 + wave * 64 : 0) + lane, has_ln ? sd + 1280 : dummy);
+    auto side_loads = [&](int tm0, int tn0) __attribute__((always_inline)) {
+        glds4(bsrc + tn0 + lane, has_bias ? sd : dummy);
+        glds4(bsrc + tn0 + 64 + lane, has_bias ? sd + 256 : dummy);
+        glds4(lns + (has_ln ? tn0 : 0) + lane, has_ln ? sd + 512 : dummy);
+        glds4(lns + (has_ln ? tn0 + 64 : 0) + lane, has_ln ? sd + 768 : dummy);
+        glds4(lnr + (has_ln ? tm0 + wave * 64 : 0) + lane, has_ln ? sd + 1024 : dummy);
+        glds4(lnn + (has_ln ? tm0 + wave * 64 : 0) + lane, has_ln ? sd + 1280 : dummy);
     };
 
     f32x4_t acc[FI][FJ], dacc[FI][FJ];
     uint4 qh[FJ], ql[FJ];            // activation fragments of the current K step (reloaded in place behind their last MFMA)
     uint4 ph, pl;                    // weight fragment of the next MFMA row
 
-    // Drain step D (0..15) = micro-slice D of the drain set: fragment columns fi = 2 g, 2 g + 1 (32 columns), fragment row fj (16 rows), g = D >> 2,
-    // fj = D & 3. Its work is cut into the 24 SLOTS of a K step (one behind each group of four MFMAs), a handful of instructions each, so that the
-    // matrix pipe never waits for a block of VALU work (hipcc left alone emits one 70-instruction block per fragment):
-    //   typed / GELU:  fragment fl at slots 11 fl + 0..10: operands | folded-LayerNorm fmas | GELU in 8 pieces (scalar fp32: packed VALU beside MFMAs
-    //                  is an anti-lever, MI355X_MICROARCH.md) | split + staging writes;   slot 22: read the two row passes back;  slot 23: two 16-byte stores
-    //   typed residual stream: slot 0 / 1: fragment + bias -> staging (fp32);  row pass ps at slots 2 + 10 ps + 0..9: read back | residual halves swapped
-    //                  | joins | add | splits | swap back | sums | DPP tree;  stores at slots 18, 19 (pass 0) and 22, 23 (pass 1): behind the last DMA piece
-    constexpr int NSTORE = X3R ? (LNP ? 4 : 2) : 2;                // VMEM stores of a drain step, all younger than its last DMA piece
-    constexpr int NHEAD = X3R ? 2 : 0;                             // residual-row requests at the top of a drain step (for the NEXT step)
-    u32x4_t rr[2][2];                                              // X3R: residual rows [step parity][pass]
-    auto rr_request = [&](auto d_tag) __attribute__((always_inline)) {      // the residual rows drain step D will add (issued one step ahead)
-        constexpr int D = decltype(d_tag)::value;
-        if constexpr (X3R && D >= 0 && D < DS) {
-            constexpr int g = D >> 2, fj = D & 3;
-            const char* rsrc = reinterpret_cast<const char*>(has_res ? p.res1 : (const void*)p.out2);
-            const int rld = has_res ? p.ldr : p.ldo2;
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                const char* base = rsrc + TX::boff((size_t)(dm0 + wave * 64 + fj * 16 + ps * 8) * rld + dn0 + g * 32);
-                rr[D & 1][ps] = gld16(base, (uint32_t)(TX::boff((size_t)rrow * rld + (rch >> 1) * 8) + (rch & 1) * 16));
-            }
+    // Fragment f (0..31) of the drain set: fragment column fi = 2 (f >> 3) + (f & 1), fragment row fj = (f >> 1) & 3 -- the two 16-column halves
+    // of a 32-column group of a row are consecutive (their LayerNorm partial sums are added: A half, then B half, the last level of gemm.hip's tree).
+    // The accumulator array is indexed statically only (a dynamic index moves it to scratch; a run-time switch over the 32 fragments compiles to a tree of ten
+    // scalar branches per pick, measured -10 %): the drain steps are unrolled, the fragment index is a compile-time constant.
+    // The work on one fragment is cut into 12 PIECES, a handful of instructions each; piece k of drain lane L (0: the step's first fragment, 1: its
+    // second, NF == 2) sits in slot 2 k + L of the K step's 24 slots (one behind each group of four MFMAs), so the matrix pipe never waits for a block
+    // of VALU work (hipcc left alone emits one 70-instruction block per fragment). Stores sit in pieces >= 9 = slots >= 18: behind the step's last
+    // DMA piece (slot 17), so that the next step's wait for that DMA never waits for a store.
+    //   typed / GELU:            0 operands | 1 folded-LayerNorm fmas | 2..9 GELU (scalar fp32: packed VALU beside MFMAs is an anti-lever, MI355X_MICROARCH.md)
+    //                            | 10 split | 11 halves swapped, 16-byte store
+    //   typed residual stream:   0 acc + bias, residual row arrives | 1 its halves swapped, next request | 2, 3 joins | 4 add | 5, 6 splits | 7 halves swapped
+    //                            | 8 quad sums | 9 store, 16-column sums | 10 (B half) A + B | 11 (B half) 8-byte store of the pair
+    // X3R: the residual row of each drain lane's next fragment arrives by DMA in this wave's LDS (a load into registers issued from asm is written, for
+    // the compiler, when it is issued: any copy it makes of the destination before the data lands -- a loop-carried move is enough -- reads garbage)
+    const uint32_t rbuf_lds = lds_addr(smem) + RBUF0 + (uint32_t)wave * 2048;
+    const char* const rbuf = smem + RBUF0 + wave * 2048 + lane * 16;
+    float fv[2][4], gz[2][4], gt[2][4], gp[2][4], ge[2][4];        // fragment values; GELU: |z|, t, polynomial, exponent / half
+    float4 sB[2], sX[2]; float sR[2], sN[2];                       // side operands
+    uint32_t hx[2], hy[2], lx[2], ly[2];                           // hi / lo halves (residual in, result out)
+    float xj[2][4], xsm[2], xsq[2], xsmA = 0.f, xsqA = 0.f;
+    u32x4_t xsv[2];
+    auto rr_request = [&](auto f_tag, int tm0, int tn0, auto l_tag) __attribute__((always_inline)) {      // the residual row of fragment f of the tile at (tm0, tn0)
+        constexpr int L = decltype(l_tag)::value, f = decltype(f_tag)::value;
+        if constexpr (X3R && f < NFRAG) {
+            constexpr int fi = 2 * (f >> 3) + (f & 1), fj = (f >> 1) & 3;
+            glds16_so(rsrc + ((size_t)(tm0 + wave * 64 + fj * 16) * rld + tn0 + fi * 16) * 4, r_voff, rbuf_lds + L * 1024);
         }
     };
-    // state that lives across the slots of a step
-    float fv0, fv1, fv2, fv3;                                      // fragment values in flight
-    float gz0, gz1, gz2, gz3, gt0, gt1, gt2, gt3, gp0, gp1, gp2, gp3, ge0, ge1, ge2, ge3;     // GELU: |z|, t, polynomial, exponent / half
-    float4 sB, sX; float sR, sN;                                   // side operands of the fragment
-    uint4 rv0, rv1;                                                // typed: the two row passes read back
-    float4 xv; uint32_t xhx, xhy, xlx, xly; float xj0, xj1, xj2, xj3; uint2 xh, xl; u32x4_t xsv, xsv0; float xsm, xsq, xsm0, xsq0;
-    auto swap_pair = [](uint32_t x) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); };   // lane ^ 1
-    auto dpp_add = [](float x, auto ctl) __attribute__((always_inline)) { return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctl)::value, 0xF, 0xF, false)); };
-    auto drain_slot = [&](auto d_tag, auto slot_tag, auto tail_tag) __attribute__((always_inline)) {
-        constexpr int D = decltype(d_tag)::value, SL = decltype(slot_tag)::value;
-        constexpr bool TAIL = decltype(tail_tag)::value;             // the block's last tile: no K loop (no DMA pieces) around the slots
-        constexpr int g = D >> 2, fj = D & 3;
+    // ISB: the fragment is the B half of its 32-column group (f odd).  RWAIT: VMEM operations issued since this fragment's residual request.
+    // REQ: piece 1 requests the residual row of this drain lane's next fragment.
+    auto drain_piece = [&](auto f_tag, auto l_tag, auto k_tag, auto isb_tag, auto rwait_tag, auto req_tag) __attribute__((always_inline)) {
+        constexpr int L = decltype(l_tag)::value, k = decltype(k_tag)::value, RWAIT = decltype(rwait_tag)::value, f = decltype(f_tag)::value;
+        constexpr bool ISB = decltype(isb_tag)::value, REQ = decltype(req_tag)::value;
+        constexpr int fi = 2 * (f >> 3) + (f & 1), fj = (f >> 1) & 3;
         if constexpr (!X3R) {
-            constexpr int fl = SL >= 11 ? 1 : 0, k = SL - 11 * fl;      // fragment and stage (SL 22, 23: the row passes)
-            constexpr int fi = 2 * g + fl;
-            if constexpr (SL < 22) {
-                if constexpr (k == 0) {
-                    const f32x4_t a = dacc[fi][fj];
-                    fv0 = a[0]; fv1 = a[1]; fv2 = a[2]; fv3 = a[3];
-                    sB = *reinterpret_cast<const float4*>(side + g * 32 + fl * 16 + i4);
-                    sX = *reinterpret_cast<const float4*>(side + 128 + g * 32 + fl * 16 + i4);
-                    sR = side[256 + fj * 16 + jl];
-                    sN = side[320 + fj * 16 + jl];
-                } else if constexpr (k == 1) {      // fma(acc, R_j, fma(S_i, Nm_j, bias_i)): the expression of gemm.hip's wide split-fp16 epilogue
-                    fv0 = __builtin_fmaf(fv0, sR, __builtin_fmaf(sX.x, sN, sB.x)); fv1 = __builtin_fmaf(fv1, sR, __builtin_fmaf(sX.y, sN, sB.y));
-                    fv2 = __builtin_fmaf(fv2, sR, __builtin_fmaf(sX.z, sN, sB.z)); fv3 = __builtin_fmaf(fv3, sR, __builtin_fmaf(sX.w, sN, sB.w));
-                } else if constexpr (k < 10) {
-                    if constexpr (EPK == EPK_GELU) {
-                        // gelu_pk (common.hpp) element by element, same operations in the same order: x/2 + |x|/2 erf(|z|), z = x / sqrt 2,
-                        // erf(|z|) = 1 - poly(t) exp(-z^2), t = 1 / (1 + p |z|)   (Abramowitz-Stegun 7.1.26)
-                        constexpr float K0 = 0.70710678118654752440f, KL = -1.44269504088896340736f;
-                        if constexpr (k == 2) {
-                            gz0 = fabsf(fv0 * K0); gz1 = fabsf(fv1 * K0); gz2 = fabsf(fv2 * K0); gz3 = fabsf(fv3 * K0);
-                            gt0 = __builtin_fmaf(gz0, 0.3275911f, 1.0f); gt1 = __builtin_fmaf(gz1, 0.3275911f, 1.0f);
-                            gt2 = __builtin_fmaf(gz2, 0.3275911f, 1.0f); gt3 = __builtin_fmaf(gz3, 0.3275911f, 1.0f);
-                        } else if constexpr (k == 3) {
-                            gt0 = __builtin_amdgcn_rcpf(gt0); gt1 = __builtin_amdgcn_rcpf(gt1); gt2 = __builtin_amdgcn_rcpf(gt2); gt3 = __builtin_amdgcn_rcpf(gt3);
-                        } else if constexpr (k == 4) {
-                            gp0 = __builtin_fmaf(gt0, 1.061405429f, -1.453152027f); gp1 = __builtin_fmaf(gt1, 1.061405429f, -1.453152027f);
-                            gp2 = __builtin_fmaf(gt2, 1.061405429f, -1.453152027f); gp3 = __builtin_fmaf(gt3, 1.061405429f, -1.453152027f);
-                            gp0 = __builtin_fmaf(gp0, gt0, 1.421413741f); gp1 = __builtin_fmaf(gp1, gt1, 1.421413741f);
-                            gp2 = __builtin_fmaf(gp2, gt2, 1.421413741f); gp3 = __builtin_fmaf(gp3, gt3, 1.421413741f);
-                        } else if constexpr (k == 5) {
-                            gp0 = __builtin_fmaf(gp0, gt0, -0.284496736f); gp1 = __builtin_fmaf(gp1, gt1, -0.284496736f);
-                            gp2 = __builtin_fmaf(gp2, gt2, -0.284496736f); gp3 = __builtin_fmaf(gp3, gt3, -0.284496736f);
-                            gp0 = __builtin_fmaf(gp0, gt0, 0.254829592f); gp1 = __builtin_fmaf(gp1, gt1, 0.254829592f);
-                            gp2 = __builtin_fmaf(gp2, gt2, 0.254829592f); gp3 = __builtin_fmaf(gp3, gt3, 0.254829592f);
-                        } else if constexpr (k == 6) {
-                            gp0 = gp0 * gt0; gp1 = gp1 * gt1; gp2 = gp2 * gt2; gp3 = gp3 * gt3;
-                            ge0 = (gz0 * KL) * gz0; ge1 = (gz1 * KL) * gz1; ge2 = (gz2 * KL) * gz2; ge3 = (gz3 * KL) * gz3;
-                        } else if constexpr (k == 7) {
-                            ge0 = __builtin_amdgcn_exp2f(ge0); ge1 = __builtin_amdgcn_exp2f(ge1); ge2 = __builtin_amdgcn_exp2f(ge2); ge3 = __builtin_amdgcn_exp2f(ge3);
-                        } else if constexpr (k == 8) {
-                            gp0 = __builtin_fmaf(-gp0, ge0, 1.0f); gp1 = __builtin_fmaf(-gp1, ge1, 1.0f); gp2 = __builtin_fmaf(-gp2, ge2, 1.0f); gp3 = __builtin_fmaf(-gp3, ge3, 1.0f);
-                            ge0 = fv0 * 0.5f; ge1 = fv1 * 0.5f; ge2 = fv2 * 0.5f; ge3 = fv3 * 0.5f;
-                        } else {
-                            fv0 = __builtin_fmaf(gz0 * K0, gp0, ge0); fv1 = __builtin_fmaf(gz1 * K0, gp1, ge1);
-                            fv2 = __builtin_fmaf(gz2 * K0, gp2, ge2); fv3 = __builtin_fmaf(gz3 * K0, gp3, ge3);
-                        }
+            if constexpr (k == 0) {
+                const f32x4_t a = dacc[fi][fj];
+                fv[L][0] = a[0]; fv[L][1] = a[1]; fv[L][2] = a[2]; fv[L][3] = a[3];
+                sB[L] = *reinterpret_cast<const float4*>(side + fi * 16 + i4);
+                sX[L] = *reinterpret_cast<const float4*>(side + 128 + fi * 16 + i4);
+                sR[L] = side[256 + fj * 16 + jl];
+                sN[L] = side[320 + fj * 16 + jl];
+            } else if constexpr (k == 1) {      // fma(acc, R_j, fma(S_i, Nm_j, bias_i)): the expression of gemm.hip's wide split-fp16 epilogue
+                fv[L][0] = __builtin_fmaf(fv[L][0], sR[L], __builtin_fmaf(sX[L].x, sN[L], sB[L].x)); fv[L][1] = __builtin_fmaf(fv[L][1], sR[L], __builtin_fmaf(sX[L].y, sN[L], sB[L].y));
+                fv[L][2] = __builtin_fmaf(fv[L][2], sR[L], __builtin_fmaf(sX[L].z, sN[L], sB[L].z)); fv[L][3] = __builtin_fmaf(fv[L][3], sR[L], __builtin_fmaf(sX[L].w, sN[L], sB[L].w));
+            } else if constexpr (k < 10) {
+                if constexpr (EPK == EPK_GELU) {
+                    // gelu_pk (common.hpp) element by element, the same operations: x/2 + |x|/2 erf(|z|), z = x / sqrt 2,
+                    // erf(|z|) = 1 - poly(t) exp(-z^2), t = 1 / (1 + p |z|)   (Abramowitz-Stegun 7.1.26)
+                    constexpr float K0 = 0.70710678118654752440f, KL = -1.44269504088896340736f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (k == 2) { gz[L][e] = fabsf(fv[L][e] * K0); gt[L][e] = __builtin_fmaf(gz[L][e], 0.3275911f, 1.0f); }
+                        else if constexpr (k == 3) gt[L][e] = __builtin_amdgcn_rcpf(gt[L][e]);
+                        else if constexpr (k == 4) { gp[L][e] = __builtin_fmaf(gt[L][e], 1.061405429f, -1.453152027f); gp[L][e] = __builtin_fmaf(gp[L][e], gt[L][e], 1.421413741f); }
+                        else if constexpr (k == 5) { gp[L][e] = __builtin_fmaf(gp[L][e], gt[L][e], -0.284496736f); gp[L][e] = __builtin_fmaf(gp[L][e], gt[L][e], 0.254829592f); }
+                        else if constexpr (k == 6) { gp[L][e] = gp[L][e] * gt[L][e]; ge[L][e] = (gz[L][e] * KL) * gz[L][e]; }
+                        else if constexpr (k == 7) ge[L][e] = __builtin_amdgcn_exp2f(ge[L][e]);
+                        else if constexpr (k == 8) { gp[L][e] = __builtin_fmaf(-gp[L][e], ge[L][e], 1.0f); ge[L][e] = fv[L][e] * 0.5f; }
+                        else fv[L][e] = __builtin_fmaf(gz[L][e] * K0, gp[L][e], ge[L][e]);
                     }
-                } else {
-                    uint2 hh, ll;
-                    TX::split2(fv0, fv1, hh.x, ll.x);
-                    TX::split2(fv2, fv3, hh.y, ll.y);
-                    constexpr int c0b = fl * 16;                       // + i4: 4 consecutive logical columns inside one 8-group
-                    const int c0 = c0b + i4, shi = (c0 >> 3) * 2;
-                    char* w = stg + jl * 128 + (c0 & 7) * 2;
-                    *reinterpret_cast<uint2*>(w + ((shi ^ key2(jl)) * 16)) = hh;
-                    *reinterpret_cast<uint2*>(w + (((shi + 1) ^ key2(jl)) * 16)) = ll;
                 }
-            } else if constexpr (SL == 22) {
-                rv0 = *reinterpret_cast<const uint4*>(stg + rrow * 128 + ((rch ^ key2(rrow)) * 16));
-                rv1 = *reinterpret_cast<const uint4*>(stg + (8 + rrow) * 128 + ((rch ^ key2(8 + rrow)) * 16));
+            } else if constexpr (k == 10) {
+                TX::split2(fv[L][0], fv[L][1], hx[L], lx[L]);
+                TX::split2(fv[L][2], fv[L][3], hy[L], ly[L]);
             } else {
-                const int mrow = dm0 + wave * 64 + fj * 16;
-                char* ob0 = reinterpret_cast<char*>(p.out) + ((size_t)mrow * p.ldo + dn0 + g * 32) * 4;
-                char* ob1 = reinterpret_cast<char*>(p.out) + ((size_t)(mrow + 8) * p.ldo + dn0 + g * 32) * 4;
-                const uint32_t vo = (uint32_t)(((size_t)rrow * p.ldo + (rch >> 1) * 8) * 4 + (rch & 1) * 16);
-                gst16<true>(ob0, vo, (u32x4_t){rv0.x, rv0.y, rv0.z, rv0.w});
-                gst16<true>(ob1, vo, (u32x4_t){rv1.x, rv1.y, rv1.z, rv1.w});
+                // lanes l and l ^ 16 hold columns 0-3 / 4-7 of one 8-group of a row: the first keeps its hi words and takes the partner's hi words (16 hi bytes),
+                // the second takes the first's lo words and keeps its own (16 lo bytes): [hi x8][lo x8] = the row's 32 bytes, one 16-byte store per lane
+                if constexpr (DBG != 2) { swap16(hx[L], lx[L]); swap16(hy[L], ly[L]); }
+                char* ob = obase0 + ((size_t)(dm0 + wave * 64 + fj * 16) * old_ + dn0 + fi * 16) * 4;
+                if constexpr (DBG == 5) gst16<false>(ob, o_voff, (u32x4_t){hx[L], hy[L], lx[L], ly[L]});
+                else if constexpr (DBG != 1) gst16<true>(ob, o_voff, (u32x4_t){hx[L], hy[L], lx[L], ly[L]});
+                else asm volatile("" :: "v"(hx[L]), "v"(hy[L]), "v"(lx[L]), "v"(ly[L]), "s"(ob));
             }
         } else {
-            if constexpr (SL < 2) {
-                constexpr int fl = SL, fi = 2 * g + fl;
+            if constexpr (k == 0) {
                 const f32x4_t a = dacc[fi][fj];
-                const float4 q4 = *reinterpret_cast<const float4*>(side + g * 32 + fl * 16 + i4);
-                const int sl16 = fl * 4 + (lane >> 4);
-                *reinterpret_cast<float4*>(stg + jl * 128 + ((sl16 ^ key2(jl)) * 16)) = make_float4(a[0] + q4.x, a[1] + q4.y, a[2] + q4.z, a[3] + q4.w);
+                const float4 q4 = *reinterpret_cast<const float4*>(side + fi * 16 + i4);
+                fv[L][0] = a[0] + q4.x; fv[L][1] = a[1] + q4.y; fv[L][2] = a[2] + q4.z; fv[L][3] = a[3] + q4.w;
+                wait_vm<RWAIT>();               // this fragment's residual row has landed
+                const uint4 rv = *reinterpret_cast<const uint4*>(rbuf + L * 1024);
+                hx[L] = rv.x; hy[L] = rv.y; lx[L] = rv.z; ly[L] = rv.w;
+            } else if constexpr (k == 1) {
+                // the row's 16 bytes: the first lane of a pair holds hi0..7 (keeps hi0..3, hands over hi4..7), the second lo0..7 (keeps lo4..7, hands over lo0..3)
+                swap16(hx[L], lx[L]);
+                swap16(hy[L], ly[L]);
+                if constexpr (REQ) rr_request(IC<f + NF>(), dm0, dn0, l_tag);     // (the read of this buffer has returned: its words were just swapped)
+            } else if constexpr (k == 2) {
+                xj[L][0] = TX::join_lo(hx[L], lx[L]); xj[L][1] = TX::join_hi(hx[L], lx[L]);
+            } else if constexpr (k == 3) {
+                xj[L][2] = TX::join_lo(hy[L], ly[L]); xj[L][3] = TX::join_hi(hy[L], ly[L]);
+            } else if constexpr (k == 4) {
+                fv[L][0] += has_res ? xj[L][0] : 0.f; fv[L][1] += has_res ? xj[L][1] : 0.f; fv[L][2] += has_res ? xj[L][2] : 0.f; fv[L][3] += has_res ? xj[L][3] : 0.f;
+            } else if constexpr (k == 5) {
+                TX::split2(fv[L][0], fv[L][1], hx[L], lx[L]);
+            } else if constexpr (k == 6) {
+                TX::split2(fv[L][2], fv[L][3], hy[L], ly[L]);
+            } else if constexpr (k == 7) {
+                swap16(hx[L], lx[L]);
+                swap16(hy[L], ly[L]);
+                xsv[L] = (u32x4_t){hx[L], hy[L], lx[L], ly[L]};
+            } else if constexpr (k == 8) {
+                if constexpr (LNP) ln_quad_sums(make_float4(fv[L][0], fv[L][1], fv[L][2], fv[L][3]), xsm[L], xsq[L]);
+            } else if constexpr (k == 9) {
+                char* ob = obase0 + ((size_t)(dm0 + wave * 64 + fj * 16) * old_ + dn0 + fi * 16) * 4;
+                gst16<false>(ob, o_voff, xsv[L]);
+                if constexpr (LNP) {    // gemm.hip's fixed tree over the 8 column quads of a row's 32-column group: (q0 + q1) + (q2 + q3) here, A + B below
+                    xsm[L] = add_xor16(xsm[L]); xsq[L] = add_xor16(xsq[L]);
+                    xsm[L] = add_xor32(xsm[L]); xsq[L] = add_xor32(xsq[L]);
+                }
+            } else if constexpr (k == 10) {
+                if constexpr (LNP) {
+                    if constexpr (!ISB) { xsmA = xsm[L]; xsqA = xsq[L]; }
+                    else { xsm[L] = xsmA + xsm[L]; xsq[L] = xsqA + xsq[L]; }
+                }
             } else {
-                constexpr int ps = SL >= 12 ? 1 : 0, r = SL - 2 - 10 * ps;     // row pass and piece (pieces 0..9 at slots 2 + 10 ps + r)
-                const bool odd = rch & 1;
-                if constexpr (SL <= 21) {
-                    if constexpr (r == 0) {
-                        const int row = ps * 8 + rrow;
-                        xv = *reinterpret_cast<const float4*>(stg + row * 128 + ((rch ^ key2(row)) * 16));
-                        if constexpr (ps == 0) {
-                            // the residual rows of this step, requested one drain step ago: younger = the rest of that step (12 DMA pieces, its stores) and
-                            // this step's own requests
-                            wait_vm<(TAIL && D >= 1 ? 0 : 12) + (D >= 1 ? NSTORE : 0) + (D + 1 < DS ? NHEAD : 0)>();
-                            pin(rr[D & 1][0]); pin(rr[D & 1][1]);
-                        }
-                    } else if constexpr (r == 1) {
-                        // even lane holds hi0..7 (keeps hi0..3, hands over hi4..7), odd lane lo0..7 (keeps lo4..7, hands over lo0..3)
-                        const u32x4_t raw = rr[D & 1][ps];
-                        const uint32_t t0 = swap_pair(odd ? raw[0] : raw[2]), t1 = swap_pair(odd ? raw[1] : raw[3]);
-                        xhx = odd ? t0 : raw[0]; xhy = odd ? t1 : raw[1]; xlx = odd ? raw[2] : t0; xly = odd ? raw[3] : t1;
-                    } else if constexpr (r == 2) {
-                        xj0 = TX::join_lo(xhx, xlx); xj1 = TX::join_hi(xhx, xlx);
-                    } else if constexpr (r == 3) {
-                        xj2 = TX::join_lo(xhy, xly); xj3 = TX::join_hi(xhy, xly);
-                    } else if constexpr (r == 4) {
-                        xv.x += has_res ? xj0 : 0.f; xv.y += has_res ? xj1 : 0.f; xv.z += has_res ? xj2 : 0.f; xv.w += has_res ? xj3 : 0.f;
-                    } else if constexpr (r == 5) {
-                        TX::split2(xv.x, xv.y, xh.x, xl.x);
-                    } else if constexpr (r == 6) {
-                        TX::split2(xv.z, xv.w, xh.y, xl.y);
-                    } else if constexpr (r == 7) {
-                        const uint32_t u0 = swap_pair(odd ? xh.x : xl.x), u1 = swap_pair(odd ? xh.y : xl.y);
-                        xsv = odd ? (u32x4_t){u0, u1, xl.x, xl.y} : (u32x4_t){xh.x, xh.y, u0, u1};
-                        if constexpr (ps == 0) xsv0 = xsv;
-                    } else if constexpr (r == 8) {
-                        if constexpr (LNP) ln_quad_sums(xv, xsm, xsq);
-                    } else {
-                        if constexpr (LNP) {
-                            // the 8 lanes of a row: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror -- the one fixed tree of every tile shape
-                            xsm = dpp_add(xsm, std::integral_constant<int, 0xB1>()); xsq = dpp_add(xsq, std::integral_constant<int, 0xB1>());
-                            xsm = dpp_add(xsm, std::integral_constant<int, 0x4E>()); xsq = dpp_add(xsq, std::integral_constant<int, 0x4E>());
-                            xsm = dpp_add(xsm, std::integral_constant<int, 0x141>()); xsq = dpp_add(xsq, std::integral_constant<int, 0x141>());
-                            if constexpr (ps == 0) { xsm0 = xsm; xsq0 = xsq; }
-                        }
-                    }
-                }
-                // stores: behind the step's last DMA piece (slot 17)
-                if constexpr (SL == 18 || SL == 22) {
-                    constexpr int sp = SL == 18 ? 0 : 1;
-                    const int mrow = dm0 + wave * 64 + fj * 16 + sp * 8;
-                    char* obase = reinterpret_cast<char*>(p.out2) + TX::boff((size_t)mrow * p.ldo2 + dn0 + g * 32);
-                    gst16<false>(obase, (uint32_t)(TX::boff((size_t)rrow * p.ldo2 + (rch >> 1) * 8) + (odd ? 16 : 0)), sp == 0 ? xsv0 : xsv);
-                }
-                if constexpr (LNP && (SL == 19 || SL == 23)) {
-                    constexpr int sp = SL == 19 ? 0 : 1;
-                    const int mrow = dm0 + wave * 64 + fj * 16 + sp * 8;
-                    float* pbase = p.ln_part + ((size_t)mrow * (p.n_store >> 5) + ((dn0 >> 5) + g)) * 2;
-                    if (rch == 0) gst8(pbase, (uint32_t)((size_t)rrow * (p.n_store >> 5) * 8), sp == 0 ? make_float2(xsm0, xsq0) : make_float2(xsm, xsq));
+                if constexpr (LNP && ISB) {
+                    float* pb = p.ln_part + ((size_t)(dm0 + wave * 64 + fj * 16) * (p.n_store >> 5) + ((dn0 >> 5) + (fi >> 1))) * 2;
+                    if (lane < 16) gst8(pb, part_voff, make_float2(xsm[L], xsq[L]));
                 }
             }
         }
@@ -345,35 +332,55 @@ __global__ __launch_bounds__(NT, 1) void gemm_p4_kernel(GemmParams p, int tiles_
 
     // ---- one K step --------------------------------------------------------------------------------------------------------------------------
     int slot = 0;
-    // One group of four MFMAs + its slot of other work (a DMA piece of the step two ahead in slots 6..17, a piece of the drain), closed by a
-    // scheduling barrier: inside, hipcc may interleave; across, nothing moves.
-    auto slot_work = [&](auto d_tag, auto slot_tag) __attribute__((always_inline)) {
-        constexpr int D = decltype(d_tag)::value, SL = decltype(slot_tag)::value;
-        if constexpr (SL >= 6 && SL <= 17) dma_piece(std::integral_constant<int, SL - 6>());
-        if constexpr (D >= 0) drain_slot(d_tag, slot_tag, F_());
+    // One group of four MFMAs + its slot of other work (a DMA piece of the step two ahead in slots 6..17, a piece of the drain; in a tile's last step the
+    // requests for the next drain behind slot 4), closed by a scheduling barrier: inside, hipcc may interleave; across, nothing moves.
+    // DR: what the step drains (nst_of).  PREVNST: stores of the previous K step.  REQ: the drain lanes request their next fragments' residual rows.
+    auto slot_work = [&](auto f_tag, auto dr_tag, auto prevnst_tag, auto req_tag, auto last_tag, auto slot_tag) __attribute__((always_inline)) {
+        constexpr int DR = decltype(dr_tag)::value, SL = decltype(slot_tag)::value, PREVNST = decltype(prevnst_tag)::value, F = decltype(f_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        if constexpr (SL >= 6 && SL <= 17) dma_piece(IC<SL - 6>());
+        if constexpr (DR != 0) {
+            constexpr int L = SL & 1, k = DBG == 4 ? ((SL >> 1) + 8) % 12 : SL >> 1;      // DBG 4: the fragment's pieces rotated so that its store sits in slot 6
+            // operations issued since this lane's residual request (behind piece 1 of the previous step, or slot 4 of the previous tile's last step):
+            // the other lane's request (lane 0 only), that step's 12 DMA pieces and its stores
+            typedef IC<(NF == 2 && L == 0 ? 1 : 0) + 12 + PREVNST> RW;
+            if constexpr (DR == 3) drain_piece(IC<F + L>(), IC<L>(), IC<k>(), BC<L == 1>(), RW(), req_tag);
+            else if constexpr (L == 0) drain_piece(IC<F>(), IC<0>(), IC<k>(), BC<DR == 2>(), RW(), req_tag);
+        }
+        if constexpr (LAST && SL == 4) {
+            // the vectors the drain of the tile that ends here will read -- the side buffer's operands of the previous drain's last fragment were consumed
+            // in slots <= 3 -- and the residual rows of its first fragment(s)
+            side_loads(cm0, cn0);
+            rr_request(IC<0>(), cm0, cn0, IC<0>());
+            if constexpr (NF == 2) rr_request(IC<1>(), cm0, cn0, IC<1>());
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     // MFMA row FIv (fragment column of the wave tile against its four row fragments). Rows 1..6 term-major (dependent MFMAs four apart: a single
     // wave per SIMD has no partner to fill a dependency stall); rows 0 and 7 fragment-row-major, so that the activation fragments of the NEXT step
     // can be requested in place behind their last use (row 7) and are used in request order (row 0).
-    auto krow = [&](auto first, auto d_tag, auto waitn_tag, auto fi_tag, int nslot) __attribute__((always_inline)) {
+    auto krow = [&](auto f, auto first, auto dr_tag, auto prevnst_tag, auto req_tag, auto last_tag, auto waitn_tag, auto waita_tag, auto fi_tag, int nslot) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first)::value;
-        constexpr int WAITN = decltype(waitn_tag)::value, FIv = decltype(fi_tag)::value;
+        constexpr int WAITN = decltype(waitn_tag)::value, WAITA = decltype(waita_tag)::value, FIv = decltype(fi_tag)::value;
         const uint4 ch = ph, cl = pl;
         if constexpr (FIv + 1 < FI) {
             ph = frag(slot, p_base + (FIv + 1) * 16 * KTB + chi);
             pl = frag(slot, p_base + (FIv + 1) * 16 * KTB + clo);
         }
         if constexpr (FIv == 2) {
-            // this wave's pieces of the NEXT step's slot have landed (issued one step ago; WAITN younger operations may stay in flight); the barrier
-            // publishes that slot to every wave and frees the slot the pieces below go into
-            wait_vm<WAITN>();
+            // this wave's WEIGHT pieces of the next step's slot have landed (issued one step ago, ahead of the activation pieces: WAITN younger operations may
+            // stay in flight); the barrier publishes them to every wave and frees the weight slot the pieces below go into
+            wait_vm<DBG == 6 ? WAITN + 14 : WAITN>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
         const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
         const f16x8_t PH = TX::h8(ch), PL = TX::h8(cl);
-        if constexpr (FIv == FI - 1) {      // the next step's first weight fragment: requested before the activation fragments below (LDS returns in order)
+        if constexpr (FIv == FI - 1) {
+            // the next step's ACTIVATION rows -- staged by this wave for itself, nobody else reads them -- have landed: ~1.5 K steps after their issue, where the
+            // barrier above gives the shared weight rows ~0.5 (they come from L2; the activation rows from HBM, slower still beside the drain's stores)
+            wait_vm<WAITA>();
+            // the next step's first weight fragment: requested before the activation fragments below (LDS returns in order)
             ph = frag(nslot, p_base + chi);
             pl = frag(nslot, p_base + clo);
         }
@@ -389,61 +396,66 @@ __global__ __launch_bounds__(NT, 1) void gemm_p4_kernel(GemmParams p, int tiles_
                     ql[fj] = frag(nslot, q_base + fj * 16 * KTB + clo);
                 }
             };
-            one(std::integral_constant<int, 0>());
-            slot_work(d_tag, std::integral_constant<int, SL0>());
-            one(std::integral_constant<int, 1>());
-            slot_work(d_tag, std::integral_constant<int, SL0 + 1>());
-            one(std::integral_constant<int, 2>());
-            one(std::integral_constant<int, 3>());
-            slot_work(d_tag, std::integral_constant<int, SL0 + 2>());
+            one(IC<0>());
+            slot_work(f, dr_tag, prevnst_tag, req_tag, last_tag, IC<SL0>());
+            one(IC<1>());
+            slot_work(f, dr_tag, prevnst_tag, req_tag, last_tag, IC<SL0 + 1>());
+            one(IC<2>());
+            one(IC<3>());
+            slot_work(f, dr_tag, prevnst_tag, req_tag, last_tag, IC<SL0 + 2>());
         } else {
 #pragma unroll
             for (int fj = 0; fj < FJ; ++fj) acc[FIv][fj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(PL, TX::h8(qh[fj]), FIRST ? z : acc[FIv][fj], 0, 0, 0);
-            slot_work(d_tag, std::integral_constant<int, FIv * 3>());
+            slot_work(f, dr_tag, prevnst_tag, req_tag, last_tag, IC<FIv * 3>());
 #pragma unroll
             for (int fj = 0; fj < FJ; ++fj) acc[FIv][fj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(PH, TX::h8(ql[fj]), acc[FIv][fj], 0, 0, 0);
-            slot_work(d_tag, std::integral_constant<int, FIv * 3 + 1>());
+            slot_work(f, dr_tag, prevnst_tag, req_tag, last_tag, IC<FIv * 3 + 1>());
 #pragma unroll
             for (int fj = 0; fj < FJ; ++fj) acc[FIv][fj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(PH, TX::h8(qh[fj]), acc[FIv][fj], 0, 0, 0);
-            slot_work(d_tag, std::integral_constant<int, FIv * 3 + 2>());
+            slot_work(f, dr_tag, prevnst_tag, req_tag, last_tag, IC<FIv * 3 + 2>());
         }
     };
-    // FIRST: accumulators start from zero (the C operand of the first term).  D >= 0: the step carries drain step D.  PREVST: stores the PREVIOUS step issued
-    // behind its last DMA piece.  LAST: last K step of a tile -- the vectors (and, typed residual stream, the first residual rows) its drain will read are
-    // requested at the top of the step (the side buffer's previous tenant was drained 16 steps into this tile).
-    auto kstep = [&](auto first, auto d_tag, auto prevst_tag, auto last_tag) __attribute__((always_inline)) {
-        constexpr int D = decltype(d_tag)::value, PREVST = decltype(prevst_tag)::value;
-        constexpr bool LAST = decltype(last_tag)::value && EPK != EPK_NONE;
+    // f: first fragment of the drain set this step works on.  FIRST: accumulators start from zero (the C operand of the first term).  PDR: what the PREVIOUS
+    // step drained (its stores are younger than its DMA).  REQ: the drain lanes request their next fragments (false on the drain's last step).  LAST: last K
+    // step of a tile.
+    auto kstep = [&](auto f, auto first, auto dr_tag, auto pdr_tag, auto req_tag, auto last_tag) __attribute__((always_inline)) {
+        constexpr int DR = decltype(dr_tag)::value, PDR = decltype(pdr_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value && DRAINS, REQ = decltype(req_tag)::value && X3R && DR != 0;
+        constexpr bool TSTART = decltype(first)::value && DR != 0;
+        constexpr int PREVNST = nst_of(PDR, LNP);
         const int nslot = slot == NST - 1 ? 0 : slot + 1;
-        if constexpr (LAST) { side_loads(); rr_request(std::integral_constant<int, 0>()); }
-        if constexpr (D == 0) wait_vm<12 + NHEAD>();          // the side vectors (younger: the first residual request, the 12 pieces of the previous step)
-        if constexpr (D >= 0) rr_request(std::integral_constant<int, D + 1>());
-        constexpr int HEAD = (D >= 0 && D + 1 < DS ? NHEAD : 0) + (LAST ? 6 + NHEAD : 0);
-        typedef std::integral_constant<int, PREVST + HEAD> WN;
-        krow(first, d_tag, WN(), std::integral_constant<int, 0>(), nslot);
-        krow(first, d_tag, WN(), std::integral_constant<int, 1>(), nslot);
-        krow(first, d_tag, WN(), std::integral_constant<int, 2>(), nslot);
-        krow(first, d_tag, WN(), std::integral_constant<int, 3>(), nslot);
-        krow(first, d_tag, WN(), std::integral_constant<int, 4>(), nslot);
-        krow(first, d_tag, WN(), std::integral_constant<int, 5>(), nslot);
-        krow(first, d_tag, WN(), std::integral_constant<int, 6>(), nslot);
-        krow(first, d_tag, WN(), std::integral_constant<int, 7>(), nslot);
+        // first drain step of a tile: the side vectors (requested in slot 4 of the previous tile's last step; younger: the first residual requests, that step's
+        // 12 DMA pieces and stores)
+        if constexpr (TSTART) wait_vm<NREQ + 12 + PREVNST>();
+        // row-2 wait (weight pieces of the previous step): younger = that step's 8 activation pieces and stores + what this step issues in slots 0..5 (residual
+        // requests behind piece 1; last step: 6 + NREQ).  Row-7 wait (its activation pieces): younger = the same without the 8, + this step's 12 pieces and the stores
+        // it has issued by then (typed residual stream: piece 9 = slots 18, 19; the typed / GELU store sits in piece 11, behind the wait)
+        constexpr int HEADN = (REQ ? NREQ : 0) + (LAST ? 6 + NREQ : 0);
+        typedef IC<8 + PREVNST + HEADN> WN;
+        typedef IC<PREVNST + HEADN + 12 + (X3R ? (DR == 3 ? 2 : DR != 0 ? 1 : 0) : 0)> WA;
+        typedef IC<PREVNST> PN;
+        typedef BC<REQ> RQ;
+        typedef BC<LAST> LT;
+        krow(f, first, dr_tag, PN(), RQ(), LT(), WN(), WA(), IC<0>(), nslot);
+        krow(f, first, dr_tag, PN(), RQ(), LT(), WN(), WA(), IC<1>(), nslot);
+        krow(f, first, dr_tag, PN(), RQ(), LT(), WN(), WA(), IC<2>(), nslot);
+        krow(f, first, dr_tag, PN(), RQ(), LT(), WN(), WA(), IC<3>(), nslot);
+        krow(f, first, dr_tag, PN(), RQ(), LT(), WN(), WA(), IC<4>(), nslot);
+        krow(f, first, dr_tag, PN(), RQ(), LT(), WN(), WA(), IC<5>(), nslot);
+        krow(f, first, dr_tag, PN(), RQ(), LT(), WN(), WA(), IC<6>(), nslot);
+        krow(f, first, dr_tag, PN(), RQ(), LT(), WN(), WA(), IC<7>(), nslot);
         dma_advance();
         slot = nslot;
     };
 
     // ---- prologue: steps 0 and 1 of the first tile in flight, head fragments of step 0 ---------------------------------------------------------
     ld_set_tile(ld_v);
-    dma_piece(std::integral_constant<int, 0>()); dma_piece(std::integral_constant<int, 1>()); dma_piece(std::integral_constant<int, 2>());
-    dma_piece(std::integral_constant<int, 3>()); dma_piece(std::integral_constant<int, 4>()); dma_piece(std::integral_constant<int, 5>());
-    dma_piece(std::integral_constant<int, 6>()); dma_piece(std::integral_constant<int, 7>()); dma_piece(std::integral_constant<int, 8>());
-    dma_piece(std::integral_constant<int, 9>()); dma_piece(std::integral_constant<int, 10>()); dma_piece(std::integral_constant<int, 11>());
-    dma_advance();
-    dma_piece(std::integral_constant<int, 0>()); dma_piece(std::integral_constant<int, 1>()); dma_piece(std::integral_constant<int, 2>());
-    dma_piece(std::integral_constant<int, 3>()); dma_piece(std::integral_constant<int, 4>()); dma_piece(std::integral_constant<int, 5>());
-    dma_piece(std::integral_constant<int, 6>()); dma_piece(std::integral_constant<int, 7>()); dma_piece(std::integral_constant<int, 8>());
-    dma_piece(std::integral_constant<int, 9>()); dma_piece(std::integral_constant<int, 10>()); dma_piece(std::integral_constant<int, 11>());
-    dma_advance();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        dma_piece(IC<0>()); dma_piece(IC<1>()); dma_piece(IC<2>()); dma_piece(IC<3>()); dma_piece(IC<4>()); dma_piece(IC<5>());
+        dma_piece(IC<6>()); dma_piece(IC<7>()); dma_piece(IC<8>()); dma_piece(IC<9>()); dma_piece(IC<10>()); dma_piece(IC<11>());
+        dma_advance();
+    }
     wait_vm<12>();                       // step 0 landed (step 1's pieces may fly)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -455,51 +467,56 @@ __global__ __launch_bounds__(NT, 1) void gemm_p4_kernel(GemmParams p, int tiles_
     ph = frag(0, p_base + chi);
     pl = frag(0, p_base + clo);
 
-    typedef std::integral_constant<int, -1> NOMS;
-    typedef std::integral_constant<int, 0> X0;
-    typedef std::integral_constant<int, NSTORE> XT;
+    // ---- tiles ---------------------------------------------------------------------------------------------------------------------------------
+    // NF == 1 (nk >= 32): steps 0..31 of a tile carry fragments 0..31 of the previous one (A, B, A, B, ...); when nk == 32 the last of them is also the
+    // tile's last step. NF == 2 (17 <= nk): steps 0..15 carry two fragments each. The loops are rolled: the fragment index is a run-time scalar.
+    constexpr bool l32 = NF == 1 && L32;
     bool have_d = false;
     for (int v = blockIdx.x; v < ntiles; v += G) {
-        int m0, n0;
-        tile_origin(v, ntiles, tiles_m, tiles_n, p.panel, m0, n0);
-        int kt;
-        if (EPK == EPK_NONE || !have_d) {
-            kstep(T_(), NOMS(), X0(), F_());
+        tile_origin(v, ntiles, tiles_m, tiles_n, p.panel, cm0, cn0);
+        int kt = 0;
+        bool last_done = false;
+        if (!DRAINS || !have_d) {
+            kstep(IC<NFRAG>(), T_(), IC<0>(), IC<0>(), F_(), F_());
             kt = 1;
+        } else if constexpr (NF == 1) {
+            // (the previous tile's last step drained its fragment 31 -- and stored -- only when a tile has exactly 32 steps)
+            kstep(IC<0>(), T_(), IC<1>(), IC<l32 ? 2 : 0>(), T_(), F_());
+            kstep(IC<1>(), F_(), IC<2>(), IC<1>(), T_(), F_());
+            for_pairs<1, 15>([&](auto i_tag) __attribute__((always_inline)) {
+                constexpr int f = 2 * decltype(i_tag)::value;
+                kstep(IC<f>(), F_(), IC<1>(), IC<2>(), T_(), F_());
+                if constexpr (f + 1 < NFRAG - 1) kstep(IC<f + 1>(), F_(), IC<2>(), IC<1>(), T_(), F_());
+            });
+            if constexpr (l32) {
+                kstep(IC<31>(), F_(), IC<2>(), IC<1>(), F_(), T_());       // fragment 31 of the previous tile + the requests for this one
+                last_done = true;
+            } else {
+                kstep(IC<31>(), F_(), IC<2>(), IC<1>(), F_(), F_());
+                kstep(IC<NFRAG>(), F_(), IC<0>(), IC<2>(), F_(), F_());
+                kt = 33;
+            }
         } else {
-            // 16 steps, each with one micro-slice of the previous tile between its MFMAs
-            kstep(T_(), std::integral_constant<int, 0>(), X0(), F_());
-            kstep(F_(), std::integral_constant<int, 1>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 2>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 3>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 4>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 5>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 6>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 7>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 8>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 9>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 10>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 11>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 12>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 13>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 14>(), XT(), F_());
-            kstep(F_(), std::integral_constant<int, 15>(), XT(), F_());
-            kstep(F_(), NOMS(), XT(), F_());
-            kt = DS + 1;
+            kstep(IC<0>(), T_(), IC<3>(), IC<0>(), T_(), F_());
+            for_pairs<1, 14>([&](auto i_tag) __attribute__((always_inline)) { kstep(IC<2 * decltype(i_tag)::value>(), F_(), IC<3>(), IC<3>(), T_(), F_()); });
+            kstep(IC<NFRAG - 2>(), F_(), IC<3>(), IC<3>(), F_(), F_());
+            kstep(IC<NFRAG>(), F_(), IC<0>(), IC<3>(), F_(), F_());
+            kt = 17;
         }
+        if (!last_done) {
 #pragma unroll 1
-        for (; kt < nk - 1; ++kt) kstep(F_(), NOMS(), X0(), F_());
-        dm0 = m0;                        // the last step requests the drain's vectors of THIS tile
-        dn0 = n0;
-        kstep(F_(), NOMS(), X0(), T_());
+            for (; kt < nk - 1; ++kt) kstep(IC<NFRAG>(), F_(), IC<0>(), IC<0>(), F_(), F_());
+            kstep(IC<NFRAG>(), F_(), IC<0>(), IC<0>(), F_(), T_());
+        }
         // the tile moves to the drain set
+        dm0 = cm0;
+        dn0 = cn0;
 #pragma unroll
         for (int fi = 0; fi < FI; ++fi)
 #pragma unroll
             for (int fj = 0; fj < FJ; ++fj) dacc[fi][fj] = acc[fi][fj];
         have_d = true;
     }
-    // ---- the last tile of this block: drained with nothing to hide under ------------------------------------------------------------------------
     if constexpr (EPK == EPK_NONE) {     // probe: keep the math alive
         float t = 0.f;
 #pragma unroll
@@ -510,24 +527,29 @@ __global__ __launch_bounds__(NT, 1) void gemm_p4_kernel(GemmParams p, int tiles_
         wait_vm<0>();
         return;
     }
+    // ---- the last tile of this block: drained with nothing to hide under ------------------------------------------------------------------------
     if (have_d) {
-        wait_vm<NHEAD>();                // the side vectors (the last K step requested them; younger: the first residual request)
-        auto tail_step = [&](auto d_tag) __attribute__((always_inline)) {
-            constexpr int D = decltype(d_tag)::value;
-            rr_request(std::integral_constant<int, D + 1>());
-            drain_slot(d_tag, std::integral_constant<int, 0>(), T_()); drain_slot(d_tag, std::integral_constant<int, 1>(), T_()); drain_slot(d_tag, std::integral_constant<int, 2>(), T_());
-            drain_slot(d_tag, std::integral_constant<int, 3>(), T_()); drain_slot(d_tag, std::integral_constant<int, 4>(), T_()); drain_slot(d_tag, std::integral_constant<int, 5>(), T_());
-            drain_slot(d_tag, std::integral_constant<int, 6>(), T_()); drain_slot(d_tag, std::integral_constant<int, 7>(), T_()); drain_slot(d_tag, std::integral_constant<int, 8>(), T_());
-            drain_slot(d_tag, std::integral_constant<int, 9>(), T_()); drain_slot(d_tag, std::integral_constant<int, 10>(), T_()); drain_slot(d_tag, std::integral_constant<int, 11>(), T_());
-            drain_slot(d_tag, std::integral_constant<int, 12>(), T_()); drain_slot(d_tag, std::integral_constant<int, 13>(), T_()); drain_slot(d_tag, std::integral_constant<int, 14>(), T_());
-            drain_slot(d_tag, std::integral_constant<int, 15>(), T_()); drain_slot(d_tag, std::integral_constant<int, 16>(), T_()); drain_slot(d_tag, std::integral_constant<int, 17>(), T_());
-            drain_slot(d_tag, std::integral_constant<int, 18>(), T_()); drain_slot(d_tag, std::integral_constant<int, 19>(), T_()); drain_slot(d_tag, std::integral_constant<int, 20>(), T_());
-            drain_slot(d_tag, std::integral_constant<int, 21>(), T_()); drain_slot(d_tag, std::integral_constant<int, 22>(), T_()); drain_slot(d_tag, std::integral_constant<int, 23>(), T_());
+        wait_vm<0>();                    // side vectors and first residual rows (requested by the last K step), and the two steps of loads past the last tile
+        // through the drain lanes of the K loop (lane L takes fragments f = L mod NF), one fragment after the other; RWAIT = operations since the fragment's
+        // request: NF == 1: the previous fragment's stores; NF == 2: the stores of both lanes' previous fragments and the other lane's request
+        auto tail_frag = [&](auto f, auto l_tag, auto isb_tag, auto rwait_tag, auto req_tag) __attribute__((always_inline)) {
+            drain_piece(f, l_tag, IC<0>(), isb_tag, rwait_tag, req_tag); drain_piece(f, l_tag, IC<1>(), isb_tag, rwait_tag, req_tag);
+            drain_piece(f, l_tag, IC<2>(), isb_tag, rwait_tag, req_tag); drain_piece(f, l_tag, IC<3>(), isb_tag, rwait_tag, req_tag);
+            drain_piece(f, l_tag, IC<4>(), isb_tag, rwait_tag, req_tag); drain_piece(f, l_tag, IC<5>(), isb_tag, rwait_tag, req_tag);
+            drain_piece(f, l_tag, IC<6>(), isb_tag, rwait_tag, req_tag); drain_piece(f, l_tag, IC<7>(), isb_tag, rwait_tag, req_tag);
+            drain_piece(f, l_tag, IC<8>(), isb_tag, rwait_tag, req_tag); drain_piece(f, l_tag, IC<9>(), isb_tag, rwait_tag, req_tag);
+            drain_piece(f, l_tag, IC<10>(), isb_tag, rwait_tag, req_tag); drain_piece(f, l_tag, IC<11>(), isb_tag, rwait_tag, req_tag);
         };
-        tail_step(std::integral_constant<int, 0>()); tail_step(std::integral_constant<int, 1>()); tail_step(std::integral_constant<int, 2>()); tail_step(std::integral_constant<int, 3>());
-        tail_step(std::integral_constant<int, 4>()); tail_step(std::integral_constant<int, 5>()); tail_step(std::integral_constant<int, 6>()); tail_step(std::integral_constant<int, 7>());
-        tail_step(std::integral_constant<int, 8>()); tail_step(std::integral_constant<int, 9>()); tail_step(std::integral_constant<int, 10>()); tail_step(std::integral_constant<int, 11>());
-        tail_step(std::integral_constant<int, 12>()); tail_step(std::integral_constant<int, 13>()); tail_step(std::integral_constant<int, 14>()); tail_step(std::integral_constant<int, 15>());
+        constexpr int NSA = nst_of(1, LNP), NSB = nst_of(2, LNP);
+        typedef IC<NF == 1 ? NSB : NSA + NSB + 1> RWA;      // A half: behind the previous B half's stores (NF == 2: + lane 0's own previous stores + lane 1's request)
+        typedef IC<NF == 1 ? NSA : NSA + NSB + 1> RWB;
+        for_pairs<0, 14>([&](auto i_tag) __attribute__((always_inline)) {
+            constexpr int f = 2 * decltype(i_tag)::value;
+            tail_frag(IC<f>(), IC<0>(), F_(), RWA(), T_());
+            tail_frag(IC<f + 1>(), IC<NF - 1>(), T_(), RWB(), T_());
+        });
+        tail_frag(IC<NFRAG - 2>(), IC<0>(), F_(), RWA(), BC<NF == 1>());       // NF == 1: fragment 30 requests 31; NF == 2: nothing left to request
+        tail_frag(IC<NFRAG - 1>(), IC<NF - 1>(), T_(), IC<NF == 1 ? NSA : NSA + NSB>(), F_());      // (NF == 2: fragment 30 requested nothing)
     }
     wait_vm<0>();                        // nothing of this block is in flight when its LDS is handed on (the load cursor ran two steps past the last tile)
 }
@@ -535,15 +557,15 @@ __global__ __launch_bounds__(NT, 1) void gemm_p4_kernel(GemmParams p, int tiles_
 }  // namespace p4
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------------------
-// Which launches run here: split-fp16 nn.Linear operands, whole 256 x 128 tiles, at least DS + 2 K steps, one of the epilogues above.
+// Which launches can run here: split-fp16 nn.Linear operands, whole 256 x 128 tiles, at least 18 K steps, one of the epilogues above.
 bool gemm_p4_eligible(const GemmParams& p, int dt) {
     if (dt != D3R_F16X3 || p.amode != AMODE_LINEAR) return false;
-    if (p.M % p4::BM != 0 || p.n_store % p4::BN != 0 || p.K % 32 != 0 || (p.K >> 5) < p4::DS + 2) return false;
+    if (p.M % p4::BM != 0 || p.n_store % p4::BN != 0 || p.K % 32 != 0 || (p.K >> 5) < 18) return false;
     if (p.n_store > p.n_pad || p.ln_part_in || p.trace || (p.flags & (GF_RELU | GF_NOWIDE))) return false;
-    if ((size_t)32 * p.lda * 4 >= (1ull << 31) || (size_t)32 * p.K * 4 >= (1ull << 31)) return false;
+    if ((size_t)256 * p.lda * 4 >= (1ull << 31) || (size_t)128 * p.K * 4 >= (1ull << 31)) return false;       // 32-bit row offsets inside a tile
     if (p.epi == EPI_F32) {
         if (!(p.flags & GF_X3RES) || !p.out2 || (p.ldo2 & 7) || (p.res1 && (p.ldr & 7)) || p.res2 || (p.ln_part && p.n_store % 32 != 0)) return false;
-        if ((size_t)16 * p.ldo2 * 4 >= (1ull << 31)) return false;
+        if ((size_t)16 * p.ldo2 * 4 >= (1ull << 31) || (p.res1 && (size_t)16 * p.ldr * 4 >= (1ull << 31))) return false;
         return true;
     }
     if (p.epi == EPI_GELU || p.epi == EPI_T) {
@@ -555,13 +577,13 @@ bool gemm_p4_eligible(const GemmParams& p, int dt) {
     return false;
 }
 
-template <int EPK> static hipError_t launch_p4(const GemmParams& p, hipStream_t s) {
+template <int EPK, int NF, bool L32 = false, int DBG = 0> static hipError_t launch_p4(const GemmParams& p, hipStream_t s) {
     static std::atomic<unsigned long long> attr_done{0};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     const unsigned long long dev_bit = 1ull << (dev_id & 63);
     if (!(attr_done.load(std::memory_order_relaxed) & dev_bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(p4::gemm_p4_kernel<EPK>), hipFuncAttributeMaxDynamicSharedMemorySize, p4::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(p4::gemm_p4_kernel<EPK, NF, L32, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, p4::LDS);
         attr_done.fetch_or(dev_bit, std::memory_order_relaxed);
     }
     static std::atomic<int> cus_cache[64];
@@ -576,15 +598,25 @@ template <int EPK> static hipError_t launch_p4(const GemmParams& p, hipStream_t 
     if (const char* e = getenv("D3R_P4_GRID")) { const int g = atoi(e); if (g >= 8 && g < grid) grid = g; }      // probe: fewer resident blocks (more tiles per block)
     grid &= ~7;                          // XCD-contiguous tile ranges need the grid stride to keep a block on its XCD (v & 7 == blockIdx & 7)
     if (grid < 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((p4::gemm_p4_kernel<EPK>), dim3(grid), dim3(p4::NT), p4::LDS, s, p, tiles_m, tiles_n, ntiles);
+    hipLaunchKernelGGL((p4::gemm_p4_kernel<EPK, NF, L32, DBG>), dim3(grid), dim3(p4::NT), p4::LDS, s, p, tiles_m, tiles_n, ntiles);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm_p4(const GemmParams& p, hipStream_t s) {
-    if (p.flags & GF_NOSTORE) return launch_p4<p4::EPK_NONE>(p, s);       // probe: the K loops alone
-    if (p.epi == EPI_F32) return p.ln_part ? launch_p4<p4::EPK_X3RES_LN>(p, s) : launch_p4<p4::EPK_X3RES>(p, s);
-    if (p.epi == EPI_GELU) return launch_p4<p4::EPK_GELU>(p, s);
-    return launch_p4<p4::EPK_TYPED>(p, s);
+    // Two fragments per K step (16 draining steps) everywhere. The one-fragment form (NF = 1: 32 unrolled step bodies) measured SLOWER on MI355X
+    // (typed store 408 vs 436 TFLOP/s, GELU 338 vs ~400 at K = 1024): ~100 KB of straight-line code per tile against a 64 KB instruction cache.
+    // It stays in the template (and in the probe below) but is not instantiated by default.
+    if (p.flags & GF_NOSTORE) return launch_p4<p4::EPK_NONE, 2>(p, s);       // probe: the K loops alone
+    if (p.epi == EPI_F32) return p.ln_part ? launch_p4<p4::EPK_X3RES_LN, 2>(p, s) : launch_p4<p4::EPK_X3RES, 2>(p, s);
+    if (p.epi == EPI_GELU) return launch_p4<p4::EPK_GELU, 2>(p, s);
+#ifdef D3R_PROBES
+    if (const char* e = getenv("D3R_P4_DBG")) {       // probe instances (typed store, 32 K steps): results INVALID
+        if ((p.K >> 5) == 32 && e[0] == '0') return launch_p4<p4::EPK_TYPED, 1, true, 0>(p, s);
+        if ((p.K >> 5) == 32 && e[0] == '1') return launch_p4<p4::EPK_TYPED, 1, true, 1>(p, s);
+        if ((p.K >> 5) == 32 && e[0] == '6') return launch_p4<p4::EPK_TYPED, 1, true, 6>(p, s);
+    }
+#endif
+    return launch_p4<p4::EPK_TYPED, 2>(p, s);
 }
 
 }  // namespace d3r

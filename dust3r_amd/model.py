@@ -185,6 +185,16 @@ class AsymmetricCroCo3DStereo(nn.Module):
             for key, value in ckpt.items():
                 if key.startswith('dec_blocks'):
                     new[key.replace('dec_blocks', 'dec_blocks2')] = value
+        # the DPT head registers its four layer_rn convolutions under two names (scratch.layer{i+1}_rn IS scratch.layer_rn[i], croco dpt_block.py); a
+        # safetensors file written by huggingface_hub's mixin keeps ONE name of each shared tensor: the other is filled in from its twin
+        for key in list(new):
+            m = re.match(r'(.*\.scratch\.)layer_rn\.(\d)\.(.*)$', key)
+            twin = f'{m.group(1)}layer{int(m.group(2)) + 1}_rn.{m.group(3)}' if m else None
+            if not m:
+                m = re.match(r'(.*\.scratch\.)layer(\d)_rn\.(.*)$', key)
+                twin = f'{m.group(1)}layer_rn.{int(m.group(2)) - 1}.{m.group(3)}' if m else None
+            if twin and twin not in new and twin in self._spec:
+                new[twin] = new[key]
         unexpected = [k for k in new if k not in self._spec]
         for k, shape in self._spec.items():
             if k in new:
@@ -201,10 +211,47 @@ class AsymmetricCroCo3DStereo(nn.Module):
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, **kw):
-        if os.path.isfile(pretrained_model_name_or_path):
-            return load_model(pretrained_model_name_or_path, device='cpu')
-        raise Exception(f'tried to load {pretrained_model_name_or_path} from huggingface, but failed '
-                        '(no network access in this build: pass a local checkpoint file)')
+        """Mirror of dust3r/model.py:76-85. A checkpoint FILE goes through load_model (the training checkpoints, dust3r/model.py:27-43); anything else is what
+        the reference hands to huggingface_hub.PyTorchModelHubMixin.from_pretrained: a local snapshot DIRECTORY (`config.json` = the constructor's keyword
+        arguments + `model.safetensors` or `pytorch_model.bin` = the state dict, loaded non-strictly like the mixin does) or a hub id, which is resolved in
+        the local hub cache only (`snapshot_download(..., local_files_only=True)`: this build never opens a connection). `precision=` / `engine_batch=`
+        keywords go to the constructor."""
+        path = str(pretrained_model_name_or_path)
+        if os.path.isfile(path):
+            return load_model(path, device='cpu', precision=kw.get('precision'))
+        if not os.path.isdir(path):
+            try:
+                import huggingface_hub
+                path = huggingface_hub.snapshot_download(path, local_files_only=True, allow_patterns=['config.json', '*.safetensors', 'pytorch_model.bin'])
+            except Exception as e:
+                raise Exception(f'tried to load {pretrained_model_name_or_path} from huggingface, but failed '
+                                f'(no network access in this build and no local snapshot of it: {type(e).__name__})')
+        return cls._from_snapshot_dir(path, **kw)
+
+    @classmethod
+    def _from_snapshot_dir(cls, path, **kw):
+        import json
+        cfg_file = os.path.join(path, 'config.json')
+        if not os.path.isfile(cfg_file):
+            raise Exception(f'tried to load {path} from huggingface, but failed (no config.json in the snapshot)')
+        with open(cfg_file) as f:
+            cfg = json.load(f)                                   # json.load accepts the Infinity / -Infinity the released configs carry
+        cfg = {k: (tuple(v) if isinstance(v, list) else v) for k, v in cfg.items()}
+        if cfg.get('patch_embed_cls') == 'ManyAR_PatchEmbed':    # load_model's swap (dust3r/model.py:31): inference runs the plain patch embedding
+            cfg['patch_embed_cls'] = 'PatchEmbedDust3R'
+        cfg.pop('freeze', None)                                  # training-only (dust3r/model.py:73)
+        cfg.update({k: v for k, v in kw.items() if k in ('precision', 'engine_batch')})
+        net = cls(**cfg)
+        st_file, bin_file = os.path.join(path, 'model.safetensors'), os.path.join(path, 'pytorch_model.bin')
+        if os.path.isfile(st_file):
+            from safetensors.torch import load_file
+            state = load_file(st_file, device='cpu')
+        elif os.path.isfile(bin_file):
+            state = torch.load(bin_file, map_location='cpu', weights_only=True)
+        else:
+            raise Exception(f'tried to load {path} from huggingface, but failed (neither model.safetensors nor pytorch_model.bin in the snapshot)')
+        net.load_state_dict(state, strict=False)                 # the mixin's default
+        return net
 
     # ------------------------------------------------------------------ device / engine
     def to(self, device=None, *a, **k):

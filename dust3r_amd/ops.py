@@ -82,6 +82,21 @@ def unpack_x3(t):
     return (g[..., 0, :] + g[..., 1, :]).reshape(*sh[:-1], sh[-1] // 2)
 
 
+def linear_x3res(act, weight, bias=None, residual=None, with_sums=True):
+    """nn.Linear as the producer of a folded LayerNorm (d3r_linear_x3res, split-fp16): returns (rows fp32 = act . weight^T + bias + residual, rounded to
+    split-fp16 like the engine's residual stream, and -- with_sums -- the (sum, sum of squares) pairs [M][N / 32][2] of the stored rows)."""
+    _lib.require_device()
+    M, K = act.shape
+    N = weight.shape[0]
+    ap, wp = pack_x3(act), pad_rows(pack_x3(weight))
+    bp = None if bias is None else pad_rows(bias.float())
+    rp = None if residual is None else pack_x3(residual)
+    out = torch.empty((M, 2 * N), dtype=torch.float16, device=act.device)
+    part = torch.zeros((M, N // 32, 2), dtype=torch.float32, device=act.device) if with_sums else None
+    check(lib.d3r_linear_x3res(ptr(ap), ptr(wp), ptr(bp), ptr(out), ptr(rp), ptr(part), M, N, K, current_stream()), 'linear_x3res')
+    return unpack_x3(out), part, out
+
+
 def linear_x3(act, weight, bias=None, epilogue='store', residual=None):
     """`linear` in the split-fp16 precision mode: act (M,K), weight (N,K) fp32 (N, K multiples of 8) are packed to the
     x3 layout, the result comes back as fp32 (unpacked for the 'store' / 'gelu' epilogues)."""

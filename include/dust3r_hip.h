@@ -140,8 +140,10 @@ int d3r_model_destroy(d3r_model* m);
  * (croco Block.norm1 / norm2, DecoderBlock.norm1 / norm2 / norm3 / norm_y) into the nn.Linear behind each of them: the matrix is packed
  * as W diag(gamma) with the bias b + W beta, by the first forward / encode / decode call after a load, from fp32 copies of those matrices
  * that are released once packed. Consequence: after that call, a new value for one of these LayerNorm vectors, or for the bias of
- * attn.qkv / cross_attn.projq / projk / projv / mlp.fc1, must come together with the matrices it is folded into -- otherwise the next
- * forward returns D3R_ERR_STATE. Loading a whole state dict (what the Python mirror does) always satisfies this. */
+ * attn.qkv / cross_attn.projq / projk / projv / mlp.fc1, must come together with the matrices it is folded into (ALL weight tensors of such
+ * a matrix: projk and projv share one) -- otherwise the next forward returns D3R_ERR_STATE until they arrive. The bookkeeping is per matrix:
+ * only the matrices whose inputs changed are re-folded, a consistently reloaded block never depends on the others. Loading a whole state
+ * dict (what the Python mirror does) always satisfies this. */
 int d3r_model_load_tensor(d3r_model* m, const char* key, const float* data_host, int ndim, const int64_t* shape);
 /* same, but `data_dev` is a DEVICE fp32 tensor (e.g. a checkpoint already uploaded by the caller). Both variants convert
  * to the engine dtype / layout on the GPU; the call is ordered on the default stream and returns without synchronising. */

@@ -83,6 +83,39 @@ def test_short_trajectory_matches_oracle(gpu):
     assert rel(scene.im_focals.data, st['im_focals']) < 1e-4
 
 
+def test_short_trajectory_matches_oracle_linear_schedule(gpu):
+    """The same under schedule='linear' (/root/reference/dust3r/cloud_opt/commons.py:88-90, base_opt.py:344-349: lr falls linearly from lr to
+    lr_min): until round 5 that schedule was only run for convergence, never compared. 20 iterations: losses of EVERY iteration and the
+    parameters against the oracle's torch-Adam loop; the two schedules must also differ from each other (a linear run that silently took the
+    cosine branch would pass the cosine test's tolerances otherwise)."""
+    from oracle.aligner_ref import AlignerRef
+    from dust3r_amd.cloud_opt.base_opt import global_alignment_loop
+    scene, out, init, gt = make_scene(gpu, 4, 32, 48, seed=7)
+    ref = AlignerRef(out).load_state(init)
+    ref_losses = ref.run(niter=20, lr=0.01, schedule='linear', lr_min=1e-6)
+    # the loop of global_alignment_loop(schedule='linear') with the per-iteration losses kept (the mirror returns the last one only)
+    from dust3r_amd._lib import check, current_stream, lib, ptr
+    eng = scene._ensure_engine()
+    check(lib.d3r_aligner_set_option(eng, 2, 0), 'reset adam')
+    losses = torch.empty(20, dtype=torch.float32, device=gpu)
+    check(lib.d3r_aligner_run(eng, 20, 0, 20, 0.01, 1e-6, 1, ptr(losses), current_stream()), 'aligner_run')
+    hist = losses.cpu().tolist()
+    for i in range(20):
+        assert abs(hist[i] / ref_losses[i] - 1) < 1e-3, (i, hist[i], ref_losses[i])
+    # and through the public mirror, from the same start: the same last loss
+    scene2, _, _, _ = make_scene(gpu, 4, 32, 48, seed=7)
+    last = global_alignment_loop(scene2, lr=0.01, niter=20, schedule='linear', lr_min=1e-6)
+    assert abs(last / hist[-1] - 1) < 1e-6
+    st = ref.state()
+    assert rel(scene.im_poses.data, st['im_poses']) < 2e-3
+    assert rel(scene.pw_poses.data, st['pw_poses']) < 2e-3
+    assert rel(scene.im_depthmaps.data, st['im_depthmaps']) < 2e-3
+    assert rel(scene.im_focals.data, st['im_focals']) < 1e-4
+    ref_cos = AlignerRef(out).load_state(init)
+    cos_losses = ref_cos.run(niter=20, lr=0.01, schedule='cosine', lr_min=1e-6)
+    assert abs(cos_losses[-1] / ref_losses[-1] - 1) > 5e-3       # the two schedules are distinguishable at this length
+
+
 def test_reference_golden_trace(gpu):
     """300 iterations against the trace recorded from the unmodified reference PointCloudOptimizer.
     The loop is chaotic at the 1e-3 level (two fp32 evaluations of the REFERENCE differ by that much),
@@ -353,7 +386,7 @@ def test_bootstrap_kernels_match_numpy(gpu):
 
 def test_pnp_batch_recovers_camera_poses(gpu):
     """The batched GPU PnP (hypotheses on the host; consensus scoring, DLT refit moments and Gauss-Newton sums in HIP) on exact
-    synthetic geometry with 5 % gross outliers: every camera pose back to 1e-3."""
+    synthetic geometry with 5 % gross outliers: every camera pose back to 3e-3 (the reference's estimator: plain least squares over the consensus set)."""
     import numpy as np
     from dust3r_amd.cloud_opt.bootstrap import solve_pnp_batch
     H, W, f = 48, 64, 70.0
@@ -377,7 +410,7 @@ def test_pnp_batch_recovers_camera_poses(gpu):
         truth.append((R, T))
     for (ok, M, cnt), (R, T) in zip(solve_pnp_batch(gpu, jobs, iterations=10), truth):
         assert ok and cnt > 0.9 * H * W
-        assert np.abs(M[:3, :3] - R).max() < 1e-3 and np.abs(M[:3, 3] - T).max() < 1e-3
+        assert np.abs(M[:3, :3] - R).max() < 3e-3 and np.abs(M[:3, 3] - T).max() < 3e-3        # least squares over the 5-pixel consensus: strays inside the band pull ~1e-3 (as in the oracle's solver)
 
 
 @pytest.mark.parametrize('name', ['mst_init_8v.pt', 'mst_init_12v_swin.pt'])
@@ -394,7 +427,7 @@ def test_spanning_tree_bootstrap_matches_reference(gpu, name):
     pnp_imgs = check_against_reference_init(scene, g, plan.pose_job, gt=gt)
     loss = float(scene())
     print(f'{name}: {len(pnp_imgs)} of {scene.n_imgs} images posed by PnP; init loss {loss:.5f} (reference {g["init_loss"]:.5f})')
-    assert loss < g['init_loss'] * (1.2 if pnp_imgs else 1.001)       # PnP-posed images: at least as consistent as the reference's start
+    assert loss < g['init_loss'] * (1.02 if pnp_imgs else 1.001)      # PnP-posed images agree with the golden's independent solver to 1e-3: so does the start
     final = scene.compute_global_alignment(init=None, niter=100, schedule='cosine', lr=0.01)
     assert final < loss
 
@@ -413,14 +446,19 @@ def test_known_poses_bootstrap(gpu):
 
 
 def test_pair_viewer_matches_reference(gpu):
-    """PairViewer on the GPU bootstrap vs the unmodified reference's PairViewer (tests/golden/pair_viewer.pt; its PnP went through
-    the cv2 stand-in): focals tightly (same Weiszfeld iterations), poses / depth / points to PnP accuracy."""
+    """PairViewer on the GPU bootstrap vs the unmodified reference's PairViewer (tests/golden/pair_viewer.pt; its cv2.solvePnPRansac call went to the
+    INDEPENDENT solver of oracle/pnp_ref.py, round 6): focals tightly (same Weiszfeld iterations), pose rotation within 1e-3, camera centre within 1e-2
+    of the baseline, depth / points to PnP accuracy."""
     from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
     g = torch.load(os.path.join(GOLD, 'pair_viewer.pt'), weights_only=False)
     out, _, gt = synthetic_scene(2, g['H'], g['W'], seed=g['seed'], symmetrize=True, noise=g['noise'])
     scene = global_aligner(out, gpu, mode=GlobalAlignerMode.PairViewer, verbose=False)
     assert float((scene.get_focals().cpu() / g['focals'] - 1).abs().max()) < 1e-4
-    assert float((scene.get_im_poses().cpu() - g['im_poses']).abs().max()) < 2e-2
+    P, Pg = scene.get_im_poses().cpu().double(), g['im_poses'].double()
+    base = float((Pg[0, :3, 3] - Pg[1, :3, 3]).norm().clamp_min(1e-6))
+    rot_err, tr_err = float((P[:, :3, :3] - Pg[:, :3, :3]).abs().max()), float((P[:, :3, 3] - Pg[:, :3, 3]).norm(dim=1).max()) / base
+    print(f'PairViewer vs the oracle-PnP golden: rotation {rot_err:.2e}, camera centre {tr_err:.2e} of the baseline')
+    assert rot_err < 1e-3 and tr_err < 1e-2
     for a, b in zip(scene.get_depthmaps(), g['depth']):
         assert a.shape == b.shape and float((a.cpu() / b - 1).abs().median()) < 1e-2
     for a, b in zip(scene.get_pts3d(), g['pts3d']):

@@ -67,7 +67,9 @@ class NumpyMaps:
         return out
 
     def solve_pnp(self, jobs, iterations=10):
-        from dust3r_amd.cloud_opt.pnp import solve_pnp_ransac
+        # the CPU double of the batched GPU PnP is the ORACLE's solver (oracle/pnp_ref.py, what the golden's reference run used through the cv2 stand-in),
+        # on the reference's arguments (init_im_poses.py:272-275): the host logic around it is then comparable with the golden image by image
+        from oracle.pnp_ref import rodrigues, solve_pnp_ransac
         res = []
         for j in jobs:
             H, W = j['H'], j['W']
@@ -76,10 +78,10 @@ class NumpyMaps:
             msk = (j['confs'].reshape(-1) > j['thr']).numpy()
             pix = np.mgrid[:W, :H].T.reshape(-1, 2).astype(np.float64)
             K = np.array([[j['f'], 0, j['pp'][0]], [0, j['f'], j['pp'][1]], [0, 0, 1.0]])
-            ok, R, T, inl = solve_pnp_ransac(pts[msk], pix[msk], K, iterations=iterations, reproj_err=5)
+            ok, rvec, T, inl = solve_pnp_ransac(pts[msk], pix[msk], K, iterationsCount=iterations, reprojectionError=5)
             M = np.eye(4)
             if ok:
-                M[:3, :3], M[:3, 3] = R, T
+                M[:3, :3], M[:3, 3] = rodrigues(rvec), T.ravel()
             res.append((bool(ok), M, 0 if inl is None else len(inl)))
         return res
 
@@ -90,11 +92,12 @@ def _scene(g):
     return global_aligner(out, 'cpu', verbose=False), gt
 
 
-def check_against_reference_init(scene, g, plan_pose_jobs=None, gt=None):
+def check_against_reference_init(scene, g, plan_pose_jobs=None, gt=None, pnp_rot_tol=1e-3, pnp_trans_tol=1e-2):
     """Parameters written by the bootstrap vs the reference's. Every pairwise pose, every focal, and pose + depth of the images posed by
-    a registration: tightly. Images posed by PnP: two different RANSAC solvers (and the reference's stand-in solver occasionally returns
-    a poor pose at its 10-iteration budget), so those are held to the GROUND TRUTH instead -- rotation relative to the root camera
-    within 0.05 rad, same viewing side -- which the reference's own result for such an image need not meet."""
+    a registration: tightly. Images posed by PnP: the golden's pose came from the INDEPENDENT solver of oracle/pnp_ref.py (the reference's
+    cv2.solvePnPRansac call through the stand-in; round 6 -- until round 5 the stand-in forwarded to the product's own solver and this branch
+    compared the product with itself): rotation within pnp_rot_tol (max abs entry), camera centre within pnp_trans_tol of the scene's scale;
+    and, with the ground truth at hand, rotation relative to the root camera within 0.05 rad."""
     pw, ref_pw = scene.pw_poses.detach().cpu().double(), g['pw_poses'].double()
     sgn = torch.sign((pw[:, :4] * ref_pw[:, :4]).sum(dim=1, keepdim=True))          # quaternion sign is free
     assert float((pw[:, :4] * sgn - ref_pw[:, :4]).abs().max()) < 2e-4
@@ -110,7 +113,13 @@ def check_against_reference_init(scene, g, plan_pose_jobs=None, gt=None):
         if k not in posed_by_pnp:
             assert float(err[k]) < 2e-4, (k, float(err[k]))
             assert float((d[k] - ref_d[k]).abs().max()) < 3e-4, k
-        elif gt is not None and root:
+        else:
+            scale = float(ref_c2w[:, :3, 3].norm(dim=1).max().clamp_min(1e-6))
+            rot_err = float((c2w[k, :3, :3] - ref_c2w[k, :3, :3]).abs().max())
+            tr_err = float((c2w[k, :3, 3] - ref_c2w[k, :3, 3]).norm()) / scale
+            print(f'  image {k} posed by PnP: rotation vs the oracle-PnP golden {rot_err:.2e}, camera centre {tr_err:.2e} of the scene scale')
+            assert rot_err < pnp_rot_tol and tr_err < pnp_trans_tol, (k, rot_err, tr_err)
+        if k in posed_by_pnp and gt is not None and root:
             r = root[0]
             rel = c2w[r, :3, :3].T @ c2w[k, :3, :3]
             rel_gt = (gt['cam2world'][r, :3, :3].T @ gt['cam2world'][k, :3, :3]).double()
@@ -130,7 +139,7 @@ def test_spanning_tree_bootstrap_host_logic_matches_reference(name):
     assert len(plan.tree_edges) == scene.n_imgs - 1 and all(a is not None for a in plan.anchor)
     scene.forward = lambda: torch.tensor(float('nan'))          # the loss needs the GPU engine; not part of this check
     B.bootstrap_from_spanning_tree(scene, niter_PnP=10, maps=maps)
-    pnp_imgs = check_against_reference_init(scene, g, plan.pose_job, gt=None)      # the stand-in solver IS the reference's solver here
+    pnp_imgs = check_against_reference_init(scene, g, plan.pose_job, gt=None)      # the double's PnP IS the golden's solver: every image tightly
     print(f'{name}: {len(pnp_imgs)} of {scene.n_imgs} images posed by PnP')
 
 
@@ -217,7 +226,7 @@ class PnpKernelEmulation:
             Jv = np.concatenate((fx[:, None] * S[:, 1] + a1[:, None] * S[:, 2], np.stack((Z, fx, a1), -1)), -1)
             r_u, r_v = ru[sel].astype(np.float64), rv[sel].astype(np.float64)
             rn = np.sqrt(r_u ** 2 + r_v ** 2)
-            hw = np.where(rn > 1, 1 / np.maximum(rn, 1e-30), 1.0)                       # Huber, delta = 1 px
+            hw = np.ones_like(rn)                                                       # plain least squares over the consensus set (the kernel's weight)
             Hm, g = (Ju * hw[:, None]).T @ Ju + (Jv * hw[:, None]).T @ Jv, Ju.T @ (hw * r_u) + Jv.T @ (hw * r_v)
             o[a, :21] = torch.from_numpy(Hm[np.triu_indices(6)])
             o[a, 21:27] = torch.from_numpy(g)
@@ -248,7 +257,9 @@ def test_pnp_batch_host_logic(monkeypatch):
     from dust3r_amd.synthetic import _axis_angle_R
     H, W, f = 48, 64, 70.0
     rng = np.random.RandomState(0)
-    for noise, tol in ((0.0, 1e-3), (0.01, 2e-2)):
+    # (exact geometry: the gross outliers that happen to reproject inside the 5-pixel band pull a plain least-squares pose by ~1e-3 -- the reference's estimator,
+    # and the oracle's: oracle/pnp_ref.py lands on the same pose; the Huber-weighted polish of rounds 2-5 stayed below 1e-3 here and 4e-3 away from the oracle elsewhere)
+    for noise, tol in ((0.0, 3e-3), (0.01, 2e-2)):
         jobs, truth = [], []
         for k in range(4):
             R = _axis_angle_R(rng.randn(3), 0.3 * rng.randn())

@@ -63,7 +63,7 @@ def compare(engine, oracle, v1, v2, max_tol, mean_tol, stat='max', tag=''):
         e = ((a.cpu() - b).abs() / b.abs()).flatten()
         err = float(e.max()) if stat == 'max' else float(e.kthvalue(max(1, int(0.99 * e.numel())))[0])
         print(f'[{tag}] {name}: rel err {stat} {err:.3e}')
-        assert err < max_tol * 3, (name, err)
+        assert err < max_tol * (1 if any(t in ('fp32', 'fp16x3') for t in tag.split()) else 3), (name, err)      # the parity-grade modes: the stated bar, also on conf
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'fp16x3', 'fp16x2f8', 'fp16f8', 'fp16', 'bf16'])
@@ -297,7 +297,7 @@ def test_full_size_fp32_pair_matches_oracle(gpu):
                 assert mx < 1e-3 and mean < 2e-4, (prec, name, mx, mean)
         cerr = float(((e1['conf'].cpu() - r1['conf']).abs() / r1['conf']).max())
         print(f'[512_dpt {prec}] conf1 rel err max {cerr:.3e}')
-        assert cerr < 3e-3
+        assert cerr < 1e-3
     # 16-bit modes on the full network: report (and bound) the error against the same fp32 oracle outputs
     for prec, bound in (('fp16', 2e-2), ('bf16', 1e-1)):
         eng.set_precision(prec)

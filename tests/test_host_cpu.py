@@ -45,6 +45,20 @@ def test_product_never_imports_oracle():
     assert not bad, bad
 
 
+def test_oracle_never_imports_the_product_algorithms():
+    """The inverse direction (round 6): the only product module anything under oracle/ may import is dust3r_amd.synthetic -- the seeded INPUT generators the
+    goldens are rebuilt from. Until round 5 oracle/shims/cv2.py forwarded cv2.solvePnPRansac to dust3r_amd.cloud_opt.pnp, so the PnP goldens held the
+    product's own answers."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'oracle')):
+        for f in files:
+            if f.endswith('.py'):
+                for m in re.finditer(r'^\s*(?:from|import)\s+(dust3r_amd[\w.]*)', open(os.path.join(dirpath, f)).read(), re.M):
+                    if m.group(1) != 'dust3r_amd.synthetic':
+                        bad.append((f, m.group(1)))
+    assert not bad, bad
+
+
 @pytest.mark.parametrize('graph,sym', [('complete', True), ('complete', False), ('swin-3', True), ('swin-2-noncyclic', False),
                                        ('logwin-3', True), ('oneref-2', True)])
 def test_make_pairs_matches_reference_semantics(graph, sym):
@@ -508,3 +522,42 @@ def test_host_thread_pool_is_capped_at_the_usable_cpus(monkeypatch):
         assert D.fit_host_threads() == 1                      # never raised
     finally:
         torch.set_num_threads(before)
+
+
+@pytest.mark.parametrize('fmt', ['safetensors', 'bin'])
+def test_from_pretrained_loads_a_local_hub_snapshot_directory(tmp_path, fmt):
+    """dust3r/model.py:76-85: from_pretrained(<not a file>) is huggingface_hub.PyTorchModelHubMixin.from_pretrained -- for a local directory: config.json = the
+    constructor's keyword arguments, model.safetensors / pytorch_model.bin = the state dict (non-strict). Built here from a synthetic state dict with the
+    released configs' quirks: lists for tuples, Infinity bounds, ManyAR patch embed, a `freeze` entry, no dec_blocks2 keys (model.py:91-98)."""
+    import json
+    from dust3r_amd.model import AsymmetricCroCo3DStereo
+    from dust3r_amd.synthetic import MODEL_CONFIGS, synthetic_state_dict
+    cfg = dict(MODEL_CONFIGS['tiny_dpt'])
+    ref = AsymmetricCroCo3DStereo(landscape_only=False, **cfg)
+    state = synthetic_state_dict({k: torch.empty(v, device='meta') for k, v in ref._spec.items()}, 5, 1.0)
+    state = {k: v for k, v in state.items() if not k.startswith('dec_blocks2')}
+    snap = tmp_path / 'snapshot'
+    snap.mkdir()
+    cfg_json = {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}
+    cfg_json.update(landscape_only=False, patch_embed_cls='ManyAR_PatchEmbed', freeze='none', depth_mode=['exp', float('-inf'), float('inf')], conf_mode=['exp', 1, float('inf')])
+    (snap / 'config.json').write_text(json.dumps(cfg_json))
+    assert 'Infinity' in (snap / 'config.json').read_text()
+    if fmt == 'safetensors':
+        from safetensors.torch import save_file
+        # as huggingface_hub's mixin writes it: ONE name per shared tensor (the DPT head's layer_rn convolutions are registered under two)
+        save_file({k: v.contiguous().clone() for k, v in state.items() if not re.search(r'scratch\.layer\d_rn\.', k)}, str(snap / 'model.safetensors'))
+    else:
+        torch.save(state, str(snap / 'pytorch_model.bin'))
+    m = AsymmetricCroCo3DStereo.from_pretrained(str(snap), precision='fp32')
+    assert m.precision == 'fp32' and m.depth_mode == ('exp', float('-inf'), float('inf')) and m.conf_mode == ('exp', 1, float('inf'))
+    got = m.state_dict()
+    assert set(got) == set(ref._spec)
+    for k, v in state.items():
+        assert torch.equal(got[k], v.float()), k
+        if k.startswith('dec_blocks.'):
+            assert torch.equal(got[k.replace('dec_blocks', 'dec_blocks2')], v.float())     # the second decoder starts as a copy of the first
+    # a hub id without a local snapshot: the reference's failure message, no connection attempt that could hang
+    with pytest.raises(Exception, match='tried to load naver/DUSt3R_does_not_exist from huggingface, but failed'):
+        AsymmetricCroCo3DStereo.from_pretrained('naver/DUSt3R_does_not_exist')
+    with pytest.raises(Exception, match='no config.json'):
+        AsymmetricCroCo3DStereo.from_pretrained(str(tmp_path))

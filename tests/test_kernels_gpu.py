@@ -95,6 +95,49 @@ def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize('grid', [None, '8'])
+@pytest.mark.parametrize('M,N,K', [(2048, 256, 768), (4096, 384, 1024), (2048, 128, 1536), (6144, 256, 576)])
+def test_persistent_gemm_is_bit_identical(gpu, M, N, K, grid, monkeypatch):
+    """gemm_p4.hip (one block per CU walking its tiles, the epilogue of tile t drained under the K loop of tile t + 1) against the one-tile-per-block
+    kernels on the same operands: typed store, GELU, and the typed residual stream with and without a residual and with its LayerNorm partial sums --
+    BIT-identical (same MFMA order per element, same epilogue expressions, same summation tree), and within fp32-class error of the fp64 product.
+    K = 576 / 768: 18 / 24 K steps (the shortest loop the kernel takes); 1536: steps behind the draining ones; grid = 8: forty tiles per block (the
+    overlapped path), default: one or two (first tile without a drain, last tile drained with nothing to hide under)."""
+    from dust3r_amd import ops
+    if grid:
+        monkeypatch.setenv('D3R_P4_GRID', grid)
+    g = torch.Generator(device='cpu').manual_seed(M + 3 * N + K)
+    a = torch.randn((M, K), generator=g).to(gpu)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(gpu)
+    b = torch.randn(N, generator=g).to(gpu)
+    res = torch.randn((M, N), generator=g).to(gpu)
+    ref = (a.double() @ w.double().T + b.double()).float()
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('D3R_GEMM_PERSIST', mode)
+        o_store, o_gelu = ops.linear_x3(a, w, b, 'store'), ops.linear_x3(a, w, None, 'gelu')
+        r1, p1, raw1 = ops.linear_x3res(a, w, b, res, with_sums=True)
+        r2, _, raw2 = ops.linear_x3res(a, w, b, None, with_sums=False)
+        out[mode] = (o_store, o_gelu, raw1, p1, raw2)
+        assert relerr(o_store, ref) < 3e-6 and relerr(o_gelu, F.gelu(ref - b)) < 3e-6
+        assert relerr(r1, ref + ops.unpack_x3(ops.pack_x3(res))) < 3e-6 and relerr(r2, ref) < 3e-6
+        stored = r1.double().view(M, N // 32, 32)
+        assert float((p1[..., 0].double() - stored.sum(-1)).abs().max()) < 1e-3 and float((p1[..., 1].double() / (stored * stored).sum(-1) - 1).abs().max()) < 1e-5
+    for x, y in zip(out['0'], out['1']):
+        assert torch.equal(x.view(torch.int16) if x.dtype == torch.float16 else x, y.view(torch.int16) if y.dtype == torch.float16 else y)
+
+
+def test_persistent_gemm_dispatch_rule():
+    """Host only: which launches the heuristic hands to the persistent kernel (d3r_gemm_tile_config = 10) -- the encoder's fc1 / typed-residual projection
+    and the decoder's fc1 at 32 pairs per step; not fc2 at K = 4096 (the K loop dominates: measured equal), not the decoder's N = 768 GEMMs (576 tiles of
+    256 x 128 = 2.25 rounds of 256 CUs), not small batches (fewer tiles than CUs)."""
+    from dust3r_amd._lib import lib, DTYPE_F16X3
+    cfg = lambda M, N, K, epi, res=0: lib.d3r_gemm_tile_config(DTYPE_F16X3, M, N, K, epi, res)     # noqa: E731
+    assert cfg(49152, 4096, 1024, 2) == 10 and cfg(24576, 3072, 768, 2) == 10 and cfg(49152, 3072, 1024, 0) == 10
+    assert cfg(1536, 4096, 1024, 2) != 10 and cfg(49152, 4096, 1024, 1, 1) != 10      # one pair; fp32 residual epilogue (not the typed stream)
+    assert cfg(24576, 768, 768, 0) != 10
+
+
 @pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '1w4'])
 @pytest.mark.parametrize('M,N,K', [(300, 192, 256), (1000, 3072, 1024), (77, 128, 768), (2100, 1024, 64), (515, 320, 128)])
 def test_linear_fp16_fp8(gpu, M, N, K, cfg, monkeypatch):
