@@ -10,8 +10,5 @@ The arithmetic lives in csrc/ (hand-written HIP for CDNA4) behind the C ABI of i
 """
 __version__ = '0.1.0'
 
-# Host-side tensor work of the path (collation, result memory, scene construction) runs on torch's intra-op pool: keep that pool inside the CPU quota
-# this process actually has (utils/device.py:fit_host_threads -- never raises the count; DUST3R_AMD_KEEP_TORCH_THREADS=1 opts out).
-from .utils.device import fit_host_threads as _fit_host_threads  # noqa: E402
-
-_fit_host_threads()
+# (No import side effects: the cap of torch's intra-op pool to the CPUs this process can use -- utils/device.py:fit_host_threads -- is applied by the first
+# inference() / global_aligner() call, logged once, and DUST3R_AMD_KEEP_TORCH_THREADS=1 opts out.)

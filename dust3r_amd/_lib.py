@@ -51,6 +51,7 @@ def _load():
         'd3r_upsample2x_nhwc': (i, [vp, vp, i, i, i, i, i, i, i, vp]),
         'd3r_gemm_set_trace': (i, [vp, C.c_size_t]),
         'd3r_gemm_tile_config': (i, [i, i, i, i, i, i]),
+        'd3r_build_has_probes': (i, []),
         'd3r_model_create': (i, [C.POINTER(vp), C.POINTER(ModelConfig)]),
         'd3r_model_destroy': (i, [vp]),
         'd3r_model_load_tensor': (i, [vp, C.c_char_p, fp, i, C.POINTER(C.c_int64)]),

@@ -19,6 +19,8 @@ _SCENES = {GlobalAlignerMode.PointCloudOptimizer: PointCloudOptimizer, GlobalAli
 
 
 def global_aligner(dust3r_output, device, mode=GlobalAlignerMode.PointCloudOptimizer, **optim_kw):
+    from ..utils.device import fit_host_threads_once
+    fit_host_threads_once()
     if mode == GlobalAlignerMode.ModularPointCloudOptimizer:
         raise NotImplementedError('ModularPointCloudOptimizer (the slow per-edge variant, unused by the demo) is out of scope: '
                                   'use GlobalAlignerMode.PointCloudOptimizer')

@@ -387,15 +387,17 @@ def global_alignment_loop_sharded(net, group=None, lr=0.01, niter=300, schedule=
     """global_alignment_loop over the ranks of `group` (one process per GPU; every rank holds the whole scene). Rank r runs the main pass of ITS images
     (include/dust3r_hip.h, d3r_aligner_set_image_range / step_begin / step_end); the reduced fp64 sums ((2 E + n) x 16 doubles: 160 KB at 100 views / 600 edges) are
     all-reduced once per iteration, and the pose / focal step runs replicated. Every partial record belongs to one image, i.e. to one rank: the other ranks add exact
-    zeros, so losses and parameters are bit-identical to the single-GPU loop for any number of ranks. Start: the trainable parameters are broadcast from rank 0 (a
-    random `init=None` start differs between processes); end: every rank receives the other ranks' rows of im_depthmaps."""
+    zeros, so losses and parameters are bit-identical to the single-GPU loop for any number of ranks. Start: all six parameter tensors are broadcast from rank 0 (a
+    random `init=None` start differs between processes, for frozen tensors too); end: every rank receives the other ranks' rows of im_depthmaps."""
     import torch.distributed as dist
     if schedule not in ('cosine', 'linear'):
         raise ValueError(f'bad lr {schedule=}')
     if niter <= 0:
         return float('inf')
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    for name in net.trainable_names():
+    # ALL six parameter tensors, frozen ones included: a frozen tensor without a preset still holds its per-process random start (init=None), and the replicated
+    # pose / focal step would then diverge silently between ranks (a few KB apart from the depth maps)
+    for name in net._TRAINABLE_KEYS:
         dist.broadcast(getattr(net, name).data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     eng = net._ensure_engine()
     ranges = image_ranges(net.edges, net.imshapes, world)
@@ -421,7 +423,11 @@ def global_alignment_loop_sharded(net, group=None, lr=0.01, niter=300, schedule=
             done += k_run
             loss = float(losses[k_run - 1])
     finally:
-        check(lib.d3r_aligner_set_image_range(eng, 0, net.n_imgs), 'set_image_range(all)')
+        # never raise from here: an error of the loop above must reach the caller as itself (the other ranks see it as a collective timeout)
+        rc = lib.d3r_aligner_set_image_range(eng, 0, net.n_imgs)
+        if rc != 0:
+            import logging
+            logging.getLogger('dust3r_amd').error('d3r_aligner_set_image_range(all) failed with code %d after the sharded loop', rc)
     # every rank's own rows of the log-depth maps -> all ranks (sum with zeros elsewhere: exact)
     depth = net.im_depthmaps.data
     own = torch.zeros_like(depth)

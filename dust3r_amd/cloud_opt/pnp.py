@@ -88,7 +88,12 @@ def dlt_pose_batch(X, xn, sel):
     X = np.asarray(X, np.float64)
     xn = np.asarray(xn, np.float64)
     b, p = X.shape[:2]
-    w = np.asarray(sel, np.float64)
+    selb = np.asarray(sel, bool)
+    w = selb.astype(np.float64)
+    # unselected rows are ZEROED, not multiplied by a zero weight: NaN * 0 and inf * 0 are NaN, and a non-finite low-confidence candidate that the scalar
+    # path never reads must not reject the hypothesis (bootstrap.solve_pnp_batch passes whole candidate windows)
+    X = np.where(selb[:, :, None], X, 0.0)
+    xn = np.where(selb[:, :, None], xn, 0.0)
     Xh = np.concatenate((X, np.ones((b, p, 1))), axis=2) * w[:, :, None]
     a1 = np.zeros((b, p, 12))
     a2 = np.zeros((b, p, 12))
@@ -110,7 +115,7 @@ def dlt_pose_batch(X, xn, sel):
     R = R * sgn[:, None, None]
     T = sgn[:, None] * P[:, :, 3] / sm[:, None]
     z = np.einsum('bpk,bk->bp', X, R[:, 2, :]) + T[:, 2:3]
-    z = np.where(np.asarray(sel, bool), z, np.nan)
+    z = np.where(selb, z, np.nan)
     with np.errstate(all='ignore'):
         import warnings
         with warnings.catch_warnings():

@@ -784,11 +784,11 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     d3r_aligner* a = new (std::nothrow) d3r_aligner();
     if (!a) return D3R_ERR_ALLOC;
     a->n = n_imgs; a->E = n_edges; a->maxA = max_area;
-    { const char* e = getenv("D3R_ALIGNER_NWV"); a->nwv = (e && e[0] == '8') ? 8 : 4; }
-    { const char* e = getenv("D3R_ALIGNER_PROBE"); a->probe = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
+    { const char* e = probe_env("D3R_ALIGNER_NWV"); a->nwv = (e && e[0] == '8') ? 8 : 4; }
+    { const char* e = probe_env("D3R_ALIGNER_PROBE"); a->probe = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
     // default since round 5: the block-interleaved copy (same-process A/B, tools/aligner_probe.py, profiles/r05_k: 3998 -> 4085 it/s at 190 edges, 2142 -> 2161 at 380,
     // bit-identical losses); D3R_ALIGNER_LAYOUT=0: the planar copy + the caller's weight rows (rounds 1-4)
-    { const char* e = getenv("D3R_ALIGNER_LAYOUT"); a->layout = (!(e && e[0] == '0') && a->nwv == 4 && !a->probe) ? 1 : 0; }
+    { const char* e = probe_env("D3R_ALIGNER_LAYOUT"); a->layout = (!(e && e[0] == '0') && a->nwv == 4 && !a->probe) ? 1 : 0; }
     a->maxAp = (max_area + 255) / 256 * 256;
     a->nslot = cdiv(max_area, a->nwv * 64 * PPT);
     a->h_w.assign(img_w, img_w + n_imgs);
@@ -835,7 +835,7 @@ extern "C" int d3r_aligner_create(d3r_aligner** out, int n_imgs, int n_edges, co
     hipStream_t st = (hipStream_t)stream;   // the clear and the re-layout below are ordered on the caller's stream, like every later call
     // D3R_ALIGNER_POISON=1 (stress harness, tools/c4_stress.py): every allocation of the handle is filled with 0xFF bytes (fp32 / fp64 NaN,
     // int -1) before its real initialisation, so that any read of a byte the create path failed to initialise shows up as NaN / a fault
-    static const bool poison = [] { const char* e = getenv("D3R_ALIGNER_POISON"); return e && e[0] == '1'; }();
+    static const bool poison = [] { const char* e = probe_env("D3R_ALIGNER_POISON"); return e && e[0] == '1'; }();
     if (poison && hipMemsetAsync(a->state, 0xFF, a->state_bytes, st) != hipSuccess) { (void)hipFree(a->state); delete a; return D3R_ERR_LAUNCH; }
     if (hipMemsetAsync(a->state, 0, a->state_bytes, st) != hipSuccess) { (void)hipFree(a->state); delete a; return D3R_ERR_LAUNCH; }
     float* b = a->state;
@@ -941,25 +941,35 @@ static int aligner_pass(d3r_aligner* a, bool update, double lr, int hist_idx, fl
     v.inv_area[0] = a->inv_area[0]; v.inv_area[1] = a->inv_area[1]; v.l2 = a->l2; v.update = update ? 1 : 0;
     v.use_dpp = a->use_dpp; v.adam = s.adam;
     // D3R_ALIGNER_PF=2: two edges of the stream in flight per wave (probe; 16 more VGPRs, 3 instead of 4 waves per SIMD)
-    static const int pf = [] { const char* e = getenv("D3R_ALIGNER_PF"); return (e && e[0] == '2') ? 2 : 1; }();
+    static const int pf = [] { const char* e = probe_env("D3R_ALIGNER_PF"); return (e && e[0] == '2') ? 2 : 1; }();
     const dim3 grid(imgc * a->nslot);
     if (imgc > 0) {
-    if (a->probe && !a->l2) {
-        if (a->probe == 1 && pf == 2) hipLaunchKernelGGL((aligner_main_kernel<false, 2, 4, 1>), grid, dim3(256), 0, st, v);
-        else if (a->probe == 1) hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 1>), grid, dim3(256), 0, st, v);
-        else hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 2>), grid, dim3(256), 0, st, v);
-    } else if (a->layout == 1) {
+    // default build: the block-interleaved layout only (a->layout == 1 whenever no probe switch is read); the planar / 512-thread / two-edges-in-flight /
+    // ablation instances are compiled in probe builds (-DD3R_PROBES)
+    bool launched = false;
+    if constexpr (kProbes) {
+        launched = true;
+        if (a->probe && !a->l2) {
+            if (a->probe == 1 && pf == 2) hipLaunchKernelGGL((aligner_main_kernel<false, 2, 4, 1>), grid, dim3(256), 0, st, v);
+            else if (a->probe == 1) hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 1>), grid, dim3(256), 0, st, v);
+            else hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 2>), grid, dim3(256), 0, st, v);
+        } else if (a->layout == 1) {
+            launched = false;
+        } else if (a->nwv == 8) {
+            if (a->l2) hipLaunchKernelGGL((aligner_main_kernel<true, 1, 8>), grid, dim3(512), 0, st, v);
+            else hipLaunchKernelGGL((aligner_main_kernel<false, 1, 8>), grid, dim3(512), 0, st, v);
+        } else if (a->l2) {
+            if (pf == 2) hipLaunchKernelGGL((aligner_main_kernel<true, 2>), grid, dim3(256), 0, st, v);
+            else hipLaunchKernelGGL((aligner_main_kernel<true, 1>), grid, dim3(256), 0, st, v);
+        } else {
+            if (pf == 2) hipLaunchKernelGGL((aligner_main_kernel<false, 2>), grid, dim3(256), 0, st, v);
+            else hipLaunchKernelGGL((aligner_main_kernel<false, 1>), grid, dim3(256), 0, st, v);
+        }
+    }
+    (void)pf;
+    if (!launched) {
         if (a->l2) hipLaunchKernelGGL((aligner_main_kernel<true, 1, 4, 0, 1>), grid, dim3(256), 0, st, v);
         else hipLaunchKernelGGL((aligner_main_kernel<false, 1, 4, 0, 1>), grid, dim3(256), 0, st, v);
-    } else if (a->nwv == 8) {
-        if (a->l2) hipLaunchKernelGGL((aligner_main_kernel<true, 1, 8>), grid, dim3(512), 0, st, v);
-        else hipLaunchKernelGGL((aligner_main_kernel<false, 1, 8>), grid, dim3(512), 0, st, v);
-    } else if (a->l2) {
-        if (pf == 2) hipLaunchKernelGGL((aligner_main_kernel<true, 2>), grid, dim3(256), 0, st, v);
-        else hipLaunchKernelGGL((aligner_main_kernel<true, 1>), grid, dim3(256), 0, st, v);
-    } else {
-        if (pf == 2) hipLaunchKernelGGL((aligner_main_kernel<false, 2>), grid, dim3(256), 0, st, v);
-        else hipLaunchKernelGGL((aligner_main_kernel<false, 1>), grid, dim3(256), 0, st, v);
     }
     }
     // part_edge | part_img and red_edge | red_img are contiguous: one launch reduces the 2E + n entries

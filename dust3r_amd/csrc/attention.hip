@@ -765,8 +765,8 @@ template <int ODT, int PROBE, int NW = 4, bool DMA = false, bool SC = false, boo
     return hipGetLastError();
 }
 template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream_t s) {
-    if constexpr (ODT == D3R_F16X3) {
-        if (const char* e = getenv("D3R_ATTN_PROBE")) {      // ablation instances (results invalid), see the kernel
+    if constexpr (kProbes && ODT == D3R_F16X3) {
+        if (const char* e = probe_env("D3R_ATTN_PROBE")) {      // ablation instances (results invalid), see the kernel
             switch (atoi(e)) {
                 case 1: return launch_x3_v2p<ODT, 1>(p, s);
                 case 2: return launch_x3_v2p<ODT, 2>(p, s);
@@ -781,7 +781,7 @@ template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream
             }
         }
     }
-    if (const char* e = getenv("D3R_ATTN_NW")) {
+    if constexpr (kProbes) if (const char* e = probe_env("D3R_ATTN_NW")) {
         if (e[0] == '8' && e[1] == 0) return launch_x3_v2p<ODT, 0, 8>(p, s);   // probe: 256 queries per workgroup (register staging, packed softmax: round 3's instance)
         // probe '8d' / '8e': 256 queries per workgroup with DMA staging and the scalar softmax slices, everywhere / for launches of >= 2048 workgroups of 128 queries only
         if (e[0] == '8' && (e[1] == 'd' || (e[1] == 'e' && (long)p.B * p.H * ((p.Nq + 127) / 128) >= 4096))) return launch_x3_v2p<ODT, 0, 8, true, true>(p, s);
@@ -793,12 +793,15 @@ template <int ODT> static hipError_t launch_x3_v2(const AttnParams& p, hipStream
     // The softmax / split slices on scalar fp32 VALU (default since round 5; D3R_ATTN_SC=0: the packed v_pk_* form; bit-identical; read per launch).
     // Measured in one process on one box (tools/ab_probe.py, profiles/r05_b/ab_probe.log, three alternating repetitions of the 32-pair forward):
     // attention 21.20 -> 20.72 ms per step, forward 171.29 -> 170.83 ms.
-    const char* e_sc = getenv("D3R_ATTN_SC");
-    const char* e_lz = getenv("D3R_ATTN_LAZY");          // 1: lazy running maximum (round 5 probe; read per launch)
-    if ((e_dma ? e_dma[0] != '0' : true) && !(e_sc && e_sc[0] == '0') && e_lz && e_lz[0] == '1') return launch_x3_v2p<ODT, 0, 4, true, true, true>(p, s);
-    if ((e_dma ? e_dma[0] != '0' : true) && !(e_sc && e_sc[0] == '0')) return launch_x3_v2p<ODT, 0, 4, true, true>(p, s);
-    if (e_dma ? e_dma[0] != '0' : true) return launch_x3_v2p<ODT, 0, 4, true>(p, s);
-    return launch_x3_v2p<ODT, 0>(p, s);
+    const char* e_sc = probe_env("D3R_ATTN_SC");
+    const char* e_lz = probe_env("D3R_ATTN_LAZY");          // 1: lazy running maximum (round 5 probe; read per launch)
+    const bool dma = e_dma ? e_dma[0] != '0' : true;
+    if constexpr (kProbes) {        // the lazy-maximum and DMA + packed-softmax instances: probe builds only (-DD3R_PROBES)
+        if (dma && !(e_sc && e_sc[0] == '0') && e_lz && e_lz[0] == '1') return launch_x3_v2p<ODT, 0, 4, true, true, true>(p, s);
+        if (dma && e_sc && e_sc[0] == '0') return launch_x3_v2p<ODT, 0, 4, true>(p, s);
+    }
+    (void)e_sc; (void)e_lz;
+    return dma ? launch_x3_v2p<ODT, 0, 4, true, true>(p, s) : launch_x3_v2p<ODT, 0>(p, s);
 }
 
 template <int DT, int ODT = DT> static hipError_t launch_t(const AttnParams& p, hipStream_t s) {

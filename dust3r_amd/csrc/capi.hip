@@ -73,6 +73,9 @@ extern "C" int d3r_gemm_set_trace(void* buf, size_t capacity_blocks) {
     return D3R_OK;
 }
 
+// 1: this library was compiled with -DD3R_PROBES (ablation kernels and probe-only environment switches present), 0: the default build
+extern "C" int d3r_build_has_probes(void) { return kProbes ? 1 : 0; }
+
 // Diagnostics, host only (no GPU, no launch): the tile configuration the heuristic of gemm.hip picks for an nn.Linear-shaped problem
 // (same `epilogue` codes as d3r_linear; with_residual: an fp32 residual is added). The dispatch table of DESIGN.md section 4.1 as a function.
 extern "C" int d3r_gemm_tile_config(int dtype, int M, int N, int K, int epilogue, int with_residual) {
@@ -83,6 +86,7 @@ extern "C" int d3r_gemm_tile_config(int dtype, int M, int N, int K, int epilogue
     p.lda = K; p.M = M; p.K = K; p.n_pad = rup(N, 128); p.n_rows = rup(N, 256); p.n_store = N;      // the engine's weight loader allocates rows the same way (engine.hip: Lin / ConvW)
     p.epi = epilogue == 1 ? EPI_F32 : (epilogue == 2 ? EPI_GELU : EPI_T);
     p.res1 = (epilogue == 1 && with_residual) ? &dummy : nullptr;
+    p.act = &dummy; p.wgt = &dummy; p.out = const_cast<float*>(&dummy);      // (never dereferenced: the rule only asks whether the operands exist)
     return gemm_pick_config(p, dtype);
 }
 

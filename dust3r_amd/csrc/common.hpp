@@ -19,6 +19,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+// Probe switches. The default build (no -DD3R_PROBES) reads only the documented product / A-B switches from the environment and does not
+// instantiate the kernels that exist for ablations only; `D3R_PROBES=1 python -m dust3r_amd.build` (tools/, profiles/ probes) compiles them back in.
+// d3r_build_has_probes() (include/dust3r_hip.h) reports which build is loaded; tests of probe-only variants skip on a default build.
+#ifdef D3R_PROBES
+constexpr bool kProbes = true;
+static inline const char* probe_env(const char* name) { return getenv(name); }
+#else
+constexpr bool kProbes = false;
+static inline const char* probe_env(const char*) { return nullptr; }
+#endif
 
 #define D3R_BF16 0
 #define D3R_F16 1

@@ -356,7 +356,7 @@ template <int DT> static void launch_upsample_t(const void* in, void* out, void*
                                                 hipStream_t s) {
     // non-temporal stores of the x2 maps: measured 13.41 -> 12.75 ms of "other" kernels per step, forward 218.7 -> 219.6 pairs/s
     // (profiles/r02_f8/bench_upsample_nt.log); D3R_UPSAMPLE_NT=0: plain stores
-    static const bool nt = [] { const char* e = getenv("D3R_UPSAMPLE_NT"); return e ? e[0] != '0' : true; }();
+    static const bool nt = [] { const char* e = probe_env("D3R_UPSAMPLE_NT"); return e ? e[0] != '0' : true; }();
     const char* e_v1 = getenv("D3R_UPSAMPLE_V1");            // 1: the one-output-pixel-per-thread kernel (A/B, parity tests); read per launch
     if (!(e_v1 && e_v1[0] == '1') && C % 8 == 0 && cstride % 8 == 0) {
         const int blocks = B * ((Ho + 1) / 2);

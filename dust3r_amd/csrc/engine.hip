@@ -75,7 +75,8 @@ struct DptHead {
 // GPU_MAX_HW_QUEUES) in creation order: with a stream per engine, the n-th engine of a process could find its second stream on the caller's own hardware queue -- the
 // two decoder sides then run one after the other (measured on MI355X: the THIRD engine created in a process took 13.1 ms per one-pair call against 10.1 ms for the
 // first, second and fourth; profiles/r05_y/ln_inline3.log). One process-wide stream per role keeps every engine on the placement the first one got. Stream order only
-// adds dependencies, so engines driven from different host threads stay correct (their side work serialises on the shared stream).
+// adds dependencies; what it costs: engines on one device are NOT independent any more -- their side-stream halves serialise, and the enqueue of a forward is a
+// process-wide critical section (run_phases: a capture of one engine must not see another engine's launches). Documented in include/dust3r_hip.h (d3r_model_create).
 static hipStream_t shared_stream(int role) {
     static std::mutex mu;
     static std::map<std::pair<int, int>, hipStream_t> pool;
@@ -117,6 +118,10 @@ struct d3r_model {
     Lin lin_head[2];
     float* rope_table = nullptr;
     void* zero_page = nullptr;
+    // split-K of the small-batch forwards (kernels.hpp GemmParams::splitk): partial-tile slabs and arrival counters, one set per stream of the forward (main, side)
+    static constexpr size_t SK_SLAB_FLOATS = (size_t)8 << 20; static constexpr int SK_CNT = 1024;
+    float* sk_slab[2] = {nullptr, nullptr}; unsigned* sk_cnt[2] = {nullptr, nullptr};
+    bool splitk_on = true;       // D3R_SPLITK=0 at creation: never (every launch then sums K in one block: a batch is bit-identical to its one-pair calls)
     void* ws = nullptr; size_t ws_bytes = 0;
     void* stage = nullptr; size_t stage_bytes = 0;   // load-time staging of host tensors
     // the two decoder sides (and the two heads) are independent inside a layer: side 1 runs on this second stream
@@ -389,6 +394,7 @@ struct Ctx {
     d3r_model* m;
     hipStream_t st;
     int rc = D3R_OK;
+    hipStream_t st0 = nullptr;    // the caller's stream (st moves between it and the engine's helper streams)
     void chk(hipError_t e) { if (e != hipSuccess && rc == D3R_OK) rc = 1000 + (int)e; }
     // profiling: one event BEFORE every launch; a launch's duration is event[i+1] - event[i]
     void mark(int kind, double work, int M = 0, int N = 0, int K = 0) {
@@ -420,6 +426,12 @@ void gemm_linear(Ctx& c, const void* act, int lda, const Lin& L, int M, int epi,
     p.epi = epi; p.out = out; p.ldo = ldo; p.res1 = res1; p.ldr = ldo; p.out2 = out2; p.ldo2 = ldo2; p.flags = flags;
     if (stats.rstd) { p.ln_rstd = stats.rstd; p.ln_nmr = stats.nmr; p.ln_colsum = L.ln_s; p.bias = L.b_fold; p.ln_part_in = stats.part_in; p.ln_inv_c = 1.0f / (float)L.K; }
     p.ln_part = part;
+    {   // split-K buffers of this launch's stream (launch_gemm decides whether the launch splits; never while profiling: one event per launch)
+        const int sset = c.st == c.st0 ? 0 : (c.st == c.m->side ? 1 : -1);
+        if (c.m->splitk_on && sset >= 0 && c.m->sk_slab[sset] && !c.m->prof_on) {
+            p.splitk = 0; p.sk_slab = c.m->sk_slab[sset]; p.sk_cnt = c.m->sk_cnt[sset]; p.sk_slab_floats = d3r_model::SK_SLAB_FLOATS; p.sk_cnt_n = d3r_model::SK_CNT;
+        }
+    }
     c.mark(prf_kind((L.dt == D3R_F16F8 || L.dt == D3R_F16X2F8) ? PRF_GEMM_F8 : PRF_GEMM, gemm_pick_config(p, L.dt)), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(L.dt, p, c.st));
 }
@@ -523,15 +535,23 @@ extern "C" int d3r_model_create(d3r_model** out, const d3r_model_config* cfg) {
     if (!build_slots(m)) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
     m->rope_table = (float*)m->dalloc(512 * 16 * 2 * sizeof(float));
     m->zero_page = m->dalloc(4096);
+    // split-K of the small-batch forwards: implemented, deterministic, and measured a LOSS on MI355X (profiles/r06_c: one pair 9.86 ms without, 9.99 ms with it on
+    // the 64 x 64 tile, 12.5-13.7 ms on 128 x 128 tiles split 4-8 ways) -- opt-in (D3R_SPLITK=1 at create, D3R_MODEL_OPT_SPLIT_K), off by default
+    { const char* e = getenv("D3R_SPLITK"); m->splitk_on = e && e[0] == '1'; }
+    for (int i = 0; i < 2 && m->dt == D3R_F16X3; ++i) {
+        m->sk_slab[i] = (float*)m->dalloc(d3r_model::SK_SLAB_FLOATS * sizeof(float));
+        m->sk_cnt[i] = (unsigned*)m->dalloc(d3r_model::SK_CNT * sizeof(unsigned));
+        if (!m->sk_slab[i] || !m->sk_cnt[i] || hipMemset(m->sk_cnt[i], 0, d3r_model::SK_CNT * sizeof(unsigned)) != hipSuccess) { m->sk_slab[i] = nullptr; m->sk_cnt[i] = nullptr; }
+    }
     if (!m->rope_table || !m->zero_page) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
     if (launch_rope_table(m->rope_table, 512, cfg->rope_freq, 1.0f, nullptr) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_LAUNCH; }
     m->side = shared_stream(0);
     if (!m->side || hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) != hipSuccess) { d3r_model_destroy(m); return D3R_ERR_ALLOC; }
     if (const char* e = getenv("D3R_GRAPH_MAX_PAIRS")) m->graph_max_pairs = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char* e = getenv("D3R_ENC_SPLIT")) m->enc_split_max = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = probe_env("D3R_ENC_SPLIT")) m->enc_split_max = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("D3R_LN_INLINE_ROWS")) m->ln_inline_rows = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char* e = getenv("D3R_DEC_KV_AHEAD")) m->kv_ahead_rows = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = probe_env("D3R_DEC_KV_AHEAD")) m->kv_ahead_rows = atoi(e) > 0 ? atoi(e) : 0;
     if (m->kv_ahead_rows > 0)          // probe only: its two streams and four events exist when it is switched on
         for (int s = 0; s < 2; ++s) {
             m->kvs[s] = shared_stream(1 + s);
@@ -632,6 +652,7 @@ extern "C" int d3r_model_set_option(d3r_model* m, int option, int value) {
     if (!m) return D3R_ERR_INVALID;
     if (option == D3R_MODEL_OPT_PROFILE) { m->prof_on = value != 0; m->prof_rec.clear(); return D3R_OK; }
     if (option == D3R_MODEL_OPT_TWO_STREAMS) { m->two_streams = value != 0; return D3R_OK; }
+    if (option == D3R_MODEL_OPT_SPLIT_K) { hipDeviceSynchronize(); m->drop_graphs(); m->splitk_on = value != 0; return D3R_OK; }
     if (option == D3R_MODEL_OPT_GRAPH_MAX_PAIRS) {
         m->graph_max_pairs = value > 0 ? value : 0;
         if (value <= 0) { hipDeviceSynchronize(); m->drop_graphs(); }     // a replay of the previous call may still be in flight
@@ -838,6 +859,7 @@ size_t forward_impl(d3r_model* m, void* ws, size_t ws_cap, int phases, const flo
     const bool dry = ws == nullptr;
     Arena ar(ws, ws_cap);
     Ctx c{m, st};
+    c.st0 = st;
 
     float* x = (float*)ar.take((size_t)Me * Ce * 4);
     void* xn = ar.take((size_t)M2 * Cmax * eb);
@@ -1172,6 +1194,11 @@ static int finalize_fold(d3r_model* m) {
 
 static int run_phases(d3r_model* m, int phases, const float* img1, const float* img2, int nimg1, int nimg, void* feat, int B, int H1, int W1,
                       int H2, int W2, float* pts1, float* conf1, float* pts2, float* conf2, hipStream_t st) {
+    // The engines of a process share their helper streams (shared_stream above): the ENQUEUE of a forward -- host side only, the device work stays asynchronous --
+    // is therefore one critical section per process. Engines driven from different host threads stay correct (one engine's stream capture cannot swallow another
+    // engine's launches on the shared side stream; fork / join events of two forwards do not interleave); their side-stream halves run in enqueue order.
+    static std::mutex enqueue_mu;
+    std::lock_guard<std::mutex> enqueue_lock(enqueue_mu);
     const int ps = m->cfg.patch_size;
     for (int v = 0; v < 2; ++v) {
         const int H = v ? H2 : H1, W = v ? W2 : W1;

@@ -187,7 +187,10 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     }
     // ---- block -> tile: XCD-contiguous ids, then 8-wide column panels walked row by row ------------------
     const int tiles_n = (p.n_store + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int sk_slice = 0;
+    if (p.splitk > 1) { sk_slice = lid % p.splitk; lid /= p.splitk; }      // a tile's K slices: consecutive ids = one XCD (the combine reads same-XCD slabs)
+    const int sk_tile = lid;
     const int PANEL = p.panel;
     const int per_panel = PANEL * tiles_m;
     const int panel = lid / per_panel, rem_p = lid - panel * per_panel;
@@ -314,7 +317,15 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     // kt is visible to every wave; every wave is done reading the stage of step kt-1) -> issue the DMA of step
     // kt+NSTAGE-1 into that freed stage -> math on step kt. NSTAGE-1 steps of HBM/L2 latency are covered.
     constexpr int NS = CF::NSTAGE, LPS = CF::LPS;
-    const int nk = p.K / KT;
+    int nk = p.K / KT;
+    if (p.splitk > 1) {               // this block's share of the K steps (launch_gemm: nn.Linear operands, the plain loop, nk % splitk == 0)
+        nk /= p.splitk;
+        const size_t skip = (size_t)sk_slice * nk * KTB;
+#pragma unroll
+        for (int q = 0; q < CF::WPASS; ++q) wsrc[q] += skip;
+#pragma unroll
+        for (int q = 0; q < CF::APASS; ++q) arow[q] += skip;
+    }
     if constexpr (CF::PP == 3) {
         // ---- asymmetric ring: activations two K steps ahead, weights one ------------------------------------------------------
         // Measured with the per-block trace (tools/gpu_probe.py gemmtrace): next to other blocks' epilogue traffic a K step of the
@@ -1152,6 +1163,45 @@ __global__ __launch_bounds__(CF::NT, CF::MINW) void gemm_kernel(GemmParams p) {
     }
     }  // !PP
 
+    // ---- split-K: partial tile -> slab, ticket, the last arriver adds the slices up in slice order ------------------------------------------------
+    if constexpr (DT == D3R_F16X3 && CF::PP == 0) {
+        if (p.splitk > 1) {
+            __builtin_amdgcn_s_setprio(0);
+            // Partial tiles travel through memory operations of AGENT scope (global_store / global_load ... sc1: written through to, and read from, the
+            // level every XCD sees) instead of ordinary stores bracketed by release / acquire fences: on gfx950 an agent-scope release is a write-back of
+            // the XCD's whole L2 (buffer_wbl2) and an acquire invalidates it (buffer_inv) -- per BLOCK, under the K loops of the other blocks of the launch.
+            // Measured with the fences (profiles/r06_c/splitk_probe_fences.log): one pair 9.99 -> 11.36 ms, i.e. split-K LOST 9 us per launch.
+            float* slab = p.sk_slab + ((size_t)sk_tile * p.splitk) * (BM * BN) + (size_t)wave * (FI * FJ * 256) + lane;
+            float* mine = slab + (size_t)sk_slice * (BM * BN);
+#pragma unroll
+            for (int a = 0; a < FI; ++a)
+#pragma unroll
+                for (int b = 0; b < FJ; ++b)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) __hip_atomic_store(mine + ((a * FJ + b) * 4 + c) * 64, acc[a][b][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // publish (cdna_hip_programming.md guideline 16, counter form): every wave's stores acknowledged -> block barrier -> ticket
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* flag = reinterpret_cast<unsigned*>(smem);      // the K loop's LDS stages are free (every wave is past its last fragment read)
+            if (tid == 0) *flag = __hip_atomic_fetch_add(p.sk_cnt + sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const unsigned ticket = *flag;
+            if (ticket != (unsigned)(p.splitk - 1)) return;          // not the last slice of this tile: done
+            if (tid == 0) __hip_atomic_store(p.sk_cnt + sk_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+            // ((s0 + s1) + s2) + ...: every slice read back from its slab (its own too), so the sum does not depend on which block arrived last
+#pragma unroll
+            for (int a = 0; a < FI; ++a)
+#pragma unroll
+                for (int b = 0; b < FJ; ++b)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float t = __hip_atomic_load(slab + ((a * FJ + b) * 4 + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int sl = 1; sl < p.splitk; ++sl)
+                            t += __hip_atomic_load(slab + (size_t)sl * (BM * BN) + ((a * FJ + b) * 4 + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        acc[a][b][c] = t;
+                    }
+        }
+    }
     // ---- epilogue ------------------------------------------------------------------------------
     __builtin_amdgcn_s_setprio(0);
     if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 8 + 2] = (unsigned long long)wall_clock64();
@@ -1936,12 +1986,12 @@ template <int DT, class CF> static hipError_t launch_cfg(const GemmParams& p, hi
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<DT, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
         attr_done.fetch_or(dev_bit, std::memory_order_relaxed);
     }
-    const int grid = cdiv(p.M, CF::BM) * cdiv(p.n_store, CF::BN);
+    const int grid = cdiv(p.M, CF::BM) * cdiv(p.n_store, CF::BN) * (p.splitk > 1 ? p.splitk : 1);
     GemmParams q = p;
     {   // first-round stagger (see the kernel): spread = factor x (epilogue bytes of the resident tiles / ~4.5 TB/s)
-        const char* e_st = getenv("D3R_GEMM_STAGGER");       // default off: measured no gain (profiles/README.md), costs half a burst per launch; read per launch (probes toggle it)
+        const char* e_st = probe_env("D3R_GEMM_STAGGER");       // default off: measured no gain (profiles/README.md), costs half a burst per launch; read per launch (probes toggle it)
         const float factor = e_st ? (float)atof(e_st) : 0.0f;
-        const char* e_sm = getenv("D3R_GEMM_STAGGER_MODE");
+        const char* e_sm = probe_env("D3R_GEMM_STAGGER_MODE");
         const int mode = e_sm ? atoi(e_sm) : 0;
         static const DevInfo dev = dev_info();
         const int resident = dev.cus * (CF::LDS * 2 <= 160 * 1024 ? 2 : 1);
@@ -1986,6 +2036,11 @@ static int device_cus() {
 // the tile configuration a launch of (p, dt) RUNS on -- what the engine's profile records and d3r_gemm_tile_config reports: the heuristic's
 // choice, then the remaps launch_t applies for operand types that do not have every shape
 static int device_cus();
+// D3R_GEMM_CFG=0..9: the tile configuration pinned from the environment (parity tests, A/B runs); read per call, -1 = not set
+static int env_forced_cfg() {
+    const char* e = getenv("D3R_GEMM_CFG");
+    return (e && e[0] >= '0' && e[0] <= '9' && e[1] == 0) ? e[0] - '0' : -1;
+}
 int gemm_p4_mode() {
     const char* e = getenv("D3R_GEMM_PERSIST");
     return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1;
@@ -1995,7 +2050,7 @@ int gemm_p4_mode() {
 // the typed-residual projections at K <= 1024 348 -> 362, typed stores +4..12 % -- ties at K = 4096 (fc2: the K loop dominates; the one-tile-per-block
 // kernels keep it) and loses where its 256 x 128 tiles leave the last round of CUs mostly empty (the decoder's N = 768 GEMMs: 576 tiles = 2.25 rounds).
 static bool use_p4(const GemmParams& p, int dt) {
-    if (dt != D3R_F16X3 || p.force_cfg >= 0 || getenv("D3R_GEMM_CFG")) return false;
+    if (dt != D3R_F16X3 || p.force_cfg >= 0 || env_forced_cfg() >= 0) return false;
     const int mode = gemm_p4_mode();
     if (mode == 0 || !gemm_p4_eligible(p, dt)) return false;
     if (mode == 1) return true;
@@ -2023,15 +2078,14 @@ static int pick_config_raw(const GemmParams& p, int dt) {
     const bool ok256 = cdiv(p.n_store, 256) * 256 <= n_rows && (p.epi != EPI_HEADS || p.head_c % 256 == 0);
     int forced = p.force_cfg;
     if (forced < 0) {   // D3R_GEMM_CFG=0|1|2|3 pins the tile configuration (parity tests, probes); infeasible choices are ignored
-        const char* e = getenv("D3R_GEMM_CFG");
-        if (e && e[0] >= '0' && e[0] <= '9' && e[1] == 0) forced = e[0] - '0';
+        forced = env_forced_cfg();
     }
     if (forced == GEMM_CFG_384x192 && dt == D3R_F16X3 && !heads && p.epi != EPI_HEADS && p.epi != EPI_HEAD4 && p.amode == AMODE_LINEAR && cdiv(p.n_store, 192) * 192 <= n_rows) return forced;
     if (forced == GEMM_CFG_128 || forced == GEMM_CFG_64 || (forced == GEMM_CFG_256 && ok256) ||
         ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128 || forced == GEMM_CFG_256x128W4 || forced == GEMM_CFG_256x128R) && !heads) || ((forced == GEMM_CFG_256S4 || forced == GEMM_CFG_256PP) && ok256))
         return forced;
     if (p.epi == EPI_F32 && p.K <= 1024) {   // probe: tile of the HBM-heavy residual-stream epilogues at short K (D3R_GEMM_F32CFG=0|2|4)
-        if (const char* e = getenv("D3R_GEMM_F32CFG"))
+        if (const char* e = probe_env("D3R_GEMM_F32CFG"))
             if ((e[0] == '0' || e[0] == '2' || e[0] == '4') && e[1] == 0) return e[0] - '0';
     }
     if (!heads && p.n_store <= 128) {
@@ -2048,7 +2102,7 @@ static int pick_config_raw(const GemmParams& p, int dt) {
     // baseline run); WITHOUT the K <= 1024 projections 191.7 -> 190.9 -- so the rule is "every eligible launch". D3R_GEMM_T384=0: never; =1: not the
     // fp32-residual projections at K <= 1024 (the probe of that A/B).
     if (dt == D3R_F16X3 && !heads && p.epi != EPI_HEADS && p.epi != EPI_HEAD4 && p.amode == AMODE_LINEAR && p.n_store % 192 == 0 && cdiv(p.n_store, 192) * 192 <= n_rows) {
-        const char* e384 = getenv("D3R_GEMM_T384");
+        const char* e384 = probe_env("D3R_GEMM_T384");
         const long t384 = (long)cdiv(p.M, 384) * cdiv(p.n_store, 192);
         const bool short_res = p.epi == EPI_F32 && p.K <= 1024;
         const int cus = device_cus();       // whole rounds of THIS device's compute units (256 on MI355X; a partitioned device has fewer)
@@ -2061,7 +2115,7 @@ static int pick_config_raw(const GemmParams& p, int dt) {
     // SIMD overlap only by half, tools/issue_probe.hip) or the K loop dominates (fc2): default = those projections only.
     // D3R_GEMM_R=0: never; =1: every eligible launch (the A/B of the round).
     if (dt == D3R_F16X3 && !heads && p.epi != EPI_HEADS && p.n_store > 128) {
-        const char* e_r = getenv("D3R_GEMM_R");      // read per call, like the other probes (tests move it with monkeypatch)
+        const char* e_r = probe_env("D3R_GEMM_R");      // read per call, like the other probes (tests move it with monkeypatch)
         const int r_on = e_r ? atoi(e_r) : -1;
         const long tiles = (long)cdiv(p.M, 256) * cdiv(p.n_store, 128);
         if (r_on == 1 && tiles >= 512) return GEMM_CFG_256x128R;
@@ -2073,7 +2127,7 @@ static int pick_config_raw(const GemmParams& p, int dt) {
     // best or within noise of it everywhere (profiles/r03_f/latency_small_tiles.log).
     if (dt == D3R_F16X3 && p.n_store > 128) {
         long t64 = 200;
-        if (const char* e = getenv("D3R_GEMM_T64")) t64 = atol(e);
+        if (const char* e = probe_env("D3R_GEMM_T64")) t64 = atol(e);
         if ((long)cdiv(p.M, 128) * cdiv(p.n_store, 128) < t64) return GEMM_CFG_64;
     }
     const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.n_store, 256);
@@ -2081,15 +2135,15 @@ static int pick_config_raw(const GemmParams& p, int dt) {
     // tile's LDS read traffic per MFMA is twice as high), so it pays from a single round of resident blocks on: measured +1.5 % on the
     // forward with the decoder's 24576 x 768 GEMMs (288 tiles, two such launches side by side on the two streams) on it
     long t256 = (dt == D3R_F16F8 || dt == D3R_F16X2F8) ? 250 : 700;     // probes: D3R_GEMM_T256 moves the 256x256 / 128x128 crossover, D3R_GEMM_MID=2 sends the shapes below it to 256x128
-    if (const char* e = getenv("D3R_GEMM_T256")) t256 = atol(e);
+    if (const char* e = probe_env("D3R_GEMM_T256")) t256 = atol(e);
     if (ok256 && tiles256 >= t256) {
         // nn.Linear operands: the ping-pong schedule measured 1-8 % ahead of the plain 2-stage loop (profiles/r01_call13);
         // implicit-GEMM operands: behind it (the per-tap address arithmetic sits in the load segment) -> plain loop
-        const char* e_pp = getenv("D3R_GEMM_PP");
+        const char* e_pp = probe_env("D3R_GEMM_PP");
         const bool pp = e_pp ? e_pp[0] == '1' : false;
         return (pp && p.amode == AMODE_LINEAR) ? GEMM_CFG_256PP : GEMM_CFG_256;
     }
-    if (const char* e = getenv("D3R_GEMM_MID")) if (e[0] == '2' && !heads) return GEMM_CFG_256x128;
+    if (const char* e = probe_env("D3R_GEMM_MID")) if (e[0] == '2' && !heads) return GEMM_CFG_256x128;
     return GEMM_CFG_128;
 }
 
@@ -2102,16 +2156,17 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
     if (cfg == GEMM_CFG_384x192 && DT != D3R_F16X3) cfg = GEMM_CFG_128;           // and the 384 x 192 one
     // the fused head tail needs a wave to hold every output channel of its rows: waves stacked along m, 128 columns per wave
     if (p.epi == EPI_HEAD4 && (DT != D3R_F16X3 || !(cfg == GEMM_CFG_512x128 || cfg == GEMM_CFG_256x128R))) return hipErrorInvalidValue;
-    if ((cfg == GEMM_CFG_256S4 || cfg == GEMM_CFG_256PP) && SPLIT) cfg = GEMM_CFG_256;
+    if ((cfg == GEMM_CFG_256S4 || cfg == GEMM_CFG_256PP) && (SPLIT || !kProbes)) cfg = GEMM_CFG_256;      // the four-wave 256 x 128, four-stage and ping-pong shapes never won a
+    if (cfg == GEMM_CFG_256x128W4 && !kProbes) cfg = GEMM_CFG_256x128;                                       // default (profiles/r01_*): compiled in probe builds only (-DD3R_PROBES)
     // the ping-pong schedule has no operand-role swap: attention projections only through the wide V^T route
     if (cfg == GEMM_CFG_256PP && p.epi == EPI_HEADS && !((DT == D3R_BF16 || DT == D3R_F16) && (p.ntok & 63) == 0 && !(p.flags & GF_NOWIDE))) cfg = GEMM_CFG_256;
-    if constexpr (!SPLIT) {
+    if constexpr (!SPLIT && kProbes) {
         if (cfg == GEMM_CFG_256x128W4) return launch_cfg<DT, Cfg256x128w4>(p, s);
         if (cfg == GEMM_CFG_256S4) return launch_cfg<DT, Cfg256s4>(p, s);
         if (cfg == GEMM_CFG_256PP) return launch_cfg<DT, Cfg256pp>(p, s);
     }
-    if constexpr (DT != D3R_F16F8 && DT != D3R_F16X2F8) {
-        const char* e_a3 = getenv("D3R_GEMM_A3");
+    if constexpr (kProbes && DT != D3R_F16F8 && DT != D3R_F16X2F8) {
+        const char* e_a3 = probe_env("D3R_GEMM_A3");
         const bool a3 = e_a3 ? e_a3[0] != '0' : false;
         if (a3 && cfg == GEMM_CFG_256) return launch_cfg<DT, Cfg256a3>(p, s);
     }
@@ -2119,18 +2174,24 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
         if (cfg == GEMM_CFG_384x192) return launch_cfg<DT, Cfg384x192>(p, s);
         if (cfg == GEMM_CFG_256x128R) return launch_cfg<DT, Cfg256x128r>(p, s);
         if (cfg == GEMM_CFG_64) {
-            const char* e_ns = getenv("D3R_GEMM_64NS");     // probe: LDS ring depth of the 64 x 64 tile (2 | 3 | 4)
+            const char* e_ns = probe_env("D3R_GEMM_64NS");     // probe: LDS ring depth of the 64 x 64 tile (2 | 3 | 4)
             const int ns = e_ns ? atoi(e_ns) : 3;             // measured (profiles/r03_f): one pair 14.56 ms on the 128 x 128 tile, 12.36 / 10.38 / 10.48 ms with 2 / 3 / 4 slots
-            return ns == 2 ? launch_cfg<DT, Cfg64>(p, s) : ns == 3 ? launch_cfg<DT, Cfg64s3>(p, s) : launch_cfg<DT, Cfg64s4>(p, s);
+            if constexpr (kProbes) {
+                if (ns == 2) return launch_cfg<DT, Cfg64>(p, s);
+                if (ns == 4) return launch_cfg<DT, Cfg64s4>(p, s);
+            }
+            (void)ns;
+            return launch_cfg<DT, Cfg64s3>(p, s);
         }
         // split-fp16: D3R_GEMM_X3SW=1 selects the software-pipelined K loop. Measured on MI355X (profiles/r02_*): equal to the plain
         // two-stage loop on the 256-wide tiles, 10-15 % behind on the 128 x 128 tile -- the K loop is not where the time goes (the
         // same launches without their epilogue run 30 % faster in either form), so the plain loop stays the default.
         // D3R_GEMM_X3IL=1 / 0: nn.Linear launches on the 256 x 256 tile with the DMA pieces interleaved with the MFMA rows (bit-identical)
-        const char* e_il = getenv("D3R_GEMM_X3IL");
+        if constexpr (kProbes) {
+        const char* e_il = probe_env("D3R_GEMM_X3IL");
         const bool x3il = e_il ? e_il[0] == '1' : false;
         if (x3il && cfg == GEMM_CFG_256 && p.amode == AMODE_LINEAR && (size_t)512 * p.lda * 4 < (1ull << 32) && (size_t)512 * p.K * 4 < (1ull << 32)) return launch_cfg<DT, Cfg256il>(p, s);
-        const char* e_sw = getenv("D3R_GEMM_X3SW");
+        const char* e_sw = probe_env("D3R_GEMM_X3SW");
         const bool sw = e_sw ? e_sw[0] == '1' : false;
         if (sw) {
             switch (cfg) {
@@ -2140,23 +2201,25 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
                 default: return launch_cfg<DT, Cfg128sw>(p, s);
             }
         }
+        }
     }
     if constexpr (DT == D3R_F16F8) {
         // two blocks per CU (256 x 128 tile, four waves, 64-byte K steps): one block's K loop under the other's epilogue. The attention
         // projections keep the square tile (their V^T regions swap the MFMA operand roles). D3R_GEMM_F8W4=1 / 0.
-        const char* e_w4 = getenv("D3R_GEMM_F8W4");
+        const char* e_w4 = probe_env("D3R_GEMM_F8W4");
         const int w4 = e_w4 ? (e_w4[0] == '1' ? 1 : 0) : 0;
-        if (w4 == 1 && cfg == GEMM_CFG_256 && p.epi != EPI_HEADS && p.n_store % 128 == 0) return launch_cfg<DT, Cfg256x128f8>(p, s);
+        if constexpr (kProbes) { if (w4 == 1 && cfg == GEMM_CFG_256 && p.epi != EPI_HEADS && p.n_store % 128 == 0) return launch_cfg<DT, Cfg256x128f8>(p, s); }
+        (void)w4;
         // DMA pieces interleaved with the MFMA rows (PP = 4). Measured on MI355X (profiles/r02_f8/bench_f8_il.log): +3 % on the 256-wide
         // tiles (one block per CU: behind the barrier neither wave of a SIMD has MFMAs to issue), -2.5 % on the 128 x 128 tile (the
         // CU's second block already fills that gap). D3R_GEMM_F8IL=0 / 1 forces the burst / interleaved loop everywhere.
-        static const int il = [] { const char* e = getenv("D3R_GEMM_F8IL"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+        static const int il = [] { const char* e = probe_env("D3R_GEMM_F8IL"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
         if (il == 1 || (il < 0 && cfg != GEMM_CFG_128)) {
             switch (cfg) {
                 case GEMM_CFG_256: return launch_cfg<DT, Cfg256il>(p, s);
                 case GEMM_CFG_256x128: return launch_cfg<DT, Cfg256x128il>(p, s);
                 case GEMM_CFG_512x128: return launch_cfg<DT, Cfg512x128il>(p, s);
-                default: return launch_cfg<DT, Cfg128il>(p, s);
+                default: if constexpr (kProbes) return launch_cfg<DT, Cfg128il>(p, s); break;
             }
         }
     }
@@ -2171,11 +2234,17 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
         }
     }
     if constexpr (DT == D3R_F16X2F8) {      // nn.Linear matrices of the transformer blocks only (N >= 768): the two square tiles; D3R_GEMM_X2IL=0 / 1:
-        const char* e_il = getenv("D3R_GEMM_X2IL");     // DMA pieces of the next step in one burst behind the barrier / interleaved with the MFMA rows (default: on the 256-wide tile)
+        const char* e_il = probe_env("D3R_GEMM_X2IL");     // DMA pieces of the next step in one burst behind the barrier / interleaved with the MFMA rows (default: on the 256-wide tile)
         const int il = e_il ? (e_il[0] == '1' ? 1 : 0) : -1;
-        if (cfg == GEMM_CFG_256) return (il != 0) ? launch_cfg<DT, Cfg256il>(p, s) : launch_cfg<DT, Cfg256>(p, s);
-        return il == 1 ? launch_cfg<DT, Cfg128il>(p, s) : launch_cfg<DT, Cfg128>(p, s);
+        if constexpr (kProbes) {
+            if (cfg == GEMM_CFG_256 && il == 0) return launch_cfg<DT, Cfg256>(p, s);
+            if (cfg != GEMM_CFG_256 && il == 1) return launch_cfg<DT, Cfg128il>(p, s);
+        }
+        (void)il;
+        return cfg == GEMM_CFG_256 ? launch_cfg<DT, Cfg256il>(p, s) : launch_cfg<DT, Cfg128>(p, s);
     } else {
+    if constexpr (DT == D3R_F16F8 && !kProbes) return launch_cfg<DT, Cfg128>(p, s);     // every other shape left through the interleaved loop above
+    else
     switch (cfg) {
         case GEMM_CFG_256: return launch_cfg<DT, Cfg256>(p, s);
         case GEMM_CFG_256x128: return launch_cfg<DT, Cfg256x128>(p, s);
@@ -2186,7 +2255,7 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
 }
 
 bool conv_k_slice_major() {
-    static const bool v = [] { const char* e = getenv("D3R_CONV_KORDER"); return !(e && e[0] == '0'); }();   // D3R_CONV_KORDER=0: tap-major (probe)
+    static const bool v = [] { const char* e = probe_env("D3R_CONV_KORDER"); return !(e && e[0] == '0'); }();   // D3R_CONV_KORDER=0: tap-major (probe)
     return v;
 }
 
@@ -2197,24 +2266,24 @@ void gemm_set_trace(unsigned long long* buf, size_t capacity_blocks) { g_trace_b
 hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     if (g_trace_buf && (size_t)cdiv(p.M, 128) * cdiv(p.n_store, 128) <= g_trace_cap) p.trace = g_trace_buf;   // capacity for the smallest tile
-    if (const char* e = getenv("D3R_GEMM_NOSTORE")) if (e[0] == '1') p.flags |= GF_NOSTORE;
+    if (const char* e = probe_env("D3R_GEMM_NOSTORE")) if (e[0] == '1') p.flags |= GF_NOSTORE;
     // (the folded-LayerNorm producer launches keep their wide epilogue: it is where the row sums and the typed residual stream are written)
     if (const char* e = getenv("D3R_GEMM_NOWIDE")) if (e[0] == '1' && !p.ln_part && !(p.flags & GF_X3RES)) p.flags |= GF_NOWIDE;
     // measurement aid (results INVALID): the fp16 + fp8 K loop issues the MFMA mix of a 2.5-unit scheme -- per 64 k four f16 MFMAs (hi.hi and
     // hi.w_lo on the f16 pipe) and half an e4m3 MFMA (a_lo.w_hi, K = 128 spans two groups) = 80 MFMA cycles instead of 64 (fp16f8) / 96 (fp16x3)
-    if (const char* e = getenv("D3R_F8_PROXY")) if (e[0] == '1') {
+    if (const char* e = probe_env("D3R_F8_PROXY")) if (e[0] == '1') {
         p.f8_proxy = 1;
         static std::atomic<bool> told{false};
         if (!told.exchange(true)) fprintf(stderr, "[dust3r_amd] D3R_F8_PROXY=1: MEASUREMENT AID -- the fp16 + fp8 K loops issue a different MFMA mix and every result of an fp16f8 engine is INVALID\n");
     }
     // wide epilogues store with the non-temporal policy (measured +3..10 % on isolated GEMMs, +1 % on the forward); D3R_GEMM_NT=0: plain stores
-    { const char* e = getenv("D3R_GEMM_NT"); if (!e || e[0] != '0') p.flags |= GF_NTSTORE; }
+    { const char* e = probe_env("D3R_GEMM_NT"); if (!e || e[0] != '0') p.flags |= GF_NTSTORE; }
     const int kt = 128 / (int)dt_bytes(dt);
     if (p.M <= 0 || p.n_pad % 128 != 0 || p.n_store > p.n_pad || p.K % kt != 0 || p.K <= 0) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV && (p.Cin % kt != 0 || p.zero_page == nullptr)) return hipErrorInvalidValue;
     if (p.amode == AMODE_CONV) p.kslice_major = conv_k_slice_major() ? 1 : 0;
-    if (const char* e = getenv("D3R_GEMM_X3NT")) p.x3res_nt = e[0] == '1' ? 1 : 0;
-    if (const char* e = getenv("D3R_GEMM_PANEL")) { const int v = atoi(e); if (v >= 1 && v <= 64) p.panel = v; }
+    if (const char* e = probe_env("D3R_GEMM_X3NT")) p.x3res_nt = e[0] == '1' ? 1 : 0;
+    if (const char* e = probe_env("D3R_GEMM_PANEL")) { const int v = atoi(e); if (v >= 1 && v <= 64) p.panel = v; }
     if (p.epi == EPI_HEADS && p.head_c % 128 != 0 && p.head_c < (1 << 29)) return hipErrorInvalidValue;
     if (p.epi == EPI_HEAD4 && (p.n_store > 128 || p.n_store % 4 != 0 || !p.res1 || !p.res2 || !p.out || !p.out2)) return hipErrorInvalidValue;
     // folded LayerNorm (kernels.hpp): statistics come out of the wide fp32 epilogue only; the consumer side exists for split-fp16 operands, typed / GELU / head outputs
@@ -2230,6 +2299,27 @@ hipError_t launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
                             (p.epi == EPI_T && (p.res1 || p.out2)) || ((p.epi == EPI_T || p.epi == EPI_GELU) && (p.ldo % 64 != 0 || p.n_store % 4 != 0))))
         return hipErrorInvalidValue;
     if (use_p4(p, dt)) return launch_gemm_p4(p, s);
+    {   // split-K (kernels.hpp): only with the caller's buffers, split-fp16 nn.Linear launches of the small-batch forwards (the problems the heuristic sends to the
+        // 64 x 64 tile: fewer than 200 tiles of 128 x 128), the plain K loop. Probe knobs (probe builds): D3R_SK_TILE=64|128 the tile the split launch runs on,
+        // D3R_SK_BLOCKS the most blocks a launch may have after the split, D3R_SK_MINSTEPS the fewest K steps (of 32) per slice.
+        int sk = 1;
+        if (p.sk_slab && p.sk_cnt && p.splitk != 1 && dt == D3R_F16X3 && p.amode == AMODE_LINEAR && !p.trace && !(p.flags & GF_NOSTORE) && p.force_cfg < 0 &&
+            gemm_pick_config(p, dt) == GEMM_CFG_64) {
+            const int cus = device_cus();
+            int tile = 64, minsteps = 16;
+            long maxblocks = (long)cus * 3;
+            if (const char* e = probe_env("D3R_SK_TILE")) tile = atoi(e) == 128 ? 128 : 64;
+            if (const char* e = probe_env("D3R_SK_BLOCKS")) maxblocks = atol(e);
+            if (const char* e = probe_env("D3R_SK_MINSTEPS")) minsteps = atoi(e);
+            const long tiles = (long)cdiv(p.M, tile) * cdiv(p.n_store, tile);
+            const int nk32 = p.K / 32;
+            for (int c : {8, 6, 4, 3, 2}) {
+                if (tiles * c <= maxblocks && nk32 % c == 0 && nk32 / c >= minsteps && (size_t)tiles * c * tile * tile <= p.sk_slab_floats && tiles <= p.sk_cnt_n) { sk = c; break; }
+            }
+            if (sk > 1 && tile == 128) p.force_cfg = GEMM_CFG_128;
+        }
+        p.splitk = sk;
+    }
 #ifdef D3R_GEMM_ONLY_DT      // development builds (-DD3R_GEMM_ONLY_DT=4): one precision mode only, a tenth of the compile time
     if (dt == D3R_GEMM_ONLY_DT) return launch_t<D3R_GEMM_ONLY_DT>(p, s);
 #else

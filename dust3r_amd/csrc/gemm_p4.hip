@@ -595,7 +595,7 @@ template <int EPK, int NF, bool L32 = false, int DBG = 0> static hipError_t laun
     }
     const int tiles_m = p.M / p4::BM, tiles_n = p.n_store / p4::BN, ntiles = tiles_m * tiles_n;
     int grid = cus < ntiles ? cus : ntiles;
-    if (const char* e = getenv("D3R_P4_GRID")) { const int g = atoi(e); if (g >= 8 && g < grid) grid = g; }      // probe: fewer resident blocks (more tiles per block)
+    if (const char* e = probe_env("D3R_P4_GRID")) { const int g = atoi(e); if (g >= 8 && g < grid) grid = g; }      // probe: fewer resident blocks (more tiles per block)
     grid &= ~7;                          // XCD-contiguous tile ranges need the grid stride to keep a block on its XCD (v & 7 == blockIdx & 7)
     if (grid < 8) return hipErrorInvalidValue;
     hipLaunchKernelGGL((p4::gemm_p4_kernel<EPK, NF, L32, DBG>), dim3(grid), dim3(p4::NT), p4::LDS, s, p, tiles_m, tiles_n, ntiles);
@@ -610,7 +610,7 @@ hipError_t launch_gemm_p4(const GemmParams& p, hipStream_t s) {
     if (p.epi == EPI_F32) return p.ln_part ? launch_p4<p4::EPK_X3RES_LN, 2>(p, s) : launch_p4<p4::EPK_X3RES, 2>(p, s);
     if (p.epi == EPI_GELU) return launch_p4<p4::EPK_GELU, 2>(p, s);
 #ifdef D3R_PROBES
-    if (const char* e = getenv("D3R_P4_DBG")) {       // probe instances (typed store, 32 K steps): results INVALID
+    if (const char* e = probe_env("D3R_P4_DBG")) {       // probe instances (typed store, 32 K steps): results INVALID
         if ((p.K >> 5) == 32 && e[0] == '0') return launch_p4<p4::EPK_TYPED, 1, true, 0>(p, s);
         if ((p.K >> 5) == 32 && e[0] == '1') return launch_p4<p4::EPK_TYPED, 1, true, 1>(p, s);
         if ((p.K >> 5) == 32 && e[0] == '6') return launch_p4<p4::EPK_TYPED, 1, true, 6>(p, s);

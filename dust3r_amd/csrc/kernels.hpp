@@ -65,6 +65,10 @@ struct GemmParams {
     // them to those two arrays) with the arithmetic of ln_finalize_kernel, which is not launched
     const float* ln_part_in = nullptr; float ln_eps = 1e-6f, ln_inv_c = 0.f;
     int x3res_nt = 0;            // GF_X3RES: typed-stream stores with the non-temporal policy (probe D3R_GEMM_X3NT=1; default plain: the rows are re-read at once)
+    // ---- split-K for SMALL problems (round 6; split-fp16, nn.Linear operands, the plain K loop): `splitk` blocks share a tile, each over 1 / splitk of the K steps;
+    // every block stores its fp32 partial tile in sk_slab ([tile][slice][wave][fragment][lane] float4), the block that draws the last ticket of sk_cnt[tile] adds the
+    // slices up in slice order (deterministic whichever block is last) and runs the epilogue. Chosen by launch_gemm when the caller lends it the two buffers.
+    int splitk = 1; float* sk_slab = nullptr; unsigned* sk_cnt = nullptr; size_t sk_slab_floats = 0; int sk_cnt_n = 0;
     int f8_proxy = 0;            // MEASUREMENT AID (D3R_F8_PROXY=1, results INVALID): fp16 + fp8 K loop with the MFMA mix of a 2.5-unit scheme (4 f16 + 1/2 fp8 MFMA per 64 k)
 };
 void gemm_set_trace(unsigned long long* buf, size_t capacity_blocks);
@@ -142,11 +146,14 @@ struct AlignerDev;  // defined in aligner.hip
 // nmr = -mean rstd; every lane of the row returns them.
 #if defined(__HIPCC__)
 // (sum, sum of squares) of the 4 values a lane holds in the read phase of a typed-residual-stream epilogue: the leaves of the fixed tree of GemmParams::ln_part.
-// Written with explicit fmas: under -ffp-contract=fast hipcc otherwise fuses `x*x + y*y` differently from kernel to kernel (gemm.hip and gemm_p4.hip
-// disagreed in 6 % of the sums' last bits), and the statistics must not depend on which kernel stored the row.
+// Contraction is switched OFF here: under -ffp-contract=fast hipcc fuses `x*x + y*y` in one kernel and not in another (gemm.hip's instances kept four rounded
+// products, gemm_p4.hip's first version fused them: 6 % of the sums' last bits differed), and the statistics must not depend on which kernel stored the row.
+// Four rounded products, pairwise sums -- the arithmetic rounds 5's engine ran and its oracle-parity figures were measured with.
 D3R_DEV void ln_quad_sums(const float4& v, float& sm, float& sq) {
+#pragma clang fp contract(off)
+    const float xx = v.x * v.x, yy = v.y * v.y, zz = v.z * v.z, ww = v.w * v.w;
     sm = (v.x + v.y) + (v.z + v.w);
-    sq = __builtin_fmaf(v.x, v.x, v.y * v.y) + __builtin_fmaf(v.z, v.z, v.w * v.w);
+    sq = (xx + yy) + (zz + ww);
 }
 template <int TPR> D3R_DEV void ln_row_stats(const float2* __restrict__ pr, int G, int sub, float inv_c, float eps, float& rstd, float& nmr) {
     static_assert(TPR == 1 || TPR == 2 || TPR == 4, "threads per row");

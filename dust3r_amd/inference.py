@@ -284,6 +284,8 @@ def inference(pairs, model, device, batch_size=8, verbose=True, encode_once=None
     `engine_batch`. `batch_size` is a LOWER bound on the pairs per engine call: the engine takes `model.engine_batch` pairs (32;
     DUST3R_AMD_ENGINE_BATCH) whatever smaller value the caller names, with bit-identical results; `engine_batch=n` pins the call size
     to exactly n pairs (use it to bound the workspace: ~0.8 GB per 512x384 pair in fp16x3)."""
+    from .utils.device import fit_host_threads_once
+    fit_host_threads_once()
     if verbose:
         print(f'>> Inference with model on {len(pairs)} image pairs')
     multiple_shapes = not check_if_same_size(pairs)

@@ -302,6 +302,8 @@ class AsymmetricCroCo3DStereo(nn.Module):
             self._engine, self._engine_device = h, device
             check(lib.d3r_model_set_postprocess(h, ('exp', 'linear', 'square').index(self.depth_mode[0]), ('exp', 'sigmoid').index(self.conf_mode[0]),
                                                 float(self.conf_mode[1]), float(self.conf_mode[2])), 'model_set_postprocess')
+            if getattr(self, '_split_k', None) is not None:
+                check(lib.d3r_model_set_option(h, 4, int(self._split_k)), 'set_option(split_k)')
             self._upload()
 
     def _upload(self):
@@ -320,6 +322,15 @@ class AsymmetricCroCo3DStereo(nn.Module):
     def set_two_streams(self, flag=True):
         """Decoder side 2 / head 2 on the engine's second HIP stream (default) or everything on the caller's stream."""
         check(lib.d3r_model_set_option(self._engine, 2, int(bool(flag))), 'set_option(two_streams)')
+        return self
+
+    def set_split_k(self, flag=True):
+        """Small-batch forwards may split an nn.Linear's K sum over several blocks (default OFF: built in round 6 for the one-pair call of dust3r/demo.py:156 /
+        visloc.py:88 and measured 1 % slower than one block per tile on MI355X). Deterministic, but a pair run alone then differs from the same
+        pair inside a large batch at fp32-rounding level; off, a batch is bit-identical to its one-pair calls (include/dust3r_hip.h, D3R_MODEL_OPT_SPLIT_K)."""
+        self._split_k = bool(flag)
+        if self._engine is not None:
+            check(lib.d3r_model_set_option(self._engine, 4, int(self._split_k)), 'set_option(split_k)')
         return self
 
     def set_graph_max_pairs(self, n=4):

@@ -34,8 +34,8 @@ def usable_cpus(cap=64):
 
 
 def fit_host_threads():
-    """Cap torch's intra-op thread pool at usable_cpus() (never raises it; DUST3R_AMD_KEEP_TORCH_THREADS=1 leaves torch alone). Called when the package is
-    imported: every host-side tensor operation of the inference path (collation, result allocation, the aligner's initialisation) runs on that pool."""
+    """Cap torch's intra-op thread pool at usable_cpus() (never raises it; DUST3R_AMD_KEEP_TORCH_THREADS=1 leaves torch alone). Called lazily by the entry points
+    of the path (fit_host_threads_once): every host-side tensor operation of the inference path (collation, result allocation, the aligner's initialisation) runs on that pool."""
     import os
     if os.environ.get('DUST3R_AMD_KEEP_TORCH_THREADS', '') not in ('', '0'):
         return torch.get_num_threads()
@@ -45,8 +45,23 @@ def fit_host_threads():
     except ValueError:
         pass
     if torch.get_num_threads() > n:
+        import logging
+        logging.getLogger('dust3r_amd').info('torch intra-op threads %d -> %d (the CPUs this process can use; DUST3R_AMD_KEEP_TORCH_THREADS=1 keeps torch\'s count)',
+                                             torch.get_num_threads(), n)
         torch.set_num_threads(n)
     return torch.get_num_threads()
+
+
+_fitted = False
+
+
+def fit_host_threads_once():
+    """fit_host_threads() on the first call of the process only -- from the entry points of the path (inference(), global_aligner()), NOT at import: importing the
+    package leaves the host application's torch thread pool alone."""
+    global _fitted
+    if not _fitted:
+        _fitted = True
+        fit_host_threads()
 
 
 def _map_leaves(x, fn):

@@ -106,6 +106,9 @@ int d3r_upsample2x_nhwc(const void* in, void* out, int B, int Hi, int Wi, int C,
  * `buf` (device memory, 8 x uint64 per block: wall-clock ticks at block entry, K-loop start, K-loop end, epilogue issued, stores
  * drained; then HW_ID, XCC_ID, blockIdx). `capacity_blocks` bounds the launches that are traced; buf = NULL switches it off. */
 int d3r_gemm_set_trace(void* buf, size_t capacity_blocks);
+/* Diagnostics, host only: 1 when the library was built with -DD3R_PROBES (`D3R_PROBES=1 python -m dust3r_amd.build`): the ablation kernels and the
+ * probe-only D3R_* environment switches of the tools/ probes are compiled in. The default build (0) reads the documented switches only. */
+int d3r_build_has_probes(void);
 /* Diagnostics, host only (no device needed): the GEMM tile configuration the engine picks for an nn.Linear-shaped problem (epilogue codes of
  * d3r_linear; with_residual: an fp32 residual row is added). 0 = 128x128 (eight waves below 1100 tiles in split-fp16), 1 = 256x256,
  * 2 = 256x128, 3 = 512x128, 7 = 256x128 by four waves with a K step's weights in registers (two blocks per CU), 8 = 64x64 on a three-slot
@@ -130,6 +133,9 @@ typedef struct d3r_model_config {
     int dpt_skip_relu_inplace;                   /* 0: skip adds un-activated x (nn.ReLU(False)); see SURVEY.md A.5 */
 } d3r_model_config;
 
+/* Concurrency: the engines of one process share their helper HIP streams per device (decoder side 2, K | V ahead); a handle is not thread-safe, and the
+ * enqueue of a forward (host side; the device work stays asynchronous) is a process-wide critical section inside the library -- engines driven from different
+ * host threads are correct, but their side-stream halves run in enqueue order, not concurrently. One engine per device is the intended use. */
 int d3r_model_create(d3r_model** out, const d3r_model_config* cfg);
 int d3r_model_destroy(d3r_model* m);
 /* Load one tensor of the reference checkpoint's state dict by its key, e.g.
@@ -194,6 +200,12 @@ size_t d3r_model_device_bytes(const d3r_model* m);
 #define D3R_MODEL_OPT_PROFILE 1
 #define D3R_MODEL_OPT_TWO_STREAMS 2 /* 1 (default): decoder side 2 and head 2 run on an engine-owned second HIP stream, joined back
                                      * into the caller's stream before d3r_model_forward's work completes; 0: everything on the caller's stream */
+#define D3R_MODEL_OPT_SPLIT_K 4 /* 0 (default): every launch sums K in one block and a batch is bit-identical to its one-pair calls (what the parity tests pin).
+                                * 1 (or D3R_SPLITK=1 at create): small-batch forwards (split-fp16 engine) split the K sum of an nn.Linear of the 64 x 64 tile over 2-8 blocks
+                                * where the launch then still fits three blocks per CU -- the one-pair call's fc2 (1536 x 1024 x 4096), the decoder's fc2. The partial tiles
+                                * travel through agent-scope stores / loads and are added in slice order by the last block to arrive: deterministic (the same call
+                                * twice is bit-equal), but a pair run alone then differs from the same pair inside a large batch at fp32-rounding level.
+                                * Round 6 built it for the one-pair latency and measured a LOSS on MI355X (9.86 -> 9.99 ms): kept as an option, not the default. */
 #define D3R_MODEL_OPT_GRAPH_MAX_PAIRS 3 /* n > 0: whole forwards (d3r_model_forward / _mixed / _packed) of at most n pairs are replayed as a hipGraph
                                          * from the third call with the same (B, image sizes, output layout) on: ~700 launches become one
                                          * graph launch + input / output copies through engine-owned staging buffers (bit-identical results).

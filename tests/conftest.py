@@ -30,3 +30,15 @@ def _cpu_threads():
     n = tune_threads()
     print(f'[conftest] torch CPU threads = {n}')
     yield
+
+
+def probes_built():
+    """True when the loaded library was compiled with -DD3R_PROBES (include/dust3r_hip.h d3r_build_has_probes): the ablation kernels and the probe-only
+    D3R_* switches exist. The driver's build (__graft_entry__.build()) is the default one; `D3R_PROBES=1 python -m dust3r_amd.build` makes the other."""
+    from dust3r_amd._lib import lib
+    return bool(lib.d3r_build_has_probes())
+
+
+def need_probes(what):
+    if not probes_built():
+        pytest.skip(f'{what}: compiled in probe builds only (D3R_PROBES=1 python -m dust3r_amd.build)')

@@ -56,6 +56,8 @@ def test_dpp_and_shuffle_reductions_agree(gpu):
 def test_workgroups_of_eight_waves_agree(gpu, monkeypatch):
     """D3R_ALIGNER_NWV=8 (read at handle creation): the main kernel on 512-thread workgroups / 2048-pixel chunks (round 5 probe: 0.644 vs 0.655 of the HBM
     peak on the BASELINE scene, not the default). Partial sums are grouped differently: same loss and gradients to fp32 rounding; several chunks per image."""
+    from conftest import need_probes
+    need_probes('the 512-thread aligner workgroups')
     scene4, out, init, gt = make_scene(gpu, 4, 64, 96, seed=3)
     monkeypatch.setenv('D3R_ALIGNER_NWV', '8')
     scene8, *_ = make_scene(gpu, 4, 64, 96, seed=3)

@@ -114,7 +114,8 @@ def test_forward_split_fp16_kernel_variants(gpu, cfg, monkeypatch):
     eng = engine_from_oracle(oracle, 'tiny_dpt', 'fp16x3', gpu)
     v1, v2 = synthetic_views(2, 128, 128, seed=6)
     outs = []
-    for sw in ('1', '0'):
+    from conftest import probes_built
+    for sw in (('1', '0') if probes_built() else ('0',)):       # the software-pipelined K loop: probe builds only
         for nowide in ('0', '1'):
             monkeypatch.setenv('D3R_GEMM_X3SW', sw)
             monkeypatch.setenv('D3R_GEMM_NOWIDE', nowide)
@@ -703,7 +704,7 @@ def test_layernorm_fold_full_size_against_oracle(gpu, monkeypatch):
         worst[name] = mx
         print(f'[512_dpt random LN affines, {name} vs CPU oracle] max {mx:.3e} p99 {p99:.3e} mean {mean:.3e}')
         assert p99 < 2e-4 and mean < 5e-5
-        assert float(((e1['conf'].cpu() - r1['conf']).abs() / r1['conf']).max()) < 3e-3
+        assert float(((e1['conf'].cpu() - r1['conf']).abs() / r1['conf']).max()) < 1e-3
     # these weights send pointmaps through the origin (per-pixel max of the LayerNorm-kernel engine itself: 2e-3 at one pixel): the folded engine is
     # held to the bar, or to the unfolded engine's own worst pixel where that is above it
     assert worst['folded'] < max(1e-3, 1.5 * worst['LayerNorm kernels'])
@@ -729,6 +730,8 @@ def test_encoder_views_on_two_streams_is_bit_identical(gpu, monkeypatch):
     images run the encoder of view 1 and of view 2 as two concurrent chains on the engine's two streams, each in its own rows of every scratch buffer. Same kernels on the
     same rows: bit-identical to the one-chain schedule, for pairs of one and of two image sizes, folded LayerNorm on and off."""
     from oracle.dust3r_ref import build_ref_model
+    from conftest import need_probes
+    need_probes('D3R_ENC_SPLIT (a schedule that never became the default)')
     oracle = build_ref_model('tiny_dpt')
     g = torch.Generator().manual_seed(5)
     cases = []
@@ -780,6 +783,8 @@ def test_cross_attention_kv_projected_ahead_is_bit_identical(gpu, monkeypatch):
     schedule -- equal views, a ragged token count (96 tokens: V^T rows padded to 128), views of two sizes (Nq != Nk), and repeated calls on one engine (buffer reuse
     across the layer boundaries and across calls)."""
     from oracle.dust3r_ref import build_ref_model
+    from conftest import need_probes
+    need_probes('D3R_DEC_KV_AHEAD (a schedule that never became the default)')
     oracle = _randomize_norms(build_ref_model('tiny_dpt'), seed=6)
     g = torch.Generator().manual_seed(9)
     cases = [synthetic_views(3, 128, 128, seed=2), synthetic_views(2, 128, 192, seed=3), synthetic_views(1, 64, 64, seed=4),

@@ -375,6 +375,11 @@ def test_gemm_tile_dispatch_table(monkeypatch):
     PLAIN, F32, GELU = 0, 1, 2
     cfg = lambda dt, M, N, K, epi=PLAIN, res=0: lib.d3r_gemm_tile_config(dt, M, N, K, epi, res)   # noqa: E731
     x3 = DTYPE_F16X3
+    # round 6: the persistent kernel (configuration 10) takes the launches whose 256 x 128 tiles fill whole rounds of the CUs and whose epilogue is a large share of
+    # a tile's life -- fc1 + GELU and the plain typed stores of the 32-pair step; never the fp32-residual epilogue, never small batches (fewer tiles than CUs)
+    assert cfg(x3, 49152, 4096, 1024, GELU) == 10 and cfg(x3, 49152, 1024, 1024) == 10 and cfg(x3, 24576, 3072, 768, GELU) == 10
+    assert cfg(x3, 49152, 1024, 4096, F32, 1) == 1 and cfg(x3, 1536, 4096, 1024, GELU) == 0 and cfg(DTYPE_BF16, 49152, 4096, 1024, GELU) == 1
+    monkeypatch.setenv('D3R_GEMM_PERSIST', '0')        # the one-tile-per-block table below it
     # 32 pairs = 64 images x 768 tokens: the encoder's four linears, the decoder's 768-wide ones (one side = 24576 rows)
     assert cfg(x3, 49152, 4096, 1024, GELU) == 1 and cfg(x3, 49152, 1024, 4096, F32, 1) == 1 and cfg(x3, 49152, 1024, 1024) == 1
     assert cfg(x3, 49152, 1024, 1024, F32, 1) == 7           # fp32-residual projection at K <= 1024: two blocks per CU, weights in registers
@@ -382,9 +387,11 @@ def test_gemm_tile_dispatch_table(monkeypatch):
     # round 4: the decoder's 24576-row GEMMs whose (M / 384) x (N / 192) tiles fill whole rounds of 256 CUs take the 384 x 192 tile (configuration 9)
     assert cfg(x3, 24576, 768, 3072, F32, 1) == 9 and cfg(x3, 24576, 3072, 768, GELU) == 9 and cfg(x3, 24576, 2304, 768) == 9 and cfg(x3, 24576, 768, 768, F32, 1) == 9
     assert cfg(DTYPE_BF16, 24576, 768, 3072, F32, 1) != 9 and cfg(x3, 24576 - 384 * 20, 768, 3072, F32, 1) != 9      # split-fp16 only; 176 tiles do not fill the chip
-    monkeypatch.setenv('D3R_GEMM_T384', '0')
-    assert cfg(x3, 24576, 768, 3072, F32, 1) == 0 and cfg(x3, 24576, 3072, 768, GELU) == 1 and cfg(x3, 24576, 768, 768, F32, 1) == 0
-    monkeypatch.delenv('D3R_GEMM_T384')
+    probes = bool(lib.d3r_build_has_probes())      # the probe-only switches move the table in probe builds only (D3R_PROBES=1 python -m dust3r_amd.build)
+    if probes:
+        monkeypatch.setenv('D3R_GEMM_T384', '0')
+        assert cfg(x3, 24576, 768, 3072, F32, 1) == 0 and cfg(x3, 24576, 3072, 768, GELU) == 1 and cfg(x3, 24576, 768, 768, F32, 1) == 0
+        monkeypatch.delenv('D3R_GEMM_T384')
     assert cfg(x3, 6291456, 128, 1152) == 3 and cfg(x3, 196608, 128, 1152) == 2 and cfg(x3, 1000, 96, 768) == 0   # N <= 128: the head's shapes
     # one pair per call = 1536 encoder rows / 768 decoder rows per side: small problems on the 64 x 64 tile, mid-size ones stay on 128 x 128
     assert cfg(x3, 1536, 1024, 4096, F32, 1) == 8 and cfg(x3, 1536, 1024, 1024, F32, 1) == 8 and cfg(x3, 768, 768, 768, F32, 1) == 8
@@ -393,9 +400,10 @@ def test_gemm_tile_dispatch_table(monkeypatch):
     assert cfg(DTYPE_BF16, 1536, 1024, 4096, F32, 1) == 0 and cfg(DTYPE_F16F8, 1536, 1024, 4096, F32, 1) == 0
     # fp16 + fp8 rows go to the 256-wide tile from one round of resident blocks on
     assert cfg(DTYPE_F16F8, 24576, 768, 768, F32, 1) == 1
+    monkeypatch.delenv('D3R_GEMM_PERSIST')
     # probes
     monkeypatch.setenv('D3R_GEMM_T64', '0')
-    assert cfg(x3, 768, 768, 768, F32, 1) == 0
+    assert cfg(x3, 768, 768, 768, F32, 1) == (0 if probes else 8)
     monkeypatch.delenv('D3R_GEMM_T64')
     monkeypatch.setenv('D3R_GEMM_CFG', '2')
     assert cfg(x3, 49152, 4096, 1024, GELU) == 2
@@ -505,12 +513,20 @@ def test_load_images_thread_pool_keeps_pixels_and_order(tmp_path, monkeypatch):
 
 def test_host_thread_pool_is_capped_at_the_usable_cpus(monkeypatch):
     """utils/device.py: usable_cpus() = min(affinity, cgroup quota); fit_host_threads() lowers torch's intra-op pool to it, never raises it, and
-    DUST3R_AMD_KEEP_TORCH_THREADS=1 leaves torch alone. Importing the package applies it."""
-    import dust3r_amd  # noqa: F401
+    DUST3R_AMD_KEEP_TORCH_THREADS=1 leaves torch alone. Importing the package does NOT apply it (no import side effect on the host application's pool, round 6):
+    the first inference() / global_aligner() call does, once (fit_host_threads_once)."""
+    import subprocess
+    import sys
+    code = ('import torch; torch.set_num_threads(3); import dust3r_amd, dust3r_amd.inference, dust3r_amd.cloud_opt; '
+            'from dust3r_amd.utils import device as D; D.usable_cpus = lambda cap=64: 2; a = torch.get_num_threads(); '
+            'D.fit_host_threads_once(); b = torch.get_num_threads(); torch.set_num_threads(3); D.fit_host_threads_once(); print(a, b, torch.get_num_threads())')
+    env = {k: v for k, v in os.environ.items() if k not in ('DUST3R_AMD_KEEP_TORCH_THREADS', 'LOCAL_WORLD_SIZE')}
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-3:] == ['3', '2', '3'], out.stdout       # import: untouched; first entry-point call: capped; later calls: nothing
     from dust3r_amd.utils import device as D
     n = D.usable_cpus()
     assert 1 <= n <= max(1, len(os.sched_getaffinity(0)))
-    assert torch.get_num_threads() <= max(n, 1)
     before = torch.get_num_threads()
     try:
         monkeypatch.setattr(D, 'usable_cpus', lambda cap=64: 1)
@@ -561,3 +577,22 @@ def test_from_pretrained_loads_a_local_hub_snapshot_directory(tmp_path, fmt):
         AsymmetricCroCo3DStereo.from_pretrained('naver/DUSt3R_does_not_exist')
     with pytest.raises(Exception, match='no config.json'):
         AsymmetricCroCo3DStereo.from_pretrained(str(tmp_path))
+
+
+def test_persistent_gemm_has_no_scratch():
+    """gemm_p4.hip keeps TWO accumulator sets (256 registers) per wave at one wave per SIMD: it only works while hipcc keeps every accumulator in a register --
+    one dynamically indexed access, one unrolled loop past the size cap, and the arrays move to scratch (90 instead of 400 TFLOP/s: DESIGN.md 4.1). The build
+    writes hipcc's resource report of the file next to its object (dust3r_amd/build.py): every kernel instance must show no scratch and no spilled VGPR."""
+    from dust3r_amd.build import CSRC, build
+    rep = os.path.join(CSRC, 'gemm_p4.resources.txt')
+    if not os.path.exists(rep) or os.path.getmtime(rep) < os.path.getmtime(os.path.join(CSRC, 'gemm_p4.hip')):
+        os.utime(os.path.join(CSRC, 'gemm_p4.hip'))
+        build(force=False, verbose=False)
+    txt = open(rep).read()
+    kernels = re.findall(r'Function Name: (\S*gemm_p4_kernel\S*)', txt)
+    scratch = [int(x) for x in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', txt)]
+    spills = [int(x) for x in re.findall(r'VGPRs Spill: (\d+)', txt)]
+    occ = [int(x) for x in re.findall(r'Occupancy \[waves/SIMD\]: (\d+)', txt)]
+    assert len(kernels) >= 5 and len(scratch) == len(kernels) == len(spills)
+    assert all(v == 0 for v in scratch) and all(v == 0 for v in spills), list(zip(kernels, scratch, spills))
+    assert all(v == 1 for v in occ)          # one wave per SIMD: the whole register file

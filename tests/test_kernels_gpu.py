@@ -74,6 +74,9 @@ def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
     software-pipelined K loop and the plain two-stage loop, the LDS-staged wide epilogue and the direct stores; K = 32 / 64 are one- and two-step K loops (pipeline prologue / drain only). Reference =
     fp32 matmul of the SAME fp32 operands: the split keeps 22 significand bits per operand, so the result is fp32-class."""
     from dust3r_amd import ops
+    from conftest import need_probes
+    if sw == '1':
+        need_probes('the software-pipelined K loop')
     monkeypatch.setenv('D3R_GEMM_CFG', cfg[0])
     monkeypatch.setenv('D3R_GEMM_T128W8', '1000000' if cfg.endswith('w8') else '0')     # '0w8': the 128 x 128 tile by eight waves (small-batch forwards)
     monkeypatch.setenv('D3R_GEMM_X3SW', sw)
@@ -96,15 +99,20 @@ def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
 
 
 @pytest.mark.parametrize('grid', [None, '8'])
-@pytest.mark.parametrize('M,N,K', [(2048, 256, 768), (4096, 384, 1024), (2048, 128, 1536), (6144, 256, 576)])
+@pytest.mark.parametrize('M,N,K', [(2048, 256, 768), (4096, 384, 1024), (2048, 128, 1536), (6144, 256, 576), (16384, 1536, 768)])
 def test_persistent_gemm_is_bit_identical(gpu, M, N, K, grid, monkeypatch):
     """gemm_p4.hip (one block per CU walking its tiles, the epilogue of tile t drained under the K loop of tile t + 1) against the one-tile-per-block
     kernels on the same operands: typed store, GELU, and the typed residual stream with and without a residual and with its LayerNorm partial sums --
     BIT-identical (same MFMA order per element, same epilogue expressions, same summation tree), and within fp32-class error of the fp64 product.
     K = 576 / 768: 18 / 24 K steps (the shortest loop the kernel takes); 1536: steps behind the draining ones; grid = 8: forty tiles per block (the
-    overlapped path), default: one or two (first tile without a drain, last tile drained with nothing to hide under)."""
+    overlapped path; probe builds), default: one or two (first tile without a drain, last tile drained with nothing to hide under) -- and three per block on
+    the 16384 x 1536 problem (768 tiles on 256 resident blocks: first / overlapped / last tile, the steady state of the 32-pair step, in every build)."""
     from dust3r_amd import ops
+    from conftest import need_probes
     if grid:
+        need_probes('D3R_P4_GRID')
+        if M > 8192:
+            pytest.skip('covered by the default grid')
         monkeypatch.setenv('D3R_P4_GRID', grid)
     g = torch.Generator(device='cpu').manual_seed(M + 3 * N + K)
     a = torch.randn((M, K), generator=g).to(gpu)
@@ -149,6 +157,9 @@ def test_linear_fp16_fp8(gpu, M, N, K, cfg, monkeypatch):
     from dust3r_amd import ops
     from oracle.f8_ref import f16f8_matmul
     # '1w4': the two-blocks-per-CU shape of the 256-wide configuration (256 x 128 tile by four waves, 64-byte K steps, three LDS slots)
+    from conftest import need_probes
+    if cfg.endswith('w4'):
+        need_probes('the four-wave 256 x 128 fp16 + fp8 tile')
     monkeypatch.setenv('D3R_GEMM_CFG', cfg[0])
     monkeypatch.setenv('D3R_GEMM_F8W4', '1' if cfg.endswith('w4') else '0')
     g = torch.Generator(device='cpu').manual_seed(M * 7 + N)
@@ -339,6 +350,9 @@ def test_attention_split_fp16(gpu, v1, B, H, Nq, Nk, monkeypatch):
     keep 22 significand bits and the probabilities are split too, so the result is fp32-class (3e-5 like the exact-fp32 kernel); 1 to 12
     key tiles, ragged last tiles, query blocks with idle lanes. A subprocess-free switch: the choice is read on every launch."""
     from dust3r_amd import ops
+    from conftest import need_probes
+    if v1 in ('pk', 'lz'):
+        need_probes('the packed-softmax / lazy-maximum attention instances')
     monkeypatch.setenv('D3R_ATTN_V1', '1' if v1 == '1' else '0')
     if v1 in ('dma', 'reg'):
         monkeypatch.setenv('D3R_ATTN_DMA', '1' if v1 == 'dma' else '0')
@@ -363,6 +377,9 @@ def test_attention_split_fp16_sharp_rows_and_late_maximum(gpu, dma, monkeypatch)
     """Running-maximum rescale of the pipelined kernel: one key dominating by a huge margin in a LATE tile (alpha = 0 there), and rows
     whose maximum moves in every tile."""
     from dust3r_amd import ops
+    from conftest import need_probes
+    if dma == 'lazy':
+        need_probes('the lazy-maximum attention instance')
     monkeypatch.setenv('D3R_ATTN_DMA', '1' if dma == 'lazy' else dma)
     monkeypatch.setenv('D3R_ATTN_LAZY', '1' if dma == 'lazy' else '0')     # head 1's maximum creeps up by 0.16 octaves per key: the lazy reference moves every ~38 keys only
     B, H, N = 1, 2, 320
@@ -388,7 +405,9 @@ def test_attention_split_fp16_dma_staging_is_bit_identical(gpu, monkeypatch):
         k = (torch.randn((B, H, Nk, 64), generator=g) * 1.5).to(gpu)
         v = torch.randn((B, H, Nk, 64), generator=g).to(gpu)
         outs = []
-        for dma, sc in (('0', '0'), ('1', '0'), ('1', '1')):       # register staging, DMA staging, DMA staging + scalar-VALU softmax slices (round 5)
+        from conftest import probes_built
+        # register staging (packed softmax slices), [probe builds: DMA staging + packed slices,] DMA staging + scalar-VALU softmax slices (round 5, the default)
+        for dma, sc in ((('0', '0'), ('1', '0'), ('1', '1')) if probes_built() else (('0', '0'), ('1', '1'), ('1', '1'))):
             monkeypatch.setenv('D3R_ATTN_DMA', dma)
             monkeypatch.setenv('D3R_ATTN_SC', sc)
             outs.append(ops.attention_x3(q, k, v, scale=0.125).clone())

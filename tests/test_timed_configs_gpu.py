@@ -46,6 +46,8 @@ def one_pair(v, b):
 def bench_engine(gpu):
     from bench import build_model        # bench.py's full-size synthetic weights, generated in HBM
     eng = build_model('fp16x3', gpu)
+    # (split-K, round 6, is opt-in: the default engine sums every K in one block -- "every kernel is batch-position independent, no tile choice changes a K
+    # order" is what this module pins; split-K itself: test_split_k_of_the_one_pair_call below)
     yield eng
     eng._destroy_engine()
     torch.cuda.empty_cache()
@@ -83,6 +85,39 @@ def test_c2_batch_of_32_is_bit_equal_to_oracle_checked_single_pair_calls(gpu, be
         assert torch.equal(e1['pts3d'][0], full[0][b]) and torch.equal(e2['pts3d_in_other_view'][0], full[2][b])
 
 
+def test_split_k_of_the_one_pair_call(gpu, bench_engine):
+    """Round 6, opt-in (set_split_k(True); measured slower than the default on MI355X): the one-pair forward (dust3r/demo.py:156, visloc.py:88)
+    splits the K sum of its small nn.Linear launches (fc2 1536 x 1024 x 4096 over two blocks per tile, the decoder's fc2 over four; include/dust3r_hip.h
+    D3R_MODEL_OPT_SPLIT_K). What is held: the same call twice is BIT-equal (the partial tiles are added in slice order whichever block arrives last), the result
+    stays at fp32-rounding distance from the unsplit evaluation (per-pixel max 2e-5 relative), and a batch of four pairs (too many tiles to split) is untouched."""
+    eng = bench_engine
+    v1, v2 = synthetic_views(4, 384, 512, seed=3, device=gpu)
+    s1, s2 = one_pair(v1, 1), one_pair(v2, 1)
+    a1, a2 = eng(s1, s2)
+    base = [t.clone() for t in (a1['pts3d'], a1['conf'], a2['pts3d_in_other_view'], a2['conf'])]
+    try:
+        eng.set_split_k(True)
+        runs = []
+        for _ in range(3):
+            o1, o2 = eng(s1, s2)
+            runs.append([t.clone() for t in (o1['pts3d'], o1['conf'], o2['pts3d_in_other_view'], o2['conf'])])
+        for r in runs[1:]:
+            assert all(torch.equal(x, y) for x, y in zip(r, runs[0]))
+        assert not all(torch.equal(x, y) for x, y in zip(runs[0], base)), 'split-K did not engage on the one-pair call'
+        for x, y in zip((runs[0][0], runs[0][2]), (base[0], base[2])):
+            rel = ((x - y).norm(dim=-1) / y.norm(dim=-1).clamp_min(1e-8))
+            print(f'split-K vs one block per tile: per-pixel max {float(rel.max()):.2e}, mean {float(rel.mean()):.2e}')
+            assert float(rel.max()) < 2e-4 and float(rel.mean()) < 2e-6
+        for x, y in zip((runs[0][1], runs[0][3]), (base[1], base[3])):
+            assert float(((x - y).abs() / y).max()) < 1e-4
+        b1, _ = eng(v1, v2)                                   # four pairs: 3072 rows x 1024 = 768 tiles already fill a round -- nothing splits
+        eng.set_split_k(False)
+        c1, _ = eng(v1, v2)
+        assert torch.equal(b1['pts3d'], c1['pts3d'])
+    finally:
+        eng.set_split_k(False)
+
+
 @pytest.mark.parametrize('cfg,H,W', [('DUSt3R_ViTLarge_BaseDecoder_224_linear', 224, 224), ('DUSt3R_ViTLarge_BaseDecoder_512_linear', 384, 512)])
 def test_full_size_linear_head_models_match_oracle(gpu, cfg, H, W):
     """The two released linear-head models at full size (configs[0] names the 224 one), one pair each: fp32 engine and the default
@@ -102,7 +137,7 @@ def test_full_size_linear_head_models_match_oracle(gpu, cfg, H, W):
             print(f'[{cfg} {prec}] {name} rel err max {s["max"]:.3e} p99 {s["p99"]:.3e} mean {s["mean"]:.3e}')
             assert s['max'] < 1e-3 and s['mean'] < 2e-4, (prec, name, s)
         for a, b in ((e1['conf'], r1['conf']), (e2['conf'], r2['conf'])):
-            assert float(((a.cpu() - b).abs() / b).max()) < 3e-3
+            assert float(((a.cpu() - b).abs() / b).max()) < 1e-3
 
 
 @pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
@@ -153,7 +188,7 @@ def _views_of(hw1, hw2, seed):
                                      ((512, 384), (384, 512)), ((384, 512), (512, 384)), ((512, 336), (288, 512))])
 def test_full_size_released_resolutions_match_oracle(gpu, c2_oracle_and_engine, hw1, hw2):
     """DUSt3R_ViTLarge_BaseDecoder_512_dpt at every other released resolution and with a portrait image in the pair: exact-fp32 engine and the
-    default engine (fp16x3) against the CPU oracle, per-pixel max <= 1e-3 on both pointmaps (north star), confidences within 3e-3."""
+    default engine (fp16x3) against the CPU oracle, per-pixel max <= 1e-3 on both pointmaps (north star), confidences within 1e-3."""
     oracle, eng = c2_oracle_and_engine
     v1, v2 = _views_of(hw1, hw2, seed=hw1[0] * 7 + hw2[0])
     with torch.no_grad():
@@ -168,7 +203,7 @@ def test_full_size_released_resolutions_match_oracle(gpu, c2_oracle_and_engine, 
             print(f'[512_dpt {hw1[1]}x{hw1[0]} + {hw2[1]}x{hw2[0]} {prec} vs CPU oracle] {name} max {st["max"]:.3e} p99.99 {st["p9999"]:.3e} p99 {st["p99"]:.3e} mean {st["mean"]:.3e}')
             assert st['max'] < 1e-3 and st['mean'] < 5e-5, (prec, name, st)
         for a, b in ((e1['conf'], r1['conf']), (e2['conf'], r2['conf'])):
-            assert float(((a.cpu() - b).abs() / b).max()) < 3e-3
+            assert float(((a.cpu() - b).abs() / b).max()) < 1e-3
     # a batch of such pairs is bit-equal to the one-pair call (the ragged token counts on the batched tiles)
     eng.set_precision('fp16x3')
     e1, e2 = eng(v1, v2)

@@ -1,7 +1,7 @@
 """One command to validate the engine against the CPU oracle on a REAL checkpoint, the moment one is available (none is reachable from the
 build container: no network, no .pth on disk -- the croco / roma restatements in oracle/ stay "parity unpinned" until this has run once).
 
-    python tools/validate_checkpoint.py <DUSt3R_ViTLarge_BaseDecoder_512_dpt.pth> [--size 512x384] [--pairs 2] [--images a.png b.png ...]
+    python tools/validate_checkpoint.py <DUSt3R_ViTLarge_BaseDecoder_512_dpt.pth | hub snapshot directory> [--size 512x384] [--pairs 2] [--images a.png b.png ...]
                                         [--precision fp16x3,fp32] [--align]
 
 What it does (GPU box; test infrastructure like everything that imports oracle/):
@@ -36,6 +36,30 @@ def load_oracle(path):
     """The reference's load_model protocol onto the CPU oracle: returns (oracle, constructor kwargs, load result)."""
     from dust3r_amd.model import parse_model_string
     from oracle.dust3r_ref import DUSt3RRef
+    if os.path.isdir(path):         # a hub snapshot directory (config.json + model.safetensors | pytorch_model.bin): what PyTorchModelHubMixin.from_pretrained reads
+        import json
+        with open(os.path.join(path, 'config.json')) as f:
+            kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in json.load(f).items()}
+        for k in ('landscape_only', 'patch_embed_cls', 'freeze'):
+            kw.pop(k, None)
+        if os.path.isfile(os.path.join(path, 'model.safetensors')):
+            from safetensors.torch import load_file
+            state = load_file(os.path.join(path, 'model.safetensors'), device='cpu')
+        else:
+            state = torch.load(os.path.join(path, 'pytorch_model.bin'), map_location='cpu', weights_only=True)
+        oracle = DUSt3RRef(**kw).eval()
+        # safetensors keeps ONE name per shared tensor (the DPT head registers scratch.layer{i+1}_rn also as scratch.layer_rn[i]): fill the twin of every such
+        # key from its alias, as the engine's loader does, so that "missing" below means missing
+        import re
+        for k in list(state):
+            m = re.search(r'scratch\.layer_rn\.(\d)\.', k)
+            if m:
+                state.setdefault(k.replace(f'scratch.layer_rn.{m.group(1)}.', f'scratch.layer{int(m.group(1)) + 1}_rn.'), state[k])
+            m = re.search(r'scratch\.layer(\d)_rn\.', k)
+            if m:
+                state.setdefault(k.replace(f'scratch.layer{m.group(1)}_rn.', f'scratch.layer_rn.{int(m.group(1)) - 1}.'), state[k])
+        res = oracle.load_state_dict(state, strict=False)
+        return oracle, kw, res
     ckpt = torch.load(path, map_location='cpu', weights_only=False)
     args = ckpt['args'].model if hasattr(ckpt['args'], 'model') else ckpt['args']['model']
     kw = parse_model_string(args.replace('ManyAR_PatchEmbed', 'PatchEmbedDust3R'))
@@ -75,7 +99,11 @@ def main():
     keys_ok = len(res.missing_keys) == 0 and len(res.unexpected_keys) == 0      # a key-for-key match of the restated module tree is part of the verdict
     if not keys_ok:
         print('           [FAIL] the restated module tree does not match the checkpoint key for key')
-    engine = load_model(a.checkpoint, dev, verbose=False, precision=a.precision.split(',')[0])
+    if os.path.isdir(a.checkpoint):
+        from dust3r_amd.model import AsymmetricCroCo3DStereo
+        engine = AsymmetricCroCo3DStereo.from_pretrained(a.checkpoint, precision=a.precision.split(',')[0]).to(dev)
+    else:
+        engine = load_model(a.checkpoint, dev, verbose=False, precision=a.precision.split(',')[0])
     print(f'engine   <- loaded, {engine.device_bytes() / 2**30:.2f} GiB in HBM, head {engine.head_type}, depth_mode {engine.depth_mode}, conf_mode {engine.conf_mode}')
     if a.images:
         from dust3r_amd.utils.image import load_images
