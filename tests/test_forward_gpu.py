@@ -124,7 +124,8 @@ def test_forward_split_fp16_kernel_variants(gpu, cfg, monkeypatch):
             outs.append(torch.cat((e1['pts3d'], e2['pts3d_in_other_view'])))
     for o in outs[1:]:
         assert pix_rel(o, outs[0].cpu())[0] < 1e-4
-    assert torch.equal(outs[0], outs[2])        # pipelined vs plain K loop, same epilogue route: bit-identical
+    if len(outs) == 4:
+        assert torch.equal(outs[0], outs[2])        # pipelined vs plain K loop, same epilogue route: bit-identical (probe builds)
 
 
 @pytest.mark.parametrize('name', ['forward_tiny_dpt.pt', 'forward_tiny_linear.pt'])
