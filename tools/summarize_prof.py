@@ -120,9 +120,10 @@ for name in names:
     entry = dict(kernel=name[:120], dispatches=fetch.get(name, write.get(name))[0], fetch_size_kib=fk, write_size_kib=wk,
                  hbm_gb_per_launch=(2 * fk + wk) * 1024 / 1e9)
     mm = re.search(r'gemm_kernel<(\d), d3r::GemmCfg<([0-9, ]+)>', name)
-    if mm:
-        cfg = CFG_OF.get(tuple(int(x) for x in mm.group(2).split(',')))
-        if cfg is not None and int(mm.group(1)) == run_dt:
+    p4 = 'gemm_p4_kernel<' in name        # the persistent split-fp16 kernel (csrc/gemm_p4.hip): tile configuration 10 of bench.py, one entry per epilogue instantiation
+    if mm or p4:
+        cfg = 10 if p4 else CFG_OF.get(tuple(int(x) for x in mm.group(2).split(',')))
+        if cfg is not None and (p4 or int(mm.group(1)) == run_dt):
             # several instantiations share a tile-configuration id of bench.py (cfg 0 = the 128x128 tile by four waves AND by eight):
             # dispatch-weighted mean under the id, every instantiation listed
             prev = digest['gemm_cfg'].get(str(cfg))
