@@ -286,6 +286,12 @@ def profile_mode(model, v1, v2, precision, quiet=False):
                 '(fp16x3: 3 f16 MFMAs; fp16f8: 1 f16 MFMA + both cross terms on one e4m3 MFMA at twice the rate = 2 units); traffic is NOT '
                 're-measured by this command: it is carried from the committed rocprofv3 PMC digest named in traffic_source',
         'timing': 'HIP events around every launch on the launch stream, single-stream schedule, one extra forward after the timed region'}}
+    # every GEMM-shaped launch of the step together (nn.Linear + implicit-GEMM convolutions, all tile configurations incl. the persistent kernel): since round 6 the
+    # fastest nn.Linear launches run on another kernel symbol (cfg10), so the dominant symbol alone no longer describes "the GEMMs"
+    g_ms = prof['linear']['ms'] + prof['conv']['ms']
+    g_gf = prof['linear']['gflop'] + prof['conv']['gflop']
+    out['roofline']['all_gemm_launches'] = {'achieved': g_gf / g_ms, 'frac': g_gf / g_ms / PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'ms_per_step': g_ms,
+                                            'share_of_step_time': g_ms / total_ms, 'launches_per_step': prof['linear']['launches'] + prof['conv']['launches']}
     kern = {f'gemm_kernel cfg{c}': dict(v, tflops=v['gflop'] / v['ms']) for c, v in prof['gemm_cfg'].items()}
     kern.update({f'gemm_kernel<fp16f8> cfg{c}': dict(v, tflops=v['gflop'] / v['ms']) for c, v in prof['gemm_f8_cfg'].items()})
     for k in ('attention', 'other'):

@@ -42,3 +42,12 @@ def probes_built():
 def need_probes(what):
     if not probes_built():
         pytest.skip(f'{what}: compiled in probe builds only (D3R_PROBES=1 python -m dust3r_amd.build)')
+
+
+def probe_arms(every, default):
+    """Parameter lists that name probe-only variants: `every` on a probe build, `default` (the variants the product library holds) otherwise -- decided at
+    collection time, so that a default build collects what it can run instead of reporting skips."""
+    try:
+        return list(every) if probes_built() else list(default)
+    except Exception:           # library not built yet: collect the product's arms
+        return list(default)

@@ -8,6 +8,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import probe_arms
+
 pytestmark = pytest.mark.gpu
 
 DTYPES = [torch.float32, torch.bfloat16, torch.float16]
@@ -64,7 +66,7 @@ def test_linear_epilogues(gpu, dtype, M, N, K):
     assert relerr(out, F.gelu(ref)) < OUT_TOL[dtype], 'gelu epilogue'
 
 
-@pytest.mark.parametrize('sw', ['1', '0'])
+@pytest.mark.parametrize('sw', probe_arms(['1', '0'], ['0']))
 @pytest.mark.parametrize('cfg', ['0', '0w8', '1', '2', '3', '7', '8', '9'])
 @pytest.mark.parametrize('M,N,K', [(300, 192, 256), (1000, 3072, 1024), (77, 96, 768), (2100, 1032, 32), (515, 328, 64)])
 def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
@@ -98,7 +100,7 @@ def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize('grid', [None, '8'])
+@pytest.mark.parametrize('grid', probe_arms([None, '8'], [None]))
 @pytest.mark.parametrize('M,N,K', [(2048, 256, 768), (4096, 384, 1024), (2048, 128, 1536), (6144, 256, 576), (16384, 1536, 768)])
 def test_persistent_gemm_is_bit_identical(gpu, M, N, K, grid, monkeypatch):
     """gemm_p4.hip (one block per CU walking its tiles, the epilogue of tile t drained under the K loop of tile t + 1) against the one-tile-per-block
@@ -146,7 +148,7 @@ def test_persistent_gemm_dispatch_rule():
     assert cfg(24576, 768, 768, 0) != 10
 
 
-@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '1w4'])
+@pytest.mark.parametrize('cfg', probe_arms(['0', '1', '2', '3', '1w4'], ['0', '1', '2', '3']))
 @pytest.mark.parametrize('M,N,K', [(300, 192, 256), (1000, 3072, 1024), (77, 128, 768), (2100, 1024, 64), (515, 320, 128)])
 def test_linear_fp16_fp8(gpu, M, N, K, cfg, monkeypatch):
     """The fp16 + fp8 operand mode at kernel level (hi.hi on the f16 MFMA, both cross terms on one K-concatenated e4m3 MFMA with an E8M0
@@ -276,7 +278,7 @@ def test_conv2d_nhwc(gpu, dtype, B, H, W, Cin, Cout, k, stride, pad):
     assert relerr(out, (ref - b).clamp_min(0)) < OUT_TOL[dtype]
 
 
-@pytest.mark.parametrize('cfg', ['0', '1', '2', '3', '4', '5', '6'])
+@pytest.mark.parametrize('cfg', probe_arms(['0', '1', '2', '3', '4', '5', '6'], ['0', '1', '2', '3']))     # 4-6: probe-only tile shapes (W4, four-stage, ping-pong)
 def test_gemm_tile_configurations(gpu, cfg, monkeypatch):
     """Every tile configuration of the GEMM template (128x128, 256x256, 256x128) on shapes with ragged M / N edges,
     K long enough to cycle both LDS stages many times, linear and implicit-GEMM convolution operands."""
@@ -341,7 +343,7 @@ def test_attention(gpu, dtype, B, H, Nq, Nk):
     assert relerr(out, ref) < tol
 
 
-@pytest.mark.parametrize('v1', ['0', '1', 'dma', 'reg', 'pk', 'lz'])
+@pytest.mark.parametrize('v1', probe_arms(['0', '1', 'dma', 'reg', 'pk', 'lz'], ['0', '1', 'dma', 'reg']))
 @pytest.mark.parametrize('B,H,Nq,Nk', [(2, 3, 196, 196), (1, 2, 768, 768), (2, 1, 6, 6), (1, 4, 130, 70), (1, 1, 768, 196), (1, 2, 40, 129), (1, 1, 300, 64), (1, 1, 64, 128)])
 def test_attention_split_fp16(gpu, v1, B, H, Nq, Nk, monkeypatch):
     """The split-fp16 attention of the default engine at kernel level, every kernel (D3R_ATTN_V1=1: the round-2 kernel; the
@@ -372,7 +374,7 @@ def test_attention_split_fp16(gpu, v1, B, H, Nq, Nk, monkeypatch):
     assert err < 3e-5
 
 
-@pytest.mark.parametrize('dma', ['0', '1', 'lazy'])
+@pytest.mark.parametrize('dma', probe_arms(['0', '1', 'lazy'], ['0', '1']))
 def test_attention_split_fp16_sharp_rows_and_late_maximum(gpu, dma, monkeypatch):
     """Running-maximum rescale of the pipelined kernel: one key dominating by a huge margin in a LATE tile (alpha = 0 there), and rows
     whose maximum moves in every tile."""
