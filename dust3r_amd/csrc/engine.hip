@@ -412,7 +412,7 @@ struct Ctx {
 // profile record kinds: GEMM-kernel launches carry their tile configuration: kind = cfg (0..7) + 8 for implicit-GEMM convolution
 enum { PRF_GEMM = 0, PRF_CONV = 8, PRF_ATTN = 16, PRF_OTHER = 17, PRF_GEMM_64 = 18, PRF_CONV_64 = 19, PRF_END = 20, PRF_GEMM_384 = 21, PRF_GEMM_P4 = 22, PRF_GEMM_F8 = 24 };   // 24..31: fp16 + fp8 linear launches by tile configuration
 // tile configuration 8 (the 64 x 64 tile of the small-batch forwards, split-fp16 only) has its own two kinds behind the 0..7 ranges
-static inline int prf_kind(int base, int cfg) { return cfg == GEMM_CFG_P4 ? PRF_GEMM_P4 : cfg == GEMM_CFG_384x192 ? PRF_GEMM_384 : cfg == GEMM_CFG_64 ? (base == PRF_CONV ? PRF_CONV_64 : PRF_GEMM_64) : base + cfg; }
+static inline int prf_kind(int base, int cfg) { return cfg == GEMM_CFG_P4 ? PRF_GEMM_P4 : cfg == GEMM_CFG_384x192 ? PRF_GEMM_384 : (cfg == GEMM_CFG_64 || cfg == GEMM_CFG_96x64) ? (base == PRF_CONV ? PRF_CONV_64 : PRF_GEMM_64) : base + cfg; }
 #define D3R_OTHER(call) do { c.mark(PRF_OTHER, 0.0); c.chk(call); } while (0)
 
 // folded LayerNorm (kernels.hpp GemmParams::ln_*): `stats` = the consumer side (rstd, -mean rstd of the input rows; the Lin carries column sums and

@@ -96,6 +96,10 @@ typedef GemmCfg<2, 2, 2, 2, 4> Cfg64;
 // to hide the load latency of a one-step lookahead (measured: 1 us per K step of 0.1 us of MFMA work, profiles/r03_f). Default: three slots.
 typedef GemmCfg<2, 2, 2, 2, 4, 128, 3> Cfg64s3;
 typedef GemmCfg<2, 2, 2, 2, 2, 128, 4> Cfg64s4;
+// M 96 x N 64 by four waves of 32 (n) x 48 (m) on the three-slot ring (60 KiB; round 6): the small tile is bound by what it pulls out of L2 per flop and by the blocks a
+// CU has to run one after the other -- 1536 x 1024 is 384 tiles of 64 x 64 (a CU in two runs two: 256 operand rows per K step) or exactly 256 of
+// 96 x 64 (one per CU: 160 rows). Tile configuration 11; same K order per output element: bit-identical.
+typedef GemmCfg<2, 2, 2, 3, 4, 128, 3> Cfg96x64;
 // 128 x 128 by EIGHT waves of 64 (n) x 32 (m): twice the waves per tile (16 per CU with two resident blocks) for the mid-size problems of the
 // small-batch forwards, where a K step is bound by latency rather than by the matrix pipe. Bit-identical to the four-wave shape.
 typedef GemmCfg<2, 4, 4, 2, 4> Cfg128w8;
@@ -2039,7 +2043,9 @@ static int device_cus();
 // D3R_GEMM_CFG=0..9: the tile configuration pinned from the environment (parity tests, A/B runs); read per call, -1 = not set
 static int env_forced_cfg() {
     const char* e = getenv("D3R_GEMM_CFG");
-    return (e && e[0] >= '0' && e[0] <= '9' && e[1] == 0) ? e[0] - '0' : -1;
+    if (!e || e[0] < '0' || e[0] > '9') return -1;
+    if (e[1] == 0) return e[0] - '0';
+    return (e[0] == '1' && e[1] == '1' && e[2] == 0) ? GEMM_CFG_96x64 : -1;
 }
 int gemm_p4_mode() {
     const char* e = getenv("D3R_GEMM_PERSIST");
@@ -2066,7 +2072,7 @@ int gemm_pick_config(const GemmParams& p, int dt) {
     int cfg = pick_config_raw(p, dt);
     const bool split = dt == D3R_F16X3 || dt == D3R_F16F8 || dt == D3R_F16X2F8;
     if (cfg == GEMM_CFG_256x128W4 && split) cfg = GEMM_CFG_256x128;
-    if ((cfg == GEMM_CFG_256x128R || cfg == GEMM_CFG_64 || cfg == GEMM_CFG_384x192) && dt != D3R_F16X3) cfg = cfg == GEMM_CFG_256x128R ? GEMM_CFG_256x128 : GEMM_CFG_128;
+    if ((cfg == GEMM_CFG_256x128R || cfg == GEMM_CFG_64 || cfg == GEMM_CFG_96x64 || cfg == GEMM_CFG_384x192) && dt != D3R_F16X3) cfg = cfg == GEMM_CFG_256x128R ? GEMM_CFG_256x128 : GEMM_CFG_128;
     if ((cfg == GEMM_CFG_256S4 || cfg == GEMM_CFG_256PP) && split) cfg = GEMM_CFG_256;
     if (dt == D3R_F16X2F8 && cfg != GEMM_CFG_256) cfg = GEMM_CFG_128;      // the 2.5-unit K loop exists on the two square tiles
     return cfg;
@@ -2081,6 +2087,7 @@ static int pick_config_raw(const GemmParams& p, int dt) {
         forced = env_forced_cfg();
     }
     if (forced == GEMM_CFG_384x192 && dt == D3R_F16X3 && !heads && p.epi != EPI_HEADS && p.epi != EPI_HEAD4 && p.amode == AMODE_LINEAR && cdiv(p.n_store, 192) * 192 <= n_rows) return forced;
+    if (forced == GEMM_CFG_96x64 && dt == D3R_F16X3 && !heads && p.epi != EPI_HEADS && p.epi != EPI_HEAD4) return forced;
     if (forced == GEMM_CFG_128 || forced == GEMM_CFG_64 || (forced == GEMM_CFG_256 && ok256) ||
         ((forced == GEMM_CFG_256x128 || forced == GEMM_CFG_512x128 || forced == GEMM_CFG_256x128W4 || forced == GEMM_CFG_256x128R) && !heads) || ((forced == GEMM_CFG_256S4 || forced == GEMM_CFG_256PP) && ok256))
         return forced;
@@ -2128,7 +2135,20 @@ static int pick_config_raw(const GemmParams& p, int dt) {
     if (dt == D3R_F16X3 && p.n_store > 128) {
         long t64 = 200;
         if (const char* e = probe_env("D3R_GEMM_T64")) t64 = atol(e);
-        if ((long)cdiv(p.M, 128) * cdiv(p.n_store, 128) < t64) return GEMM_CFG_64;
+        if ((long)cdiv(p.M, 128) * cdiv(p.n_store, 128) < t64) {
+            // round 6: M 96 x N 64 instead, where its tiles come to 1.5 ... 2 per CU. The small tiles run at the rate their operand rows arrive: the 96 x 64
+            // shape moves 17 % fewer bytes per flop, but a CU needs two or three resident blocks' worth of loads in flight to keep that rate -- measured on MI355X
+            // (tools/tile_probe.py, profiles/r06_f; 64 x 64 -> 96 x 64, us per launch): 3072 x 1024 x 4096 81 -> 71, 2304 x 1024 x 4096 75 -> 61, 3072 x 768 x 3072 66 -> 53,
+            // 1536 x 1536 x 768 20 -> 18, 768 x 3072 x 768 20 -> 18 (384 or 512 tiles); 1536 x 1024 x 4096 56 -> 61 (256 tiles: one block per CU), 1152 x 768 x 3072 33 -> 40 (144),
+            // 1536 x 2304 x 768 28 -> 30 (576). nn.Linear operands without attention heads only. INSIDE the forward (tools/env_latency_ab.py, same process, rule on | off) the
+            // K = 768 / 1024 cases do not carry over -- one pair 10.04 vs 9.96 ms (the decoder's two sides run side by side: twice the tiles in flight), two pairs 14.49 vs
+            // 14.68 -- so the rule keeps the long K loops only (K >= 2048: fc2 of the encoder at two / three pairs, of the decoder at four).
+            const long t96 = (long)cdiv(p.M, 96) * cdiv(p.n_store, 64);
+            const int cus = device_cus();
+            const char* e96 = probe_env("D3R_GEMM_T96");        // probe builds: 0 = never
+            if (!(e96 && e96[0] == '0') && !heads && p.epi != EPI_HEADS && p.epi != EPI_HEAD4 && p.amode == AMODE_LINEAR && p.K >= 2048 && t96 * 2 >= (long)cus * 3 && t96 <= (long)cus * 2) return GEMM_CFG_96x64;
+            return GEMM_CFG_64;
+        }
     }
     const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.n_store, 256);
     // fp16 + fp8 rows: the 256-wide tile is 1.3-1.6x ahead of the 128 x 128 one per tile (its K loop lost a third of its MFMA work, the small
@@ -2152,7 +2172,7 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
     constexpr bool SPLIT = (DT == D3R_F16X3 || DT == D3R_F16F8 || DT == D3R_F16X2F8);   // split-fp16 and fp16 + fp8 rows need 128-byte K rows, two stages
     if (cfg == GEMM_CFG_256x128W4 && SPLIT) cfg = GEMM_CFG_256x128;
     if (cfg == GEMM_CFG_256x128R && DT != D3R_F16X3) cfg = GEMM_CFG_256x128;      // the weights-in-registers shape exists for split-fp16 only
-    if (cfg == GEMM_CFG_64 && DT != D3R_F16X3) cfg = GEMM_CFG_128;                // the 64 x 64 shape too
+    if ((cfg == GEMM_CFG_64 || cfg == GEMM_CFG_96x64) && DT != D3R_F16X3) cfg = GEMM_CFG_128;                // the 64 x 64 / 96 x 64 shapes too
     if (cfg == GEMM_CFG_384x192 && DT != D3R_F16X3) cfg = GEMM_CFG_128;           // and the 384 x 192 one
     // the fused head tail needs a wave to hold every output channel of its rows: waves stacked along m, 128 columns per wave
     if (p.epi == EPI_HEAD4 && (DT != D3R_F16X3 || !(cfg == GEMM_CFG_512x128 || cfg == GEMM_CFG_256x128R))) return hipErrorInvalidValue;
@@ -2173,6 +2193,7 @@ template <int DT> static hipError_t launch_t(const GemmParams& p, hipStream_t s)
     if constexpr (DT == D3R_F16X3) {
         if (cfg == GEMM_CFG_384x192) return launch_cfg<DT, Cfg384x192>(p, s);
         if (cfg == GEMM_CFG_256x128R) return launch_cfg<DT, Cfg256x128r>(p, s);
+        if (cfg == GEMM_CFG_96x64) return launch_cfg<DT, Cfg96x64>(p, s);
         if (cfg == GEMM_CFG_64) {
             const char* e_ns = probe_env("D3R_GEMM_64NS");     // probe: LDS ring depth of the 64 x 64 tile (2 | 3 | 4)
             const int ns = e_ns ? atoi(e_ns) : 3;             // measured (profiles/r03_f): one pair 14.56 ms on the 128 x 128 tile, 12.36 / 10.38 / 10.48 ms with 2 / 3 / 4 slots

@@ -13,7 +13,7 @@ enum { EPI_T = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_HEADS = 3, EPI_CONVT = 4, EPI_H
 // ldo2 = its pixel stride, res1 = the 1x1 weights [4][n_store] fp32, res2 = its bias [4] fp32. Nothing of the C-channel map is stored.
 enum { HEAD_ROPE = 1, HEAD_VT = 2, HEAD_PLAIN = 3 };
 enum { GF_RELU = 1, GF_NOSTORE = 2, GF_NOWIDE = 4, GF_NTSTORE = 8, GF_X3RES = 16 };   // GF_X3RES (EPI_F32, split-fp16): res1 and the result live in split-fp16 rows only (out2); no fp32 row is stored   // GF_NTSTORE: wide epilogues store with the non-temporal policy (default; D3R_GEMM_NT=0 clears it)
-enum { GEMM_CFG_128 = 0, GEMM_CFG_256 = 1, GEMM_CFG_256x128 = 2, GEMM_CFG_512x128 = 3, GEMM_CFG_256x128W4 = 4, GEMM_CFG_256S4 = 5, GEMM_CFG_256PP = 6, GEMM_CFG_256x128R = 7, GEMM_CFG_64 = 8, GEMM_CFG_384x192 = 9, GEMM_CFG_P4 = 10 };
+enum { GEMM_CFG_128 = 0, GEMM_CFG_256 = 1, GEMM_CFG_256x128 = 2, GEMM_CFG_512x128 = 3, GEMM_CFG_256x128W4 = 4, GEMM_CFG_256S4 = 5, GEMM_CFG_256PP = 6, GEMM_CFG_256x128R = 7, GEMM_CFG_64 = 8, GEMM_CFG_384x192 = 9, GEMM_CFG_P4 = 10, GEMM_CFG_96x64 = 11 };
 
 struct GemmParams {
     const void* act = nullptr;   // [M][lda] (linear) or NHWC image batch (conv), element type DT

@@ -113,7 +113,9 @@ int d3r_build_has_probes(void);
  * d3r_linear; with_residual: an fp32 residual row is added). 0 = 128x128 (eight waves below 1100 tiles in split-fp16), 1 = 256x256,
  * 2 = 256x128, 3 = 512x128, 7 = 256x128 by four waves with a K step's weights in registers (two blocks per CU), 8 = 64x64 on a three-slot
  * ring (problems of fewer than 200 128x128 tiles, split-fp16), 9 = M 384 x N 192 by eight waves of 192 (n) x 48 (m) (split-fp16 nn.Linear launches without
- * attention heads whose tiles fill whole rounds of 256 CUs: the decoder's 24576-row GEMMs of the 32-pair step). The D3R_GEMM_* probe variables apply. DESIGN.md section 4.1. */
+ * attention heads whose tiles fill whole rounds of 256 CUs: the decoder's 24576-row GEMMs of the 32-pair step), 10 = the persistent kernel (gemm_p4.hip: M 256 x N 128, the
+ * epilogue of a tile under the next tile's K loop), 11 = M 96 x N 64 on the three-slot ring (small-batch launches with K >= 2048 whose tiles come to 1.5 ... 2 per CU).
+ * D3R_GEMM_CFG / D3R_GEMM_PERSIST apply. DESIGN.md section 4.1. */
 int d3r_gemm_tile_config(int dtype, int M, int N, int K, int epilogue, int with_residual);
 
 /* ------------------------------------------------------------------------------------------------

@@ -102,14 +102,14 @@ def test_forward_16bit_with_pinned_gemm_tile(gpu, cfg, monkeypatch):
     compare(eng, oracle, v1, v2, *TOLS['fp16'], tag=f'tiny_dpt fp16 128x128 cfg{cfg}')
 
 
-@pytest.mark.parametrize('cfg', ['0', '0w8', '1', '2', '3', '7', '8', '9'])
+@pytest.mark.parametrize('cfg', ['0', '0w8', '1', '2', '3', '7', '8', '9', '11'])
 def test_forward_split_fp16_kernel_variants(gpu, cfg, monkeypatch):
     """fp16x3 (the default, parity-grade mode) at 128x128 = 64 tokens, where the attention projections take the LDS-staged
     x3 epilogue (q / k RoPE scatter, operand-swapped V^T): every (software-pipelined | plain K loop) x (wide | direct epilogue)
     combination within 1e-3 of the oracle, and all of them within 1e-4 of each other (same MFMA order; RoPE / GELU may
     contract differently between the two epilogue routes)."""
     from oracle.dust3r_ref import build_ref_model
-    monkeypatch.setenv('D3R_GEMM_CFG', cfg[0])
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg[:-2] if cfg.endswith(('w8', 'w4')) else cfg)
     monkeypatch.setenv('D3R_GEMM_T128W8', '1000000' if cfg.endswith('w8') else '0')     # '0w8': 128 x 128 by eight waves
     oracle = build_ref_model('tiny_dpt')
     eng = engine_from_oracle(oracle, 'tiny_dpt', 'fp16x3', gpu)

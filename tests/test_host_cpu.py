@@ -395,7 +395,11 @@ def test_gemm_tile_dispatch_table(monkeypatch):
     assert cfg(x3, 6291456, 128, 1152) == 3 and cfg(x3, 196608, 128, 1152) == 2 and cfg(x3, 1000, 96, 768) == 0   # N <= 128: the head's shapes
     # one pair per call = 1536 encoder rows / 768 decoder rows per side: small problems on the 64 x 64 tile, mid-size ones stay on 128 x 128
     assert cfg(x3, 1536, 1024, 4096, F32, 1) == 8 and cfg(x3, 1536, 1024, 1024, F32, 1) == 8 and cfg(x3, 768, 768, 768, F32, 1) == 8
-    assert cfg(x3, 768, 3072, 768, GELU) == 8 and cfg(x3, 1536, 3072, 1024) == 0 and cfg(x3, 1536, 4096, 1024, GELU) == 0
+    assert cfg(x3, 1536, 3072, 1024) == 0 and cfg(x3, 1536, 4096, 1024, GELU) == 0
+    # round 6: M 96 x N 64 (configuration 11) for the long K loops (K >= 2048) whose 96 x 64 tiles come to 1.5 ... 2 per CU -- the encoder's fc2 at two pairs (512 tiles)
+    # and three (384), the decoder's fc2 at four (384); not at one tile per CU (1536 x 1024: 256 tiles stay on 64 x 64), not at K = 768 / 1024 (no gain inside the forward)
+    assert cfg(x3, 3072, 1024, 4096, F32, 1) == 11 and cfg(x3, 2304, 1024, 4096, F32, 1) == 11 and cfg(x3, 3072, 768, 3072, F32, 1) == 11
+    assert cfg(x3, 768, 3072, 768, GELU) == 8 and cfg(x3, 1536, 1536, 768) == 8 and cfg(x3, 1152, 768, 3072, F32, 1) == 8 and cfg(DTYPE_BF16, 3072, 1024, 4096, F32, 1) == 0
     # the small tile exists for split-fp16 only
     assert cfg(DTYPE_BF16, 1536, 1024, 4096, F32, 1) == 0 and cfg(DTYPE_F16F8, 1536, 1024, 4096, F32, 1) == 0
     # fp16 + fp8 rows go to the 256-wide tile from one round of resident blocks on

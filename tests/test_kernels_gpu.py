@@ -67,7 +67,7 @@ def test_linear_epilogues(gpu, dtype, M, N, K):
 
 
 @pytest.mark.parametrize('sw', probe_arms(['1', '0'], ['0']))
-@pytest.mark.parametrize('cfg', ['0', '0w8', '1', '2', '3', '7', '8', '9'])
+@pytest.mark.parametrize('cfg', ['0', '0w8', '1', '2', '3', '7', '8', '9', '11'])
 @pytest.mark.parametrize('M,N,K', [(300, 192, 256), (1000, 3072, 1024), (77, 96, 768), (2100, 1032, 32), (515, 328, 64)])
 def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
     """The parity-grade precision mode (fp16x3: operands split into fp16 hi + lo, three MFMAs per product) at kernel level:
@@ -79,7 +79,7 @@ def test_linear_split_fp16(gpu, M, N, K, cfg, sw, monkeypatch):
     from conftest import need_probes
     if sw == '1':
         need_probes('the software-pipelined K loop')
-    monkeypatch.setenv('D3R_GEMM_CFG', cfg[0])
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg[:-2] if cfg.endswith(('w8', 'w4')) else cfg)
     monkeypatch.setenv('D3R_GEMM_T128W8', '1000000' if cfg.endswith('w8') else '0')     # '0w8': the 128 x 128 tile by eight waves (small-batch forwards)
     monkeypatch.setenv('D3R_GEMM_X3SW', sw)
     g = torch.Generator(device='cpu').manual_seed(M * 7 + N)
@@ -162,7 +162,7 @@ def test_linear_fp16_fp8(gpu, M, N, K, cfg, monkeypatch):
     from conftest import need_probes
     if cfg.endswith('w4'):
         need_probes('the four-wave 256 x 128 fp16 + fp8 tile')
-    monkeypatch.setenv('D3R_GEMM_CFG', cfg[0])
+    monkeypatch.setenv('D3R_GEMM_CFG', cfg[:-2] if cfg.endswith(('w8', 'w4')) else cfg)
     monkeypatch.setenv('D3R_GEMM_F8W4', '1' if cfg.endswith('w4') else '0')
     g = torch.Generator(device='cpu').manual_seed(M * 7 + N)
     a = torch.randn((M, K), generator=g).to(gpu)

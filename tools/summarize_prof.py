@@ -76,7 +76,7 @@ for tag in ('pmc_sq1', 'pmc_sq2'):
 # ---- machine-readable digest for bench.py's roofline.traffic (copied by hand to profiles/pmc_latest.json) ------------------
 import json  # noqa: E402
 
-CFG_OF = {(1, 8, 12, 3, 2, 128, 2, 0): 9, (2, 2, 2, 2, 4, 128, 3, 0): 8, (2, 4, 4, 2, 4, 128, 2, 0): 0, (2, 2, 4, 4, 2, 128, 2, 0): 0, (2, 4, 8, 4, 2, 128, 2, 0): 1, (2, 4, 4, 4, 2, 128, 2, 0): 2, (1, 8, 8, 4, 2, 128, 2, 0): 3,
+CFG_OF = {(1, 8, 12, 3, 2, 128, 2, 0): 9, (2, 2, 2, 2, 4, 128, 3, 0): 8, (2, 2, 2, 3, 4, 128, 3, 0): 8, (2, 4, 4, 2, 4, 128, 2, 0): 0, (2, 2, 4, 4, 2, 128, 2, 0): 0, (2, 4, 8, 4, 2, 128, 2, 0): 1, (2, 4, 4, 4, 2, 128, 2, 0): 2, (1, 8, 8, 4, 2, 128, 2, 0): 3,
           (1, 4, 8, 4, 2, 64, 3, 0): 4, (2, 4, 8, 4, 2, 64, 4, 0): 5,
           (2, 2, 4, 4, 2, 128, 2): 0, (2, 4, 8, 4, 2, 128, 2): 1, (2, 4, 4, 4, 2, 128, 2): 2, (1, 8, 8, 4, 2, 128, 2): 3,
           (1, 4, 8, 4, 2, 64, 3): 4, (2, 4, 8, 4, 2, 64, 4): 5, (2, 4, 8, 4, 2, 64, 4, 1): 6,

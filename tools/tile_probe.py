@@ -31,6 +31,8 @@ def timeit(fn, warm=2, reps=8):
 SHAPES = [(49152, 4096, 1024, 2, 'enc fc1 + GELU'), (49152, 3072, 1024, 0, 'enc qkv-sized plain store'), (49152, 1024, 1024, 3, 'enc proj + typed residual + sums'),
           (49152, 1024, 4096, 3, 'enc fc2 + typed residual + sums'), (24576, 3072, 768, 2, 'dec fc1 + GELU'), (24576, 768, 768, 3, 'dec proj + typed residual + sums'),
           (24576, 768, 3072, 3, 'dec fc2 + typed residual + sums'), (24576, 2304, 768, 0, 'dec qkv-sized plain store')]
+if os.environ.get('D3R_PROBE_CUSTOM'):        # "M,N,K,epi;M,N,K,epi;..." instead of the 32-pair step's shapes (e.g. the one-pair call's: 1536,1024,4096,3)
+    SHAPES = [tuple(int(x) for x in t.split(',')) + (f'custom {t}',) for t in os.environ['D3R_PROBE_CUSTOM'].split(';')]
 if os.environ.get('D3R_PROBE_SHAPES'):
     SHAPES = [SHAPES[int(i)] for i in os.environ['D3R_PROBE_SHAPES'].split(',')]
 
