@@ -598,7 +598,9 @@ template <int EPK, int NF, bool L32 = false, int DBG = 0> static hipError_t laun
     if (const char* e = probe_env("D3R_P4_GRID")) { const int g = atoi(e); if (g >= 8 && g < grid) grid = g; }      // probe: fewer resident blocks (more tiles per block)
     grid &= ~7;                          // XCD-contiguous tile ranges need the grid stride to keep a block on its XCD (v & 7 == blockIdx & 7)
     if (grid < 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((p4::gemm_p4_kernel<EPK, NF, L32, DBG>), dim3(grid), dim3(p4::NT), p4::LDS, s, p, tiles_m, tiles_n, ntiles);
+    GemmParams q = p;
+    if (const char* e = probe_env("D3R_P4_PANEL")) { const int v = atoi(e); if (v >= 1 && v <= 64) q.panel = v; }      // probe: width in tiles of the column panels of the tile walk
+    hipLaunchKernelGGL((p4::gemm_p4_kernel<EPK, NF, L32, DBG>), dim3(grid), dim3(p4::NT), p4::LDS, s, q, tiles_m, tiles_n, ntiles);
     return hipGetLastError();
 }
 

@@ -280,7 +280,8 @@ def test_pnp_batch_host_logic(monkeypatch):
 
 def test_dlt_pose_batch_equals_the_per_set_solver():
     """pnp.dlt_pose_batch (one batched eigh / svd for all hypotheses of an initialisation) against pnp._dlt_pose per set: sets of 6..12 selected
-    points out of 48 candidates, a set with too few points, a set behind the camera, a set with a non-finite point."""
+    points out of 48 candidates, a set with too few points, a set behind the camera, a set with a non-finite selected point, and sets
+    whose UNSELECTED candidates are non-finite (they must stay valid)."""
     from dust3r_amd.cloud_opt import pnp
     from dust3r_amd.synthetic import _axis_angle_R
     rng = np.random.RandomState(3)
@@ -294,7 +295,11 @@ def test_dlt_pose_batch_equals_the_per_set_solver():
         ok = rng.rand(p) < 0.6
         sel[k] = ok & (np.cumsum(ok) <= (4 if k == 7 else 6 + k % 7))                                       # set 7: four points only
     X[9, np.nonzero(sel[9])[0][0]] = np.nan
+    # non-finite UNSELECTED candidates (low-confidence pixels of a window the scalar path never reads) must not reject their hypothesis: NaN * 0 is NaN
+    X[11, np.nonzero(~sel[11])[0][0]] = np.nan
+    xn[12, np.nonzero(~sel[12])[0][1]] = np.inf
     R, T, good = pnp.dlt_pose_batch(X, xn, sel)
+    assert good[11] and good[12]
     for k in range(b):
         idx = np.nonzero(sel[k])[0]
         one = pnp._dlt_pose(X[k, idx], xn[k, idx]) if len(idx) >= 6 else None
