@@ -142,3 +142,32 @@ def test_validate_checkpoint_tool_on_a_synthetic_checkpoint(gpu, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert 'missing keys [] (0), unexpected [] (0)' in r.stdout
     assert r.stdout.count('[PASS at 1e-3 / conf 3e-3]') == 2
+
+
+def test_validate_checkpoint_tool_on_a_synthetic_hub_snapshot(gpu, tmp_path):
+    """The same harness on a hub SNAPSHOT DIRECTORY (what PyTorchModelHubMixin.from_pretrained reads, dust3r/model.py:76-85; `DUST3R_CKPT=<dir> python bench.py` runs exactly
+    this first): config.json with lists / Infinity / ManyAR patch embed / freeze, model.safetensors with ONE name per shared tensor (the DPT head's layer_rn convolutions)
+    and no dec_blocks2 keys. Oracle and engine both load it key for key and every precision passes the bar."""
+    import json
+    import re
+    import subprocess
+    import sys
+    from safetensors.torch import save_file
+    from dust3r_amd.synthetic import MODEL_CONFIGS
+    from oracle.dust3r_ref import build_ref_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = dict(MODEL_CONFIGS['tiny_dpt'])
+    oracle = build_ref_model('tiny_dpt')
+    state = {k: v.detach().contiguous().clone() for k, v in oracle.state_dict().items() if not re.search(r'scratch\.layer\d_rn\.', k) and not k.startswith('dec_blocks2')}
+    snap = tmp_path / 'snapshot'
+    snap.mkdir()
+    cfg_json = {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}
+    cfg_json.update(landscape_only=False, patch_embed_cls='ManyAR_PatchEmbed', freeze='none', depth_mode=['exp', float('-inf'), float('inf')], conf_mode=['exp', 1, float('inf')])
+    (snap / 'config.json').write_text(json.dumps(cfg_json))
+    save_file(state, str(snap / 'model.safetensors'))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'validate_checkpoint.py'), str(snap), '--size', '96x64', '--pairs', '1', '--precision', 'fp16x3,fp32'],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert 'missing keys [] (0), unexpected [] (0)' in r.stdout
+    assert r.stdout.count('[PASS at 1e-3 / conf 3e-3]') == 2

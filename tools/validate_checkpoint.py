@@ -58,6 +58,10 @@ def load_oracle(path):
             m = re.search(r'scratch\.layer(\d)_rn\.', k)
             if m:
                 state.setdefault(k.replace(f'scratch.layer{m.group(1)}_rn.', f'scratch.layer_rn.{int(m.group(1)) - 1}.'), state[k])
+        if not any(k.startswith('dec_blocks2') for k in state):        # dust3r/model.py:91-98
+            for k, v in list(state.items()):
+                if k.startswith('dec_blocks'):
+                    state[k.replace('dec_blocks', 'dec_blocks2')] = v
         res = oracle.load_state_dict(state, strict=False)
         return oracle, kw, res
     ckpt = torch.load(path, map_location='cpu', weights_only=False)
