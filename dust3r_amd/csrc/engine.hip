@@ -444,6 +444,16 @@ void gemm_heads(Ctx& c, const void* act, int lda, const Lin& L, int M, int head_
     p.epi = EPI_HEADS; p.head_c = head_c;
     for (int i = 0; i < nreg; ++i) { p.head_kind[i] = kinds[i]; p.head_dst[i] = dsts[i]; }
     p.heads = heads; p.ntok = ntok; p.tok_w = tok_w; p.ldv = ldv; p.rope_table = c.m->rope_table;
+    if constexpr (kProbes) {    // measurement aids, results INVALID (tools/launch_table.py): what the V^T scatter / the RoPE of the attention projections' epilogue cost --
+        // D3R_PROBE_V_PLAIN=1 stores the V region row-major like K (the GEMM side of a design whose attention kernel transposes V with ds_read_b64_tr_b16),
+        // D3R_PROBE_QK_PLAIN=1 stores q / k without the rotation
+        const char* ev = probe_env("D3R_PROBE_V_PLAIN");
+        const char* eq = probe_env("D3R_PROBE_QK_PLAIN");
+        for (int i = 0; i < nreg; ++i) {
+            if (ev && ev[0] == '1' && p.head_kind[i] == HEAD_VT) p.head_kind[i] = HEAD_PLAIN;
+            if (eq && eq[0] == '1' && p.head_kind[i] == HEAD_ROPE) p.head_kind[i] = HEAD_PLAIN;
+        }
+    }
     c.mark(prf_kind((L.dt == D3R_F16F8 || L.dt == D3R_F16X2F8) ? PRF_GEMM_F8 : PRF_GEMM, gemm_pick_config(p, L.dt)), 2.0 * M * (double)L.N * L.K, M, L.N, L.K);
     c.chk(launch_gemm(L.dt, p, c.st));
 }
