@@ -54,13 +54,21 @@ ALIGN_SCENE = dict(n_views=7, H=96, W=128, seed=3, scene_graph='complete', symme
 ALIGN_NITER = 40
 
 
-def aligned_scene(gpu, group, init):
+def aligned_scene(gpu, group, init, seed=11):
     import torch
     from dust3r_amd.cloud_opt import GlobalAlignerMode, global_aligner
     from dust3r_amd.synthetic import synthetic_scene
     out, state, _ = synthetic_scene(device=gpu, **ALIGN_SCENE)
-    torch.manual_seed(11)                                    # the random start of init=None (every process draws the same; rank 0's is broadcast anyway)
+    torch.manual_seed(seed)                                  # the random start of init=None (every process draws the same; rank 0's is broadcast anyway)
     scene = global_aligner(out, device=gpu, mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False)
+    if init == 'frozen':
+        # a DIFFERENT random start per rank (seed) with the focals frozen and not preset: the frozen tensor must come from rank 0 like the trainable ones,
+        # or the replicated pose step diverges silently between ranks (round-5 advisor item)
+        scene.im_focals.requires_grad_(False)
+        loss = scene.compute_global_alignment(init=None, niter=12, schedule='linear', lr=0.01, group=group)
+        res = {k: getattr(scene, k).detach().cpu().clone() for k in ('pw_poses', 'pw_adaptors', 'im_poses', 'im_depthmaps', 'im_focals', 'im_pp')}
+        res['loss'] = float(loss)
+        return res
     if init == 'state':
         scene.load_state_dict(state)
         loss = scene.compute_global_alignment(init=None, niter=ALIGN_NITER, schedule='cosine', lr=0.01, group=group)
@@ -80,6 +88,7 @@ def align_worker(rank, world, port, outdir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         out = {init: aligned_scene(gpu, True, init) for init in ('state', 'mst')}
+        out['frozen'] = aligned_scene(gpu, True, 'frozen', seed=100 + rank)
         torch.save(out, os.path.join(outdir, f'align_rank{rank}.pt'))
         dist.barrier()
     finally:

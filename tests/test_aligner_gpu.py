@@ -500,4 +500,10 @@ def test_alignment_loop_over_ranks_is_bit_identical_to_one_gpu(gpu, tmp_path, wo
             assert got[init]['loss'] == ref[init]['loss'], (r, init, got[init]['loss'], ref[init]['loss'])
             for k in ('pw_poses', 'im_poses', 'im_focals', 'im_depthmaps'):
                 assert torch.equal(got[init][k], ref[init][k]), (r, init, k, float((got[init][k] - ref[init][k]).abs().max()))
+    # every rank started from its OWN random draw with frozen, un-preset focals: all six parameter tensors are rank 0's after the loop's broadcast, so the ranks agree bit for bit
+    fz = [torch.load(os.path.join(str(tmp_path), f'align_rank{r}.pt'), weights_only=False)['frozen'] for r in range(world)]
+    for r in range(1, world):
+        assert fz[r]['loss'] == fz[0]['loss']
+        for k in ('pw_poses', 'pw_adaptors', 'im_poses', 'im_depthmaps', 'im_focals', 'im_pp'):
+            assert torch.equal(fz[r][k], fz[0][k]), (r, k)
     assert ref['state']['loss'] < 0.1 and ref['mst']['loss'] < 0.1
